@@ -1,0 +1,246 @@
+"""founder-sequences_amd: MI355X-native segmentation engine (host-side Python mirror of the C ABI).
+
+The compute lives in libfseq_hip.so (hand-written HIP for gfx950, built in-tree by build.py) behind
+the C ABI declared in include/fseq.h.  This module is a thin ctypes mirror of that ABI, named after
+the reference's interface for the path (segmentation_lp_context / segmentation_container,
+include/founder_sequences/segmentation_lp_context.hh:45-121, segmentation_container.hh:15-20).
+
+There is NO CPU fallback: if the library is missing, or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfseq_hip.so")
+
+FSEQ_OK, FSEQ_E_ARG, FSEQ_E_NO_REDUCTION, FSEQ_E_HIP, FSEQ_E_OOM, FSEQ_E_UNSUPPORTED = range(6)
+
+
+class FseqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("fseq error %d: %s" % (code, msg))
+        self.code = code
+
+
+class NoReduction(FseqError):
+    """generate_context.cc:192-200: max segment size equals the number of input sequences."""
+
+
+class Params(C.Structure):
+    _fields_ = [("m", C.c_uint32), ("n", C.c_uint64), ("segment_length", C.c_uint64),
+                ("pbwt_sample_rate", C.c_uint64), ("block_len", C.c_uint32), ("list_cap", C.c_uint32),
+                ("device", C.c_int32)]
+
+
+class SynthSpec(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("n_founders", C.c_uint32), ("block_len", C.c_uint32),
+                ("mut_threshold", C.c_uint64), ("kind", C.c_uint32)]
+
+
+class Segment(C.Structure):
+    _fields_ = [("lb", C.c_uint64), ("rb", C.c_uint64), ("segment_size", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class DpArg(C.Structure):
+    _fields_ = [("lb", C.c_uint64), ("rb", C.c_uint64), ("segment_max_size", C.c_uint32), ("segment_size", C.c_uint32)]
+
+
+class Result(C.Structure):
+    _fields_ = [("max_segment_size", C.c_uint32), ("short_path", C.c_uint32),
+                ("dp_segment_count", C.c_uint64), ("segment_count", C.c_uint64)]
+
+
+class Timings(C.Structure):
+    _fields_ = [("ms_total", C.c_double), ("ms_phase_a", C.c_double), ("ms_phase_b", C.c_double),
+                ("ms_phase_c", C.c_double), ("ms_dp", C.c_double), ("ms_pass2", C.c_double), ("ms_host", C.c_double),
+                ("ms_colstep_kernels", C.c_double), ("colstep_launches", C.c_uint64), ("colstep_cells", C.c_uint64),
+                ("pass2_cells", C.c_uint64), ("list_cap_used", C.c_uint32), ("retries", C.c_uint32),
+                ("block_len", C.c_uint32), ("n_blocks", C.c_uint32)]
+
+
+SEGMENT_DTYPE = np.dtype([("lb", "<u8"), ("rb", "<u8"), ("segment_size", "<u4"), ("reserved", "<u4")])
+DPARG_DTYPE = np.dtype([("lb", "<u8"), ("rb", "<u8"), ("segment_max_size", "<u4"), ("segment_size", "<u4")])
+
+# every symbol include/fseq.h declares
+EXPORTS = [
+    "fseq_abi_version", "fseq_strerror", "fseq_create", "fseq_destroy", "fseq_last_error",
+    "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
+    "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
+    "fseq_short_path_runs", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libfseq_hip.so; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run `python __graft_entry__.py build` (hipcc --offload-arch=gfx950); "
+                          "there is no CPU fallback for the segmentation path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, u64, sz = C.c_void_p, C.c_uint64, C.c_size_t
+    L.fseq_abi_version.restype = C.c_uint32
+    L.fseq_strerror.restype = C.c_char_p
+    L.fseq_strerror.argtypes = [C.c_int]
+    L.fseq_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
+    L.fseq_destroy.argtypes = [vp]
+    L.fseq_destroy.restype = None
+    L.fseq_last_error.restype = C.c_char_p
+    L.fseq_last_error.argtypes = [vp]
+    L.fseq_set_rows.argtypes = [vp, C.POINTER(vp)]
+    L.fseq_set_matrix.argtypes = [vp, vp, sz, sz]
+    L.fseq_set_device_columns.argtypes = [vp, vp, sz, C.c_uint32]
+    L.fseq_generate_synthetic.argtypes = [vp, C.POINTER(SynthSpec)]
+    L.fseq_get_matrix.argtypes = [vp, u64, u64, vp, sz, sz]
+    L.fseq_run_segmentation.argtypes = [vp, C.POINTER(Result)]
+    L.fseq_get_traceback.argtypes = [vp, vp]
+    L.fseq_get_segments.argtypes = [vp, vp]
+    L.fseq_boundary_state.argtypes = [vp, u64, vp, vp]
+    L.fseq_short_path_runs.argtypes = [vp, vp, vp]
+    L.fseq_debug_dp.argtypes = [vp, vp, vp, vp]
+    L.fseq_debug_block_state.argtypes = [vp, u64, vp, vp]
+    L.fseq_debug_column_list.argtypes = [vp, u64, vp, vp, vp, vp, vp]
+    L.fseq_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    _lib = L
+    return L
+
+
+def synth_threshold(mu):
+    """mu * 2^64 as the generator's integer threshold (same rounding as the C implementations)."""
+    if mu <= 0.0:
+        return 0
+    if mu >= 1.0:
+        return 0xFFFFFFFFFFFFFFFF
+    return int(mu * 18446744073709551616.0)
+
+
+class SegmentationContext:
+    """Mirror of segmentation_lp_context / segmentation_sp_context behind the C ABI.
+
+    generate_traceback + update_samples_to_traceback_positions + find_segments_greedy
+    (segmentation_lp_context.hh:119-121) are one call here: run().  The result fields mirror
+    segmentation_container (reduced_traceback, reduced_pbwt_samples via boundary_state(),
+    max_segment_size)."""
+
+    def __init__(self, m, n, segment_length, pbwt_sample_rate=0, block_len=0, list_cap=0, device=0):
+        self.L = load_library()
+        self.m, self.n, self.segment_length = int(m), int(n), int(segment_length)
+        p = Params(self.m, self.n, self.segment_length, int(pbwt_sample_rate), int(block_len), int(list_cap), int(device))
+        h = C.c_void_p()
+        rc = self.L.fseq_create(C.byref(p), C.byref(h))
+        if rc != FSEQ_OK:
+            raise FseqError(rc, self.L.fseq_strerror(rc).decode())
+        self.h = h
+        self.result = None
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fseq_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc == FSEQ_OK:
+            return
+        msg = self.L.fseq_last_error(self.h).decode() or self.L.fseq_strerror(rc).decode()
+        if rc == FSEQ_E_NO_REDUCTION:
+            raise NoReduction(rc, msg)
+        raise FseqError(rc, msg)
+
+    # ---- input (delegate->sequences(), delegate->alphabet())
+    def set_sequences(self, msa):
+        """msa: uint8 array [m, n] of raw symbol bytes, any memory order."""
+        assert msa.dtype == np.uint8 and msa.shape == (self.m, self.n)
+        self._check(self.L.fseq_set_matrix(self.h, msa.ctypes.data, msa.strides[0], msa.strides[1]))
+
+    def set_device_columns(self, ptr, ld, sigma, keepalive=None):
+        self._keep = keepalive
+        self._check(self.L.fseq_set_device_columns(self.h, ptr, ld, sigma))
+
+    def generate_synthetic(self, seed, n_founders, block_len, mu, kind=0):
+        s = SynthSpec(seed, n_founders, block_len, synth_threshold(mu), kind)
+        self._check(self.L.fseq_generate_synthetic(self.h, C.byref(s)))
+
+    def get_sequences(self, c0=0, c1=None):
+        c1 = self.n if c1 is None else c1
+        out = np.zeros((self.m, c1 - c0), dtype=np.uint8, order="F")
+        self._check(self.L.fseq_get_matrix(self.h, c0, c1, out.ctypes.data, out.strides[0], out.strides[1]))
+        return out
+
+    # ---- the path
+    def run(self):
+        res = Result()
+        rc = self.L.fseq_run_segmentation(self.h, C.byref(res))
+        self.result = res
+        self._check(rc)
+        return res
+
+    @property
+    def max_segment_size(self):
+        return self.result.max_segment_size
+
+    def traceback(self):
+        out = np.zeros(self.result.dp_segment_count, dtype=DPARG_DTYPE)
+        if len(out):
+            self._check(self.L.fseq_get_traceback(self.h, out.ctypes.data))
+        return out
+
+    def reduced_traceback(self):
+        out = np.zeros(self.result.segment_count, dtype=SEGMENT_DTYPE)
+        if len(out):
+            self._check(self.L.fseq_get_segments(self.h, out.ctypes.data))
+        return out
+
+    def boundary_state(self, i):
+        """(input_permutation, input_divergence) of reduced_pbwt_samples[i]."""
+        a = np.zeros(self.m, dtype=np.uint32)
+        d = np.zeros(self.m, dtype=np.uint32)
+        self._check(self.L.fseq_boundary_state(self.h, i, a.ctypes.data, d.ctypes.data))
+        return a, d
+
+    def short_path_runs(self):
+        k = self.result.max_segment_size
+        f = np.zeros(k, dtype=np.uint32)
+        r = np.zeros(k, dtype=np.uint32)
+        self._check(self.L.fseq_short_path_runs(self.h, f.ctypes.data, r.ctypes.data))
+        return f, r
+
+    # ---- debug / parity of intermediate state
+    def debug_dp(self):
+        k = self.n - self.segment_length + 1
+        lb = np.zeros(k, dtype=np.uint32)
+        mx = np.zeros(k, dtype=np.uint32)
+        sz = np.zeros(k, dtype=np.uint32)
+        self._check(self.L.fseq_debug_dp(self.h, lb.ctypes.data, mx.ctypes.data, sz.ctypes.data))
+        return lb, mx, sz
+
+    def debug_block_state(self, b):
+        a = np.zeros(self.m, dtype=np.uint32)
+        d = np.zeros(self.m, dtype=np.uint32)
+        self._check(self.L.fseq_debug_block_state(self.h, b, a.ctypes.data, d.ctypes.data))
+        return a, d
+
+    def debug_column_list(self, col):
+        cap = self.m + 2
+        v = np.zeros(cap, dtype=np.uint32)
+        c = np.zeros(cap, dtype=np.uint32)
+        ne, c0, comp = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._check(self.L.fseq_debug_column_list(self.h, col, v.ctypes.data, c.ctypes.data,
+                                                  C.byref(ne), C.byref(c0), C.byref(comp)))
+        return v[:ne.value].copy(), c[:ne.value].copy(), c0.value, bool(comp.value)
+
+    def timings(self):
+        t = Timings()
+        self._check(self.L.fseq_get_timings(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in Timings._fields_}

@@ -1,0 +1,820 @@
+// fseq_api.hip -- C ABI (include/fseq.h) + host orchestration of the HIP segmentation path.
+//
+// Host side of what segmentation_lp_context drives through libdispatch queues
+// (founder-sequences/segmentation_lp_context.cc:26-390): here one HIP stream, kernels per phase,
+// and only the O(S) pieces (traceback walk lp.cc:191-224, segment merge lp.cc:335-390) on the CPU.
+// There is deliberately NO CPU fallback for the column work: if the device or a kernel shape is
+// unavailable the call fails with an error code.
+#include "../../include/fseq.h"
+#include "fseq_kernels.hpp"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace fseq;
+
+namespace {
+
+struct KernelSet {
+	uint32_t T, E, sigma, cap;
+	size_t lds_colblock;
+	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
+	             uint32_t *, uint32_t *, uint32_t *);
+	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
+	             uint32_t const *, uint32_t const *, uint64_t const *, uint32_t *, uint32_t *);
+	size_t (*columns_lds)(uint32_t B);
+	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
+	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint2 *, uint4 *);
+	size_t lds_chain;
+	void (*chain)(hipStream_t, size_t lds, uint32_t const *, uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t *, uint32_t *);
+	hipError_t (*prepare)(size_t lds_columns);
+};
+
+template <typename K>
+hipError_t allow_lds(K kernel, size_t bytes)
+{
+	if (bytes <= 64 * 1024) return hipSuccess;
+	return hipFuncSetAttribute(reinterpret_cast<void const *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+}
+
+template <int T, int E, int SIGMA>
+struct Launch {
+	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+	                 uint32_t nblocks, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
+	{
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, rank_, keyd, nkeys,
+		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr);
+	}
+	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+	                 uint32_t nblocks, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint32_t *sa, uint32_t *sd)
+	{
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks,
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, sa, sd);
+	}
+	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA>(B); }
+	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr)
+	{
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, X, stride, ent, hdr);
+	}
+	static void chain(hipStream_t st, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
+	                  uint32_t nblocks, uint32_t *ba, uint32_t *bd)
+	{
+		hipLaunchKernelGGL((k_chain<T, E>), dim3(1), dim3(T), lds, st, rank_, keyd, nkeys, m, nblocks, ba, bd);
+	}
+	static hipError_t prepare(size_t lds_columns)
+	{
+		hipError_t e;
+		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK>, colblock_lds_bytes<T, E, SIGMA>())) != hipSuccess) return e;
+		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP>, colblock_lds_bytes<T, E, SIGMA>())) != hipSuccess) return e;
+		if ((e = allow_lds(k_columns<T, E, SIGMA>, lds_columns)) != hipSuccess) return e;
+		if ((e = allow_lds(k_chain<T, E>, chain_lds_bytes<T, E>())) != hipSuccess) return e;
+		return hipSuccess;
+	}
+	static KernelSet make()
+	{
+		KernelSet k;
+		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
+		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA>();
+		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns;
+		k.lds_chain = chain_lds_bytes<T, E>();
+		k.chain = &chain; k.prepare = &prepare;
+		return k;
+	}
+};
+
+bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
+{
+#define FSEQ_TRY(T_, E_)                                                             \
+	if (m <= (uint32_t) (T_) * (E_))                                                 \
+	{                                                                                \
+		*out = (sigma <= 4) ? Launch<T_, E_, 4>::make() : Launch<T_, E_, 16>::make(); \
+		return true;                                                                 \
+	}
+	if (sigma > 16) return false;
+	FSEQ_TRY(64, 1)
+	FSEQ_TRY(64, 7)
+	FSEQ_TRY(256, 5)
+	FSEQ_TRY(256, 11)
+	FSEQ_TRY(1024, 7)
+#undef FSEQ_TRY
+	return false;
+}
+
+constexpr size_t LDS_LIMIT = 160 * 1024;
+
+double now_ms()
+{
+	using namespace std::chrono;
+	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+struct fseq_ctx {
+	fseq_params p{};
+	hipStream_t stream = nullptr;
+	std::string err;
+
+	// input
+	uint8_t *d_msa = nullptr;
+	size_t ld = 0;
+	bool own_msa = false;
+	bool have_input = false;
+	uint32_t sigma = 0;
+	uint8_t code_to_byte[256]{};
+
+	// geometry
+	uint32_t B = 0, nblocks = 0, N2 = 0;
+	KernelSet ks{};
+	bool kernels_ready = false;
+	size_t lds_columns = 0;
+
+	// device work buffers
+	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
+	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
+	uint2 *d_ent = nullptr;
+	uint4 *d_hdr = nullptr;
+	uint32_t X = 0, stride = 0;
+	DpArrays dp{};
+	uint32_t *d_flags = nullptr;
+	uint64_t dp_size = 0;
+	uint64_t *d_cols = nullptr;           // scratch: column / rb lists
+	size_t cols_cap = 0;
+	uint2 *d_gent = nullptr;
+	uint4 *d_ghdr = nullptr;
+	size_t gather_cap = 0, gather_stride = 0;
+	uint32_t *d_snap_a = nullptr, *d_snap_d = nullptr;
+	size_t snap_cap = 0;
+
+	// results
+	bool have_result = false;
+	fseq_result res{};
+	std::vector<uint32_t> h_LB, h_M, h_SZ;
+	std::vector<fseq_dp_arg> traceback;
+	std::vector<fseq_segment> segments;
+	std::vector<uint32_t> sp_first, sp_len;
+	fseq_timings tm{};
+	hipEvent_t ev[8]{};
+};
+
+namespace {
+
+int fail(fseq_ctx *c, int code, char const *what, hipError_t e = hipSuccess)
+{
+	char buf[512];
+	if (e != hipSuccess)
+		snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+	else
+		snprintf(buf, sizeof(buf), "%s", what);
+	c->err = buf;
+	return code;
+}
+
+#define HIP_TRY(c, expr)                                                   \
+	do {                                                                   \
+		hipError_t e_ = (expr);                                            \
+		if (e_ != hipSuccess) return fail((c), FSEQ_E_HIP, #expr, e_);     \
+	} while (0)
+
+template <typename U>
+int dev_alloc(fseq_ctx *c, U **p, size_t count)
+{
+	if (*p) { (void) hipFree(*p); *p = nullptr; }
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(U));
+	if (e != hipSuccess)
+	{
+		*p = nullptr;
+		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, "hipMalloc", e);
+	}
+	return FSEQ_OK;
+}
+
+template <typename U>
+void dev_free(U **p)
+{
+	if (*p) { (void) hipFree(*p); *p = nullptr; }
+}
+
+void free_msa(fseq_ctx *c)
+{
+	if (c->own_msa) dev_free(&c->d_msa);
+	c->d_msa = nullptr;
+	c->own_msa = false;
+	c->have_input = false;
+}
+
+int alloc_msa(fseq_ctx *c)
+{
+	free_msa(c);
+	c->ld = ((size_t) c->p.m + 15) & ~size_t(15);
+	int rc = dev_alloc(c, &c->d_msa, c->ld * c->p.n + 16);
+	if (rc) return rc;
+	c->own_msa = true;
+	return FSEQ_OK;
+}
+
+uint32_t auto_block_len(uint64_t n)
+{
+	uint64_t b = (n + 1023) / 1024;
+	if (b < 16) b = 16;
+	if (b > 4096) b = 4096;
+	return (uint32_t) b;
+}
+
+int prepare_geometry(fseq_ctx *c)
+{
+	fseq_params const &p = c->p;
+	c->B = p.block_len ? p.block_len : auto_block_len(p.n);
+	if (c->B > p.n) c->B = (uint32_t) p.n;
+	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
+	uint32_t n2 = 1;
+	while (n2 < p.m) n2 <<= 1;
+	if (n2 < 2) n2 = 2;
+	c->N2 = n2;
+	if (!select_kernels(p.m, c->sigma, &c->ks))
+		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 7168, sigma <= 16 in this build)");
+	c->lds_columns = c->ks.columns_lds(c->B);
+	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT)
+		return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
+	HIP_TRY(c, c->ks.prepare(c->lds_columns));
+	c->kernels_ready = true;
+	return FSEQ_OK;
+}
+
+int ensure_work_buffers(fseq_ctx *c, uint32_t X)
+{
+	fseq_params const &p = c->p;
+	size_t const m = p.m;
+	int rc;
+	if (!c->d_rank)
+	{
+		if ((rc = dev_alloc(c, &c->d_rank, (size_t) c->nblocks * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_keyd, (size_t) c->nblocks * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_nkeys, c->nblocks))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bstate_a, ((size_t) c->nblocks + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_bstate_d, ((size_t) c->nblocks + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
+		if ((rc = dev_alloc(c, &c->d_flags, 4))) return rc;
+		if (p.n >= 2 * p.segment_length)
+		{
+			c->dp_size = p.n - p.segment_length + 1;
+			c->dp.tstride = (uint32_t) (c->dp_size / 64 + 2);
+			if ((rc = dev_alloc(c, &c->dp.M, c->dp_size))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.LB, c->dp_size))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.SZ, c->dp_size))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.P, c->dp_size))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.S, c->dp_size + 64))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.Tb, (size_t) 32 * c->dp.tstride))) return rc;
+		}
+	}
+	if (!c->d_ent || c->X != X)
+	{
+		c->X = X;
+		c->stride = (X + 1 + 1) & ~1u;            // X+1 entries, even
+		if ((rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride))) return rc;
+	}
+	return FSEQ_OK;
+}
+
+void free_work(fseq_ctx *c)
+{
+	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
+	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
+	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
+	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.P); dev_free(&c->dp.S); dev_free(&c->dp.Tb);
+	dev_free(&c->d_cols); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
+	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d);
+	c->cols_cap = c->gather_cap = c->snap_cap = 0;
+}
+
+int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t cs)
+{
+	fseq_params const &p = c->p;
+	bool present[256] = {false};
+	for (uint32_t r = 0; r < p.m; ++r)
+	{
+		uint8_t const *row = base + (size_t) r * rs;
+		for (uint64_t col = 0; col < p.n; ++col) present[row[col * cs]] = true;
+	}
+	// consecutive_alphabet_as_builder: dense codes in ascending byte order (generate_context.cc:135-147, A2)
+	uint8_t code_of[256] = {0};
+	uint32_t sigma = 0;
+	for (int b = 0; b < 256; ++b)
+		if (present[b]) { code_of[b] = (uint8_t) sigma; c->code_to_byte[sigma] = (uint8_t) b; ++sigma; }
+	c->sigma = sigma;
+	int rc = alloc_msa(c);
+	if (rc) return rc;
+	// encode + transpose on the host in column tiles, then one copy per tile
+	size_t const tile = std::max<size_t>(1, (size_t) (8u << 20) / c->ld);
+	std::vector<uint8_t> buf(tile * c->ld);
+	for (uint64_t c0 = 0; c0 < p.n; c0 += tile)
+	{
+		uint64_t const c1 = std::min<uint64_t>(p.n, c0 + tile);
+		std::fill(buf.begin(), buf.end(), 0);
+		for (uint32_t r = 0; r < p.m; ++r)
+		{
+			uint8_t const *row = base + (size_t) r * rs;
+			for (uint64_t col = c0; col < c1; ++col)
+				buf[(col - c0) * c->ld + r] = code_of[row[col * cs]];
+		}
+		HIP_TRY(c, hipMemcpy(c->d_msa + c0 * c->ld, buf.data(), (c1 - c0) * c->ld, hipMemcpyHostToDevice));
+	}
+	c->have_input = true;
+	c->have_result = false;
+	c->kernels_ready = false;
+	return FSEQ_OK;
+}
+
+// host-side traceback walk: segmentation_lp_context.cc:191-224
+void follow_traceback(fseq_ctx *c)
+{
+	uint64_t const L = c->p.segment_length;
+	c->traceback.clear();
+	uint64_t arg_idx = c->dp_size - 1;
+	while (true)
+	{
+		fseq_dp_arg e;
+		e.lb = c->h_LB[arg_idx];
+		e.rb = arg_idx + L;
+		e.segment_max_size = c->h_M[arg_idx];
+		e.segment_size = c->h_SZ[arg_idx];
+		c->traceback.push_back(e);
+		if (0 == e.lb) break;
+		arg_idx = e.lb - L;
+	}
+	std::reverse(c->traceback.begin(), c->traceback.end());
+}
+
+int run_long_path(fseq_ctx *c, fseq_result *res)
+{
+	fseq_params const &p = c->p;
+	uint32_t const m = p.m;
+	uint64_t const n = p.n;
+	uint64_t const L = p.segment_length;
+	hipStream_t st = c->stream;
+	KernelSet const &ks = c->ks;
+	int rc;
+
+	uint32_t X = p.list_cap ? p.list_cap : 255u;
+	if (X >= m) X = m;
+	c->tm = fseq_timings{};
+	c->tm.block_len = c->B;
+	c->tm.n_blocks = c->nblocks;
+	double const t_begin = now_ms();
+
+	if ((rc = ensure_work_buffers(c, X))) return rc;
+
+	// ---- phase A + B (independent of X)
+	HIP_TRY(c, hipEventRecord(c->ev[0], st));
+	ks.rank(st, c->nblocks, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
+	HIP_TRY(c, hipEventRecord(c->ev[1], st));
+	ks.chain(st, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, c->d_bstate_a, c->d_bstate_d);
+	HIP_TRY(c, hipEventRecord(c->ev[2], st));
+	HIP_TRY(c, hipGetLastError());
+
+	double ms_c = 0, ms_dp = 0, ms_host = 0;
+	uint32_t retries = 0;
+	std::vector<uint2> h_gent;
+	std::vector<uint4> h_ghdr;
+	while (true)
+	{
+		if ((rc = ensure_work_buffers(c, X))) return rc;
+		// ---- phase C + D
+		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
+		HIP_TRY(c, hipEventRecord(c->ev[3], st));
+		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, c->X, c->stride, c->d_ent, c->d_hdr);
+		HIP_TRY(c, hipEventRecord(c->ev[4], st));
+		hipLaunchKernelGGL((k_dp<1024>), dim3(1), dim3(1024), 0, st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
+		HIP_TRY(c, hipEventRecord(c->ev[5], st));
+		HIP_TRY(c, hipGetLastError());
+
+		c->h_LB.resize(c->dp_size); c->h_M.resize(c->dp_size); c->h_SZ.resize(c->dp_size);
+		uint32_t h_flags[4] = {0, 0, 0, 0};
+		HIP_TRY(c, hipMemcpyAsync(c->h_LB.data(), c->dp.LB, c->dp_size * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(c->h_M.data(), c->dp.M, c->dp_size * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(c->h_SZ.data(), c->dp.SZ, c->dp_size * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		{
+			float f = 0;
+			HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
+			HIP_TRY(c, hipEventElapsedTime(&f, c->ev[4], c->ev[5])); ms_dp += f;
+		}
+		double const th0 = now_ms();
+		bool overflow = (h_flags[0] & 1u) != 0;
+
+		if (!overflow)
+		{
+			follow_traceback(c);
+			uint32_t const max_seg = c->traceback.back().segment_max_size;
+			c->res.max_segment_size = max_seg;
+			c->res.dp_segment_count = c->traceback.size();
+			c->res.short_path = 0;
+			size_t const S = c->traceback.size();
+
+			// ---- find_segments_greedy (lp.cc:335-390) from the per-column lists at the traceback rbs
+			c->segments.clear();
+			if (max_seg < m)
+			{
+				if (S > 1)
+				{
+					if (c->cols_cap < S) { if ((rc = dev_alloc(c, &c->d_cols, S))) return rc; c->cols_cap = S; }
+					if (c->gather_cap < S || c->gather_stride != c->stride)
+					{
+						if ((rc = dev_alloc(c, &c->d_gent, S * (size_t) c->stride))) return rc;
+						if ((rc = dev_alloc(c, &c->d_ghdr, S))) return rc;
+						c->gather_cap = S; c->gather_stride = c->stride;
+					}
+					std::vector<uint64_t> cols(S);
+					for (size_t j = 0; j < S; ++j) cols[j] = c->traceback[j].rb - 1;
+					HIP_TRY(c, hipMemcpyAsync(c->d_cols, cols.data(), S * 8, hipMemcpyHostToDevice, st));
+					hipLaunchKernelGGL(k_gather_lists, dim3((uint32_t) S), dim3(64), 0, st, c->d_cols, c->stride, c->d_ent, c->d_hdr, c->d_gent, c->d_ghdr);
+					h_gent.resize(S * (size_t) c->stride);
+					h_ghdr.resize(S);
+					HIP_TRY(c, hipMemcpyAsync(h_gent.data(), c->d_gent, h_gent.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
+					HIP_TRY(c, hipMemcpyAsync(h_ghdr.data(), c->d_ghdr, S * sizeof(uint4), hipMemcpyDeviceToHost, st));
+					HIP_TRY(c, hipStreamSynchronize(st));
+				}
+				uint64_t current_lb = 0;
+				uint64_t prev_size = c->traceback[0].segment_size;
+				size_t prev = 0;
+				for (size_t j = 1; j < S && !overflow; ++j)
+				{
+					// unique_substring_count_lhs(current_lb) = #{d > current_lb} (Appendix B A7)
+					uint4 const h = h_ghdr[j];
+					uint2 const *list = h_gent.data() + j * (size_t) c->stride;
+					uint64_t cnt = 0;
+					bool known = h.z != 0;
+					for (uint32_t i = 0; i < h.x; ++i)
+					{
+						if (list[i].x > current_lb) cnt += list[i].y;
+						else { known = true; break; }
+					}
+					if (!known && cnt <= max_seg) { overflow = true; break; }
+					if (cnt <= max_seg)
+						prev_size = cnt;
+					else
+					{
+						fseq_segment s{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
+						c->segments.push_back(s);
+						prev_size = c->traceback[j].segment_size;
+						current_lb = c->traceback[prev].rb;
+					}
+					prev = j;
+				}
+				if (!overflow)
+				{
+					fseq_segment s{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
+					c->segments.push_back(s);
+				}
+			}
+		}
+		ms_host += now_ms() - th0;
+		if (!overflow) break;
+		if (X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
+		X = (uint32_t) std::min<uint64_t>(m, (uint64_t) X * 4 + 3);
+		++retries;
+	}
+	c->res.segment_count = c->segments.size();
+
+	// ---- pass 2: (a,d) at the merged boundaries (update_pbwt_task.cc:13-35)
+	uint64_t pass2_cells = 0;
+	double ms_p2 = 0;
+	size_t const S2 = c->segments.size();
+	if (S2)
+	{
+		if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
+		if (c->snap_cap < S2)
+		{
+			if ((rc = dev_alloc(c, &c->d_snap_a, S2 * (size_t) m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_snap_d, S2 * (size_t) m))) return rc;
+			c->snap_cap = S2;
+		}
+		std::vector<uint64_t> rbs(S2);
+		for (size_t i = 0; i < S2; ++i)
+		{
+			rbs[i] = c->segments[i].rb;
+			uint64_t blk = std::min<uint64_t>(rbs[i] / c->B, c->nblocks);
+			pass2_cells += (rbs[i] - blk * c->B) * m;
+		}
+		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipEventRecord(c->ev[6], st));
+		ks.snap(st, (uint32_t) S2, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_snap_a, c->d_snap_d);
+		HIP_TRY(c, hipEventRecord(c->ev[7], st));
+		HIP_TRY(c, hipGetLastError());
+		HIP_TRY(c, hipStreamSynchronize(st));
+		float f = 0;
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); ms_p2 = f;
+	}
+
+	{
+		float f = 0;
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[0], c->ev[1])); c->tm.ms_phase_a = f;
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[1], c->ev[2])); c->tm.ms_phase_b = f;
+	}
+	c->tm.ms_phase_c = ms_c;
+	c->tm.ms_dp = ms_dp;
+	c->tm.ms_pass2 = ms_p2;
+	c->tm.ms_host = ms_host;
+	c->tm.ms_colstep_kernels = c->tm.ms_phase_a + ms_c + ms_p2;
+	c->tm.colstep_launches = 2 + retries + (S2 ? 1 : 0);
+	c->tm.colstep_cells = (uint64_t) m * n * (2 + retries) + pass2_cells;
+	c->tm.pass2_cells = pass2_cells;
+	c->tm.list_cap_used = X;
+	c->tm.retries = retries;
+	c->tm.ms_total = now_ms() - t_begin;
+	c->have_result = true;
+	*res = c->res;
+	if (!(c->res.max_segment_size < m))
+		return fail(c, FSEQ_E_NO_REDUCTION, "Unable to reduce the number of sequences; the maximum segment size is equal to the number of input sequences.");
+	return FSEQ_OK;
+}
+
+// segmentation_sp_context::process (segmentation_sp_context.cc:21-28): one sweep over all n columns
+// from the identity; the distinct rows are the block keys of a single block [0, n).
+int run_short_path(fseq_ctx *c, fseq_result *res)
+{
+	fseq_params const &p = c->p;
+	uint32_t const m = p.m;
+	hipStream_t st = c->stream;
+	int rc;
+	c->tm = fseq_timings{};
+	double const t_begin = now_ms();
+	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nk = nullptr;
+	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
+	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
+	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
+	c->ks.rank(st, 1, c->ks.lds_colblock, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
+	std::vector<uint32_t> rank(m);
+	uint32_t nk = 0;
+	hipError_t e1 = hipMemcpyAsync(rank.data(), d_rank, (size_t) m * 4, hipMemcpyDeviceToHost, st);
+	hipError_t e2 = hipMemcpyAsync(&nk, d_nk, 4, hipMemcpyDeviceToHost, st);
+	hipError_t e3 = hipStreamSynchronize(st);
+	dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk);
+	if (e1 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path copy", e1);
+	if (e2 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path copy", e2);
+	if (e3 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path sync", e3);
+	// identical rows keep ascending row-id order in the pBWT, so a run's first row is its smallest id
+	c->sp_first.assign(nk, 0xFFFFFFFFu);
+	c->sp_len.assign(nk, 0);
+	for (uint32_t r = 0; r < m; ++r)
+	{
+		uint32_t const k = rank[r];
+		if (c->sp_first[k] == 0xFFFFFFFFu) c->sp_first[k] = r;
+		++c->sp_len[k];
+	}
+	c->res = fseq_result{};
+	c->res.max_segment_size = nk;
+	c->res.short_path = 1;
+	c->traceback.clear();
+	c->segments.clear();
+	c->tm.colstep_launches = 1;
+	c->tm.colstep_cells = (uint64_t) m * p.n;
+	c->tm.ms_total = now_ms() - t_begin;
+	c->have_result = true;
+	*res = c->res;
+	if (!(nk < m))
+		return fail(c, FSEQ_E_NO_REDUCTION, "Unable to reduce the number of sequences; the maximum segment size is equal to the number of input sequences.");
+	return FSEQ_OK;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+uint32_t fseq_abi_version(void) { return FSEQ_ABI_VERSION; }
+
+char const *fseq_strerror(int code)
+{
+	switch (code)
+	{
+		case FSEQ_OK: return "ok";
+		case FSEQ_E_ARG: return "bad argument";
+		case FSEQ_E_NO_REDUCTION: return "unable to reduce the number of sequences";
+		case FSEQ_E_HIP: return "HIP runtime error";
+		case FSEQ_E_OOM: return "out of device memory";
+		case FSEQ_E_UNSUPPORTED: return "unsupported shape for this build";
+		default: return "unknown";
+	}
+}
+
+int fseq_create(fseq_params const *params, fseq_ctx **out)
+{
+	if (!params || !out) return FSEQ_E_ARG;
+	*out = nullptr;
+	if (0 == params->m || 0 == params->n || 0 == params->segment_length) return FSEQ_E_ARG;
+	if (params->n >= 0xFFFFFFF0ull) return FSEQ_E_ARG;
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return FSEQ_E_HIP;
+	if (params->device < 0 || params->device >= ndev) return FSEQ_E_ARG;
+	if (hipSetDevice(params->device) != hipSuccess) return FSEQ_E_HIP;
+	fseq_ctx *c = new fseq_ctx();
+	c->p = *params;
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	for (auto &e : c->ev)
+		if (hipEventCreate(&e) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	*out = c;
+	return FSEQ_OK;
+}
+
+void fseq_destroy(fseq_ctx *c)
+{
+	if (!c) return;
+	(void) hipSetDevice(c->p.device);
+	if (c->stream) (void) hipStreamSynchronize(c->stream);
+	free_msa(c);
+	free_work(c);
+	for (auto &e : c->ev) if (e) (void) hipEventDestroy(e);
+	if (c->stream) (void) hipStreamDestroy(c->stream);
+	delete c;
+}
+
+char const *fseq_last_error(fseq_ctx const *c) { return c ? c->err.c_str() : "null context"; }
+
+int fseq_set_matrix(fseq_ctx *c, uint8_t const *base, size_t row_stride, size_t col_stride)
+{
+	if (!c || !base) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	return set_alphabet_and_upload(c, base, row_stride, col_stride);
+}
+
+int fseq_set_rows(fseq_ctx *c, uint8_t const *const *rows)
+{
+	if (!c || !rows) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	// gather into one row-major staging buffer view by view (rows need not be contiguous)
+	fseq_params const &p = c->p;
+	std::vector<uint8_t> tmp((size_t) p.m * p.n);
+	for (uint32_t r = 0; r < p.m; ++r)
+	{
+		if (!rows[r]) return fail(c, FSEQ_E_ARG, "null row pointer");
+		memcpy(tmp.data() + (size_t) r * p.n, rows[r], p.n);
+	}
+	return set_alphabet_and_upload(c, tmp.data(), p.n, 1);
+}
+
+int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_t sigma)
+{
+	if (!c || !d_codes) return FSEQ_E_ARG;
+	if (ld < c->p.m || (ld & 15) || (reinterpret_cast<uintptr_t>(d_codes) & 15))
+		return fail(c, FSEQ_E_ARG, "device columns: ld must be >= m and a multiple of 16, base 16-byte aligned");
+	if (sigma == 0 || sigma > 256) return fail(c, FSEQ_E_ARG, "sigma out of range");
+	free_msa(c);
+	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_codes));
+	c->ld = ld;
+	c->own_msa = false;
+	c->sigma = sigma;
+	for (uint32_t i = 0; i < 256; ++i) c->code_to_byte[i] = (uint8_t) i;
+	c->have_input = true;
+	c->have_result = false;
+	c->kernels_ready = false;
+	return FSEQ_OK;
+}
+
+int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
+{
+	if (!c || !spec || 0 == spec->n_founders || 0 == spec->block_len || spec->kind > 1) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	int rc = alloc_msa(c);
+	if (rc) return rc;
+	char const *alpha = spec->kind ? "ACGTRYSWKMBDHVN-" : "ACGT";
+	uint32_t const sigma = spec->kind ? 16u : 4u;
+	SynthArgs A;
+	A.seed = spec->seed; A.n_founders = spec->n_founders; A.block_len = spec->block_len;
+	A.mut_threshold = spec->mut_threshold; A.kind = spec->kind; A.sigma = sigma;
+	for (uint32_t i = 0; i < 16; ++i) A.code_of_sym[i] = 0;
+	for (uint32_t i = 0; i < sigma; ++i)
+	{
+		uint32_t rank = 0;
+		for (uint32_t j = 0; j < sigma; ++j) rank += ((uint8_t) alpha[j] < (uint8_t) alpha[i]) ? 1u : 0u;
+		A.code_of_sym[i] = (uint8_t) rank;
+		c->code_to_byte[rank] = (uint8_t) alpha[i];
+	}
+	c->sigma = sigma;
+	uint64_t const total = (c->ld / 4) * c->p.n;
+	uint64_t const grid = (total + 255) / 256;
+	if (grid > 0x7FFFFFFFull) return fail(c, FSEQ_E_UNSUPPORTED, "synthetic generator grid too large");
+	hipLaunchKernelGGL(k_synth, dim3((uint32_t) grid), dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n);
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	c->have_input = true;
+	c->have_result = false;
+	c->kernels_ready = false;
+	return FSEQ_OK;
+}
+
+int fseq_get_matrix(fseq_ctx *c, uint64_t c0, uint64_t c1, uint8_t *out, size_t row_stride, size_t col_stride)
+{
+	if (!c || !out || !c->have_input || c0 > c1 || c1 > c->p.n) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	std::vector<uint8_t> buf((c1 - c0) * c->ld);
+	HIP_TRY(c, hipMemcpy(buf.data(), c->d_msa + c0 * c->ld, buf.size(), hipMemcpyDeviceToHost));
+	for (uint64_t col = c0; col < c1; ++col)
+		for (uint32_t r = 0; r < c->p.m; ++r)
+			out[(size_t) r * row_stride + (col - c0) * col_stride] = c->code_to_byte[buf[(col - c0) * c->ld + r]];
+	return FSEQ_OK;
+}
+
+int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
+{
+	if (!c || !res) return FSEQ_E_ARG;
+	if (!c->have_input) return fail(c, FSEQ_E_ARG, "no input set");
+	(void) hipSetDevice(c->p.device);
+	c->have_result = false;
+	if (!c->kernels_ready)
+	{
+		int rc = prepare_geometry(c);
+		if (rc) return rc;
+	}
+	// generate_context::calculate_segmentation, generate_context.cc:386-389
+	if (c->p.n < 2 * c->p.segment_length)
+		return run_short_path(c, res);
+	return run_long_path(c, res);
+}
+
+int fseq_get_traceback(fseq_ctx *c, fseq_dp_arg *out)
+{
+	if (!c || !out || !c->have_result) return FSEQ_E_ARG;
+	std::copy(c->traceback.begin(), c->traceback.end(), out);
+	return FSEQ_OK;
+}
+
+int fseq_get_segments(fseq_ctx *c, fseq_segment *out)
+{
+	if (!c || !out || !c->have_result) return FSEQ_E_ARG;
+	std::copy(c->segments.begin(), c->segments.end(), out);
+	return FSEQ_OK;
+}
+
+int fseq_boundary_state(fseq_ctx *c, uint64_t i, uint32_t *a_out, uint32_t *d_out)
+{
+	if (!c || !c->have_result || i >= c->segments.size()) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	size_t const m = c->p.m;
+	if (a_out) HIP_TRY(c, hipMemcpy(a_out, c->d_snap_a + i * m, m * 4, hipMemcpyDeviceToHost));
+	if (d_out) HIP_TRY(c, hipMemcpy(d_out, c->d_snap_d + i * m, m * 4, hipMemcpyDeviceToHost));
+	return FSEQ_OK;
+}
+
+int fseq_short_path_runs(fseq_ctx *c, uint32_t *first_idx, uint32_t *run_len)
+{
+	if (!c || !c->have_result || !c->res.short_path) return FSEQ_E_ARG;
+	if (first_idx) std::copy(c->sp_first.begin(), c->sp_first.end(), first_idx);
+	if (run_len) std::copy(c->sp_len.begin(), c->sp_len.end(), run_len);
+	return FSEQ_OK;
+}
+
+int fseq_debug_dp(fseq_ctx *c, uint32_t *lb, uint32_t *max_size, uint32_t *size)
+{
+	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (lb) std::copy(c->h_LB.begin(), c->h_LB.end(), lb);
+	if (max_size) std::copy(c->h_M.begin(), c->h_M.end(), max_size);
+	if (size) std::copy(c->h_SZ.begin(), c->h_SZ.end(), size);
+	return FSEQ_OK;
+}
+
+int fseq_debug_block_state(fseq_ctx *c, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out)
+{
+	if (!c || !c->have_result || c->res.short_path || block_idx > c->nblocks) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	size_t const m = c->p.m;
+	if (a_out) HIP_TRY(c, hipMemcpy(a_out, c->d_bstate_a + block_idx * m, m * 4, hipMemcpyDeviceToHost));
+	if (d_out) HIP_TRY(c, hipMemcpy(d_out, c->d_bstate_d + block_idx * m, m * 4, hipMemcpyDeviceToHost));
+	return FSEQ_OK;
+}
+
+int fseq_debug_column_list(fseq_ctx *c, uint64_t col, uint32_t *values, uint32_t *counts,
+                           uint32_t *n_entries, uint32_t *cnt0, uint32_t *complete)
+{
+	if (!c || !c->have_result || c->res.short_path || col >= c->p.n) return FSEQ_E_ARG;
+	(void) hipSetDevice(c->p.device);
+	uint4 h;
+	HIP_TRY(c, hipMemcpy(&h, c->d_hdr + col, sizeof(h), hipMemcpyDeviceToHost));
+	std::vector<uint2> e(h.x);
+	if (h.x) HIP_TRY(c, hipMemcpy(e.data(), c->d_ent + col * (size_t) c->stride, h.x * sizeof(uint2), hipMemcpyDeviceToHost));
+	for (uint32_t i = 0; i < h.x; ++i)
+	{
+		if (values) values[i] = e[i].x;
+		if (counts) counts[i] = e[i].y;
+	}
+	if (n_entries) *n_entries = h.x;
+	if (cnt0) *cnt0 = h.y;
+	if (complete) *complete = h.z;
+	return FSEQ_OK;
+}
+
+int fseq_get_timings(fseq_ctx const *c, fseq_timings *out)
+{
+	if (!c || !out) return FSEQ_E_ARG;
+	*out = c->tm;
+	return FSEQ_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,301 @@
+// fseq_core.hpp -- device building blocks for the pBWT column update on gfx950 (wave64).
+//
+// The unit of work is one *stable sigma-bucket partition step* of an LDS-resident order
+// (a[], d[]) of up to T*E rows, owned by one workgroup of T threads (E consecutive positions
+// per thread):
+//     dst(i)  = start[sym_i] + #{j < i : sym_j == sym_i}            (stable counting sort)
+//     d'(dst) = first in its bucket ? first_val : max d(p, i]        (p = previous row with sym_i)
+// This is libbio::pbwt::pbwt_context::process for one column (SURVEY.md Appendix A step 2;
+// instantiation include/founder_sequences/founder_sequences.hh:56-65), and it is also the digit
+// pass of the block-rank sort in phase B.  Both prefix problems are solved with ONE block-wide
+// scan of a per-thread summary {counts[sigma], running-max[sigma], seen-mask}:
+// wave-level Hillis-Steele over 64 lanes, then a fold of the wave totals through LDS.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace fseq {
+
+constexpr int WAVE = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t shfl_up_u32(uint32_t v, int delta) { return (uint32_t) __shfl_up((int) v, delta, WAVE); }
+__device__ __forceinline__ uint32_t shfl_dn_u32(uint32_t v, int delta) { return (uint32_t) __shfl_down((int) v, delta, WAVE); }
+__device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, WAVE); }
+
+// inclusive add-scan over the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
+{
+	uint32_t const lane = lane_id();
+#pragma unroll
+	for (int delta = 1; delta < WAVE; delta <<= 1)
+	{
+		uint32_t const o = shfl_up_u32(v, delta);
+		if (lane >= (uint32_t) delta) v += o;
+	}
+	return v;
+}
+
+// Block-wide exclusive add-scan of one uint32 per thread. scratch: T/64 + 1 words of LDS.
+// Contains two __syncthreads().  Returns the exclusive prefix; *total = sum over the block.
+template <int T>
+__device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *scratch, uint32_t *total)
+{
+	constexpr int NW = T / WAVE;
+	uint32_t const inc = wave_incl_add(v);
+	if (NW == 1)
+	{
+		*total = shfl_u32(inc, 63);
+		return inc - v;
+	}
+	__syncthreads();                       // protect scratch against the previous use
+	if (lane_id() == 63) scratch[wave_id()] = inc;
+	__syncthreads();
+	uint32_t pre = 0, tot = 0;
+#pragma unroll
+	for (int w = 0; w < NW; ++w)
+	{
+		uint32_t const x = scratch[w];
+		if ((uint32_t) w < wave_id()) pre += x;
+		tot += x;
+	}
+	*total = tot;
+	return pre + inc - v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-thread summary for the partition scan.
+// cnt: two 16-bit counts per word (m <= 65535 for the LDS-resident kernels).
+// val[x]: max d since the last row with symbol x inside the summarised range (whole range if none).
+// has:  bit x set iff symbol x occurs in the range.
+// combine(L, R) (L to the left of R): cnt = L.cnt + R.cnt ; val[x] = R.has[x] ? R.val[x] : max(L.val[x], R.val[x]).
+// ---------------------------------------------------------------------------------------------
+template <int SIGMA>
+struct Summary {
+	static constexpr int NC = SIGMA / 2;
+	uint32_t cnt[NC];
+	uint32_t val[SIGMA];
+	uint32_t has;
+
+	__device__ __forceinline__ void clear()
+	{
+#pragma unroll
+		for (int i = 0; i < NC; ++i) cnt[i] = 0;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) val[x] = 0;
+		has = 0;
+	}
+
+	// *this = L (+) *this
+	__device__ __forceinline__ void prepend(Summary const &L)
+	{
+#pragma unroll
+		for (int i = 0; i < NC; ++i) cnt[i] += L.cnt[i];
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			uint32_t const mx = max(L.val[x], val[x]);
+			val[x] = ((has >> x) & 1u) ? val[x] : mx;
+		}
+		has |= L.has;
+	}
+
+	__device__ __forceinline__ Summary shifted_up(int delta) const
+	{
+		Summary o;
+#pragma unroll
+		for (int i = 0; i < NC; ++i) o.cnt[i] = shfl_up_u32(cnt[i], delta);
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) o.val[x] = shfl_up_u32(val[x], delta);
+		o.has = shfl_up_u32(has, delta);
+		return o;
+	}
+
+	__device__ __forceinline__ Summary from_lane(int src) const
+	{
+		Summary o;
+#pragma unroll
+		for (int i = 0; i < NC; ++i) o.cnt[i] = shfl_u32(cnt[i], src);
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) o.val[x] = shfl_u32(val[x], src);
+		o.has = shfl_u32(has, src);
+		return o;
+	}
+
+	__device__ __forceinline__ uint32_t count(int x) const { return (cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu; }
+};
+
+template <int T, int SIGMA>
+struct StepScratch {
+	static constexpr int NW = T / WAVE;
+	static constexpr int NC = SIGMA / 2;
+	uint32_t cnt[NW][NC];
+	uint32_t val[NW][SIGMA];
+	uint32_t has[NW];
+};
+
+// One partition step.  In: d[e], s[e] for the thread's E consecutive positions (s >= SIGMA marks an
+// unused tail position; its d must be 0).  Out: dst[e], dnew[e].  Contains exactly one
+// __syncthreads(); the caller must barrier again before the scratch is reused.
+template <int T, int E, int SIGMA>
+__device__ __forceinline__ void partition_step(
+	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
+	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E])
+{
+	static_assert(E <= 15, "local counts are nibble-packed");
+	static_assert(SIGMA == 4 || SIGMA == 16, "sigma instantiations");
+	constexpr int NW = T / WAVE;
+	constexpr int NC = SIGMA / 2;
+	uint32_t const lane = lane_id();
+	uint32_t const wave = wave_id();
+
+	// ---- local pass over the thread's E rows
+	uint32_t run[SIGMA];
+#pragma unroll
+	for (int x = 0; x < SIGMA; ++x) run[x] = 0;
+	uint32_t has = 0, pend = 0;
+	uint64_t lcp = 0;                       // nibble x = rows with symbol x seen so far in this thread
+	uint32_t lidx[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e)
+	{
+		uint32_t const c = s[e];
+		bool const act = c < (uint32_t) SIGMA;
+		uint32_t const de = d[e];
+		uint32_t o = 0;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			uint32_t const r = max(run[x], de);
+			bool const is = (c == (uint32_t) x);
+			o = is ? r : o;
+			run[x] = is ? 0u : r;
+		}
+		dnew[e] = o;
+		uint32_t const sh = (c & 15u) * 4u;
+		lidx[e] = (uint32_t) (lcp >> sh) & 15u;
+		pend |= (act && !((has >> (c & 15u)) & 1u)) ? (1u << e) : 0u;
+		lcp += act ? (1ull << sh) : 0ull;
+		has |= act ? (1u << (c & 15u)) : 0u;
+	}
+
+	Summary<SIGMA> S;
+#pragma unroll
+	for (int i = 0; i < NC; ++i)
+	{
+		uint32_t const lo = (uint32_t) (lcp >> (8 * i)) & 15u;
+		uint32_t const hi = (uint32_t) (lcp >> (8 * i + 4)) & 15u;
+		S.cnt[i] = lo | (hi << 16);
+	}
+#pragma unroll
+	for (int x = 0; x < SIGMA; ++x) S.val[x] = run[x];
+	S.has = has;
+
+	// ---- wave-level inclusive scan
+#pragma unroll
+	for (int delta = 1; delta < WAVE; delta <<= 1)
+	{
+		Summary<SIGMA> const L = S.shifted_up(delta);
+		if (lane >= (uint32_t) delta) S.prepend(L);
+	}
+	if (NW > 1 && lane == 63)
+	{
+#pragma unroll
+		for (int i = 0; i < NC; ++i) scr.cnt[wave][i] = S.cnt[i];
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) scr.val[wave][x] = S.val[x];
+		scr.has[wave] = S.has;
+	}
+	// exclusive within the wave
+	Summary<SIGMA> C = S.shifted_up(1);
+	if (lane == 0) C.clear();
+
+	Summary<SIGMA> TOT;                     // whole-block totals (counts only are used)
+	if (NW == 1)
+	{
+		TOT = S.from_lane(63);
+		__syncthreads();
+	}
+	else
+	{
+		__syncthreads();
+		if (NW <= 4)
+		{
+			Summary<SIGMA> P;               // fold of the waves to the left of this one
+			P.clear();
+			TOT.clear();
+#pragma unroll
+			for (int w = 0; w < NW; ++w)
+			{
+				Summary<SIGMA> W;
+#pragma unroll
+				for (int i = 0; i < NC; ++i) W.cnt[i] = scr.cnt[w][i];
+#pragma unroll
+				for (int x = 0; x < SIGMA; ++x) W.val[x] = scr.val[w][x];
+				W.has = scr.has[w];
+#pragma unroll
+				for (int i = 0; i < NC; ++i) TOT.cnt[i] += W.cnt[i];
+				if ((uint32_t) w < wave) { W.prepend(P); P = W; }
+			}
+			C.prepend(P);
+		}
+		else
+		{
+			// second-level scan over the NW wave totals, done redundantly by every wave
+			Summary<SIGMA> W;
+			W.clear();
+			if (lane < (uint32_t) NW)
+			{
+#pragma unroll
+				for (int i = 0; i < NC; ++i) W.cnt[i] = scr.cnt[lane][i];
+#pragma unroll
+				for (int x = 0; x < SIGMA; ++x) W.val[x] = scr.val[lane][x];
+				W.has = scr.has[lane];
+			}
+#pragma unroll
+			for (int delta = 1; delta < NW; delta <<= 1)
+			{
+				Summary<SIGMA> const L = W.shifted_up(delta);
+				if (lane >= (uint32_t) delta) W.prepend(L);
+			}
+			TOT = W.from_lane(NW - 1);
+			Summary<SIGMA> P = W.from_lane(wave == 0 ? 0 : (int) wave - 1);
+			if (wave == 0) P.clear();
+			C.prepend(P);
+		}
+	}
+
+	// ---- bucket bases and resolution of the pending (first-in-thread) rows
+	uint32_t base[SIGMA];
+	{
+		uint32_t acc = 0;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			base[x] = acc + C.count(x);
+			acc += TOT.count(x);
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < E; ++e)
+	{
+		uint32_t const c = s[e];
+		uint32_t b = 0, cv = 0;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			bool const is = (c == (uint32_t) x);
+			b = is ? base[x] : b;
+			cv = is ? C.val[x] : cv;
+		}
+		bool const seen_before = (C.has >> (c & 15u)) & 1u;
+		if ((pend >> e) & 1u)
+			dnew[e] = seen_before ? max(cv, dnew[e]) : first_val;
+		dst[e] = b + lidx[e];
+	}
+}
+
+} // namespace fseq

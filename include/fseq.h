@@ -1,0 +1,153 @@
+/*
+ * fseq.h -- C ABI of the MI355X-native segmentation engine (libfseq_hip.so).
+ *
+ * Drop-in boundary for ONE path of tsnorri/founder-sequences: everything
+ * founder_sequences::segmentation_lp_context does (pBWT pass 1 + minimum-segmentation DP +
+ * traceback + pass 2 + greedy segment merge) and segmentation_sp_context::process.
+ * The reference has no FFI for this path; its boundary is the C++ delegate pair
+ *   segmentation_lp_context_delegate          include/founder_sequences/segmentation_lp_context.hh:45-58
+ *   segmentation_context / _delegate          include/founder_sequences/segmentation_context.hh:14-33
+ * and the hand-off type
+ *   segmentation_container                    include/founder_sequences/segmentation_container.hh:15-20
+ * Each entry point below names the reference interface it replaces.  Plain pointers and sizes
+ * only; no exceptions and no exit() cross this ABI.  All paths are relative to /root/reference.
+ */
+#ifndef FSEQ_H
+#define FSEQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FSEQ_ABI_VERSION 1
+
+enum {
+	FSEQ_OK             = 0,
+	FSEQ_E_ARG          = 1,   /* bad argument / call order */
+	FSEQ_E_NO_REDUCTION = 2,   /* max segment size >= m: generate_context.cc:192-200 */
+	FSEQ_E_HIP          = 3,   /* HIP runtime error, see fseq_last_error */
+	FSEQ_E_OOM          = 4,
+	FSEQ_E_UNSUPPORTED  = 5    /* shape outside what this build's kernels cover (fails loudly, no CPU fallback) */
+};
+
+typedef struct fseq_ctx fseq_ctx;
+
+/* Construction parameters = what segmentation_lp_context reads from its delegate
+ * (segmentation_lp_context.hh:47-50): sequence_count(), sequences().front().size(),
+ * segment_length(), pbwt_sample_rate(). */
+typedef struct fseq_params {
+	uint32_t m;                 /* sequence_count()                                   */
+	uint64_t n;                 /* sequence length (columns)                           */
+	uint64_t segment_length;    /* L, --segment-length-bound (cmdline.ggo:16-17)       */
+	uint64_t pbwt_sample_rate;  /* accepted for interface parity; results do not depend on it. The
+	                               engine keeps an exact (a,d) state every block_len columns instead. */
+	uint32_t block_len;         /* column-block length B; 0 = choose automatically     */
+	uint32_t list_cap;          /* X: per-column divergence list covers the X largest entries; 0 = default.
+	                               Too small a value is detected and retried internally (results stay exact). */
+	int32_t  device;            /* HIP device ordinal                                  */
+} fseq_params;
+
+/* Synthetic founder-mosaic input, generated on the device. */
+typedef struct fseq_synth_spec {
+	uint64_t seed;
+	uint32_t n_founders;
+	uint32_t block_len;         /* recombination block length */
+	uint64_t mut_threshold;     /* mutation iff hash < mut_threshold (= mu * 2^64) */
+	uint32_t kind;              /* 0: "ACGT" uniform; 1: "ACGTRYSWKMBDHVN-", P(ACGT)=0.9 */
+} fseq_synth_spec;
+
+/* One reduced segment: segmentation_container::reduced_traceback entry
+ * (segmentation_dp_arg.hh:18-23 built by the 3-argument constructor at
+ * segmentation_lp_context.cc:368,380). */
+typedef struct fseq_segment {
+	uint64_t lb;                /* inclusive */
+	uint64_t rb;                /* exclusive */
+	uint32_t segment_size;
+	uint32_t reserved;
+} fseq_segment;
+
+/* One traceback entry before merging (segmentation_lp_context.cc:191-224). */
+typedef struct fseq_dp_arg {
+	uint64_t lb, rb;
+	uint32_t segment_max_size, segment_size;
+} fseq_dp_arg;
+
+typedef struct fseq_result {
+	uint32_t max_segment_size;      /* segmentation_container::max_segment_size           */
+	uint32_t short_path;            /* 1 if n < 2L (generate_context.cc:386-389)          */
+	uint64_t dp_segment_count;      /* S reported by context_did_finish_traceback (:221-223) */
+	uint64_t segment_count;         /* S' = reduced_traceback.size()                       */
+} fseq_result;
+
+typedef struct fseq_timings {
+	double ms_total;                /* wall, whole fseq_run_segmentation call                       */
+	double ms_phase_a, ms_phase_b, ms_phase_c, ms_dp, ms_pass2, ms_host;   /* device phases: HIP event time */
+	double ms_colstep_kernels;      /* summed HIP-event time of the column-update kernels (A + C + pass 2) */
+	uint64_t colstep_launches;      /* number of those launches                            */
+	uint64_t colstep_cells;         /* cells (rows x columns) those launches processed     */
+	uint64_t pass2_cells;           /* R: cells re-processed for the boundary snapshots    */
+	uint32_t list_cap_used;         /* X that produced the result                          */
+	uint32_t retries;               /* list_cap retries                                    */
+	uint32_t block_len;             /* B in use                                            */
+	uint32_t n_blocks;
+} fseq_timings;
+
+uint32_t    fseq_abi_version(void);
+char const *fseq_strerror(int code);
+
+/* replaces: new segmentation_lp_context(delegate, ...)  generate_context.cc:184 */
+int  fseq_create(fseq_params const *params, fseq_ctx **out);
+/* replaces: segmentation_lp_context::cleanup  segmentation_lp_context.hh:117 */
+void fseq_destroy(fseq_ctx *ctx);
+char const *fseq_last_error(fseq_ctx const *ctx);
+
+/* Input = delegate->sequences() (m spans of n raw bytes, founder_sequences.hh:38-40) plus
+ * delegate->alphabet() (generate_context.cc:135-147).  rows[r] points at n bytes.  The bytes
+ * are mapped to dense codes in ascending byte order and stored column-major in HBM. */
+int  fseq_set_rows(fseq_ctx *ctx, uint8_t const *const *rows);
+/* Same, from one host buffer: sym(r,c) = base[r*row_stride + c*col_stride]. */
+int  fseq_set_matrix(fseq_ctx *ctx, uint8_t const *base, size_t row_stride, size_t col_stride);
+/* Input already resident in HBM: column-major dense codes, column c at d_codes + c*ld, ld >= m.
+ * sigma = number of codes (codes are < sigma).  The buffer is borrowed, not copied. */
+int  fseq_set_device_columns(fseq_ctx *ctx, void const *d_codes, size_t ld, uint32_t sigma);
+/* Generate the alignment on the device (bench / large configs). */
+int  fseq_generate_synthetic(fseq_ctx *ctx, fseq_synth_spec const *spec);
+/* Copy columns [c0,c1) back as raw bytes, out[r*row_stride + (c-c0)*col_stride] (tests, writers). */
+int  fseq_get_matrix(fseq_ctx *ctx, uint64_t c0, uint64_t c1, uint8_t *out, size_t row_stride, size_t col_stride);
+
+/* replaces: generate_traceback + update_samples_to_traceback_positions + find_segments_greedy
+ * (segmentation_lp_context.cc:26-390) or segmentation_sp_context::process
+ * (segmentation_sp_context.cc:21-28) when n < 2L.  Returns FSEQ_E_NO_REDUCTION exactly when the
+ * reference would print "Unable to reduce the number of sequences" (the traceback is still
+ * available then). */
+int  fseq_run_segmentation(fseq_ctx *ctx, fseq_result *res);
+
+/* segmentation_lp_context::m_segmentation_traceback_res (before merging), dp_segment_count entries. */
+int  fseq_get_traceback(fseq_ctx *ctx, fseq_dp_arg *out);
+/* segmentation_container::reduced_traceback, segment_count entries. */
+int  fseq_get_segments(fseq_ctx *ctx, fseq_segment *out);
+/* segmentation_container::reduced_pbwt_samples[i]: input_permutation() / input_divergence() at
+ * sequence_idx() == segments[i].rb (greedy_matcher.cc:242-257, join_context.cc:73).  m uint32 each. */
+int  fseq_boundary_state(fseq_ctx *ctx, uint64_t i, uint32_t *a_out, uint32_t *d_out);
+/* Short path result (segmentation_sp_context.hh:28): one (first row id, copy number) per distinct
+ * row in pBWT order; returns max_segment_size entries. */
+int  fseq_short_path_runs(fseq_ctx *ctx, uint32_t *first_idx, uint32_t *run_len);
+
+/* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
+int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
+/* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */
+int  fseq_debug_block_state(fseq_ctx *ctx, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out);
+/* Per-column divergence list after column c: descending (value,count), up to list_cap+1 entries;
+ * *n_entries, *cnt0 (count of value 0) and *complete (list reaches the smallest value). */
+int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_t *counts,
+                            uint32_t *n_entries, uint32_t *cnt0, uint32_t *complete);
+
+int  fseq_get_timings(fseq_ctx const *ctx, fseq_timings *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,63 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports
+every symbol include/fseq.h declares.  No compute is called here (no GPU in this container)."""
+import ctypes as C
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    build = importlib.import_module("founder-sequences_amd.build")
+    build.build()
+    return importlib.import_module("founder-sequences_amd")
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "fseq.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fseq_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert _declared_symbols() == sorted(pkg.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = pkg.load_library()
+    for name in _declared_symbols():
+        assert hasattr(lib, name), name
+    assert lib.fseq_abi_version() == 1
+    assert lib.fseq_strerror(2).decode().startswith("unable to reduce")
+
+
+def test_struct_layouts_match_header(pkg):
+    # sizes the C compiler gives the header's structs (natural alignment, x86-64)
+    assert C.sizeof(pkg.Params) == 48
+    assert C.sizeof(pkg.SynthSpec) == 32
+    assert C.sizeof(pkg.Segment) == 24 == pkg.SEGMENT_DTYPE.itemsize
+    assert C.sizeof(pkg.DpArg) == 24 == pkg.DPARG_DTYPE.itemsize
+    assert C.sizeof(pkg.Result) == 24
+    assert C.sizeof(pkg.Timings) == 8 * 8 + 3 * 8 + 4 * 4
+
+
+def test_header_compiles_as_plain_c(tmp_path):
+    import subprocess
+    src = tmp_path / "t.c"
+    src.write_text('#include "fseq.h"\nint main(void){ fseq_params p; (void)p; return sizeof(fseq_segment) == 24 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    assert subprocess.run([str(exe)]).returncode == 0
+
+
+def test_bad_arguments_fail_without_touching_a_device(pkg):
+    lib = pkg.load_library()
+    h = C.c_void_p()
+    assert lib.fseq_create(None, C.byref(h)) == pkg.FSEQ_E_ARG
+    p = pkg.Params(0, 10, 2, 0, 0, 0, 0)
+    assert lib.fseq_create(C.byref(p), C.byref(h)) == pkg.FSEQ_E_ARG
+    assert lib.fseq_last_error(None).decode() == "null context"

@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Bit-exact: DP array, traceback, merged segments, boundary (a, d) states, block states, lists."""
+import importlib
+
+import numpy as np
+import pytest
+
+import fso
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return importlib.import_module("founder-sequences_amd")
+
+
+def run_gpu(pkg, msa, L, **kw):
+    m, n = msa.shape
+    ctx = pkg.SegmentationContext(m, n, L, **kw)
+    ctx.set_sequences(msa)
+    try:
+        ctx.run()
+    except pkg.NoReduction:
+        pass
+    return ctx
+
+
+def compare_long(pkg, msa, L, check_dp=True, **kw):
+    m, n = msa.shape
+    ref = fso.segment_long(msa, L, keep_dp=check_dp, threads=4)
+    ctx = run_gpu(pkg, msa, L, **kw)
+    assert ctx.result.short_path == 0
+    assert ctx.result.max_segment_size == ref["max_segment_size"]
+    if check_dp:
+        lb, mx, sz = ctx.debug_dp()
+        dp = ref["dp"]
+        written = np.ones(len(dp), dtype=bool)
+        written[n - 2 * L + 1:n - L] = False
+        assert np.array_equal(mx[written], dp["segment_max_size"][written])
+        assert np.array_equal(lb[written], dp["lb"][written].astype(np.uint32))
+        assert np.array_equal(sz[written], dp["segment_size"][written])
+    tb = ctx.traceback()
+    assert len(tb) == len(ref["traceback"])
+    for f in ("lb", "rb", "segment_max_size", "segment_size"):
+        assert np.array_equal(tb[f], ref["traceback"][f]), f
+    if ref["status"] != 0:
+        assert ctx.result.segment_count == 0
+        return ctx, ref
+    red = ctx.reduced_traceback()
+    assert len(red) == len(ref["reduced"])
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f]), f
+    for i in range(len(red)):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(a, ref["a"][i]), i
+        assert np.array_equal(d, ref["d"][i]), i
+    return ctx, ref
+
+
+CASES = [
+    # m, n, L, K, Brec, mu, seed, kind, block_len
+    (8, 1000, 10, 3, 100, 5e-3, 0x5EED0001, 0, 0),       # BASELINE config C1
+    (8, 1000, 10, 3, 100, 5e-3, 0x5EED0001, 0, 1),       # B = 1
+    (8, 1000, 10, 3, 100, 5e-3, 0x5EED0001, 0, 1000),    # one block
+    (24, 400, 7, 4, 60, 1e-2, 11, 0, 37),
+    (40, 300, 20, 5, 50, 5e-3, 12, 0, 64),
+    (16, 64, 32, 2, 30, 1e-2, 13, 0, 10),                # n == 2L
+    (12, 200, 1, 3, 20, 2e-2, 15, 0, 7),                 # L = 1
+    (70, 500, 9, 6, 45, 8e-3, 21, 0, 50),                # 64 < m <= 448 : one wave, 7 rows per lane
+    (300, 2000, 25, 8, 200, 2e-3, 22, 0, 0),             # T = 256, E = 5
+    (1000, 3000, 30, 10, 300, 1e-3, 23, 0, 100),
+    (2500, 4000, 50, 16, 2000, 1e-4, 0x5EED0002, 0, 0),  # C2 rows, shortened columns (T=256, E=11)
+    (3000, 1500, 40, 12, 500, 5e-4, 24, 0, 128),         # T = 1024, E = 7
+    (30, 300, 8, 4, 50, 1e-2, 5, 1, 32),                 # sigma = 16
+    (600, 1500, 20, 8, 300, 2e-3, 25, 1, 64),            # sigma = 16, T = 256
+    (1, 50, 5, 1, 10, 0.0, 26, 0, 8),                    # single row: cannot reduce
+]
+
+
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed,kind,B", CASES)
+def test_long_path_matches_oracle(pkg, m, n, L, K, Brec, mu, seed, kind, B):
+    msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+    compare_long(pkg, msa, L, block_len=B)
+
+
+def test_block_states_and_lists_match_oracle(pkg):
+    m, n, L, B = 200, 1200, 15, 100
+    msa = fso.synth_msa(fso.synth_spec(31, 6, 150, 3e-3), m, n)
+    ctx = run_gpu(pkg, msa, L, block_len=B)
+    p = fso.Pbwt(msa, debug=False)
+    nblocks = (n + B - 1) // B
+    for k in range(n + 1):
+        if k % B == 0 or k == n:
+            b = k // B if k < n else nblocks
+            a, d = ctx.debug_block_state(b)
+            assert np.array_equal(a, p.a), k
+            assert np.array_equal(d, p.d), k
+        if k < n:
+            p.step()
+            if k % 7 == 0 or k > n - 5:
+                v, c = p.counts()
+                gv, gc, cnt0, complete = ctx.debug_column_list(k)
+                assert complete or gc.sum() > ctx.timings()["list_cap_used"]
+                assert np.array_equal(gv, v[::-1][:len(gv)]), k
+                assert np.array_equal(gc, c[::-1][:len(gc)]), k
+                assert cnt0 == (c[0] if v[0] == 0 else 0)
+
+
+def test_small_list_cap_retries_to_exact_result(pkg):
+    msa = fso.synth_msa(fso.synth_spec(77, 4, 60, 1e-2), 60, 400)
+    ctx, ref = compare_long(pkg, msa, 10, block_len=40, list_cap=2)
+    t = ctx.timings()
+    assert t["retries"] >= 1 and t["list_cap_used"] > 2
+
+
+def test_unreducible_input_reports_no_reduction(pkg):
+    rng = np.random.default_rng(0)
+    msa = (rng.integers(0, 4, size=(6, 200)) + 65).astype(np.uint8)
+    ctx = pkg.SegmentationContext(6, 200, 20)
+    ctx.set_sequences(msa)
+    with pytest.raises(pkg.NoReduction):
+        ctx.run()
+    ref = fso.segment_long(msa, 20)
+    assert ref["status"] == 1 and ctx.result.max_segment_size == ref["max_segment_size"]
+
+
+def test_short_path_matches_oracle(pkg):
+    spec = fso.synth_spec(3, 3, 1000, 1e-3)
+    msa = fso.synth_msa(spec, 50, 30)
+    ctx = pkg.SegmentationContext(50, 30, 20)       # n < 2L
+    ctx.set_sequences(msa)
+    res = ctx.run()
+    assert res.short_path == 1
+    f, r = fso.segment_short(msa)
+    gf, gr = ctx.short_path_runs()
+    assert res.max_segment_size == len(f)
+    assert np.array_equal(gf, f) and np.array_equal(gr, r)
+
+
+def test_device_generator_matches_host_generator(pkg):
+    for name, m, n in (("C1", 8, 1000), ("C2", 100, 3000), ("C5", 64, 2000)):
+        c = fso.CONFIGS[name]
+        ctx = pkg.SegmentationContext(m, n, c["L"])
+        ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+        host = fso.synth_msa(fso.config_spec(name), m, n)
+        assert np.array_equal(ctx.get_sequences(), host)
+        assert np.array_equal(ctx.get_sequences(10, 50), host[:, 10:50])
+
+
+def test_row_major_and_column_major_inputs_agree(pkg):
+    msa = fso.synth_msa(fso.synth_spec(9, 4, 80, 5e-3), 33, 700)
+    c1 = run_gpu(pkg, np.asfortranarray(msa), 12)
+    c2 = run_gpu(pkg, np.ascontiguousarray(msa), 12)
+    assert np.array_equal(c1.reduced_traceback(), c2.reduced_traceback())
+    a1, d1 = c1.boundary_state(0)
+    a2, d2 = c2.boundary_state(0)
+    assert np.array_equal(a1, a2) and np.array_equal(d1, d2)
+
+
+def test_config_c2_full_size_properties(pkg):
+    """BASELINE config C2 at full size: size-independent properties + oracle parity of the result."""
+    c = fso.CONFIGS["C2"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    tb = ctx.traceback()
+    red = ctx.reduced_traceback()
+    # segments tile [0, n), each at least L long, merged boundaries are DP boundaries
+    assert tb["lb"][0] == 0 and tb["rb"][-1] == n
+    assert np.array_equal(tb["lb"][1:], tb["rb"][:-1]) and (tb["rb"] - tb["lb"]).min() >= L
+    assert red["lb"][0] == 0 and red["rb"][-1] == n and np.array_equal(red["lb"][1:], red["rb"][:-1])
+    assert set(red["rb"].tolist()) <= set(tb["rb"].tolist())
+    assert res.max_segment_size == tb["segment_size"].max() == tb["segment_max_size"][-1] < m
+    assert red["segment_size"].max() <= res.max_segment_size
+    # boundary states are permutations and their divergences reproduce the segment sizes
+    for i in (0, len(red) // 2, len(red) - 1):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(np.sort(a), np.arange(m))
+        assert int((d > red["lb"][i]).sum()) == red["segment_size"][i]
+        assert d[0] == red["rb"][i]
+    # idempotence
+    res2 = ctx.run()
+    assert np.array_equal(ctx.reduced_traceback(), red) and res2.max_segment_size == res.max_segment_size
+    # the oracle on the same input (a few seconds of CPU)
+    msa = fso.synth_msa(fso.config_spec("C2"), m, n)
+    ref = fso.segment_long(msa, L, threads=8)
+    assert ref["max_segment_size"] == res.max_segment_size
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f])
+    for i in (0, len(red) // 3, len(red) - 1):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
