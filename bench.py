@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- alignment cells/s through pBWT + segmentation DP on MI355X.
+
+One "step" = one complete pass of the hot path (everything segmentation_lp_context does:
+pBWT pass 1 + DP, traceback, segment merge, pass-2 boundary states) over one synthetic
+founder-mosaic alignment that is already resident in HBM (column-major, 1 B/cell).
+Workload at N=1: BASELINE.json configs[1] (C2: m=2,500 x n=100,000, sigma=4, L=50).
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+N > 1 (this round): every rank segments its own alignment of the same shape (different seed), no
+data-path collective -> "scaling": "weak"; value = all ranks' cells / max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "oracle")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+BYTES_PER_CELL = 17             # 1 (symbol) + 4+4 (a_k,d_k read) + 4+4 (a_k+1,d_k+1 written)
+
+WORKLOADS = {
+    # name: m, n, L, founders K, recombination block, mutation rate, seed, kind
+    "C1": dict(m=8, n=1000, L=10, K=3, B=100, mu=5e-3, seed=0x5EED0001, kind=0),
+    "C2": dict(m=2500, n=100000, L=50, K=16, B=2000, mu=1e-4, seed=0x5EED0002, kind=0),
+    "C3": dict(m=2504, n=1000000, L=100, K=24, B=5000, mu=1e-4, seed=0x5EED0003, kind=0),
+}
+
+
+def cpu_baseline(ctx, w, threads):
+    """The oracle (CPU restatement, -O2) timed on this host: pass 1 on one core as the reference
+    runs it, pass 2 on `threads` threads.  Sample = the whole workload when it is
+    small enough, else a column prefix."""
+    import numpy as np
+    import fso
+    m, n, L = w["m"], w["n"], w["L"]
+    ncols = n
+    budget_cells = 3.0e8                     # ~10-30 s of CPU work
+    if m * n > budget_cells:
+        ncols = max(4 * L, int(budget_cells // m))
+    msa = np.ascontiguousarray(ctx.get_sequences(0, ncols))        # row-major, as the reference holds it
+    t0 = time.perf_counter()
+    r = fso.segment_long(msa, L, sample_rate=fso.sample_rate_for(ncols), threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": m * ncols / dt,
+        "unit": "cells/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": "oracle/fseq_oracle.c on the same synthetic input, first %d of %d columns, all %d rows, row-major; "
+                  "pass 1 + DP on 1 thread (%.2f s), pass 2 on %d threads (%.2f s), host has %d cores"
+                  % (ncols, n, m, r["t_pass1"], r["pass2_threads"], r["t_pass2"], os.cpu_count() or 0),
+        "seconds": dt,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--block-len", type=int, default=0)
+    ap.add_argument("--list-cap", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the segmentation path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("founder-sequences_amd")
+    w = dict(WORKLOADS[args.workload])
+    m, n, L = w["m"], w["n"], w["L"]
+    ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
+    ctx.generate_synthetic(w["seed"] + 0x1000 * rank, w["K"], w["B"], w["mu"], w["kind"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.run()
+    barrier()
+    t0 = time.perf_counter()
+    phase = {}
+    for _ in range(args.steps):
+        ctx.run()
+        t = ctx.timings()
+        for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
+            phase[k] = phase.get(k, 0.0) + t[k]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    t = ctx.timings()
+    res = ctx.result
+    steps = max(1, args.steps)
+    ms_c = phase["ms_phase_c"] / steps          # one k_columns launch per step (plus retries, if any)
+    launches_c = 1 + t["retries"]
+    achieved = BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9
+    out = {
+        "metric": "alignment cells/s (m*n/T) through pBWT+DP",
+        "value": world * m * n * steps / dt,
+        "unit": "cells/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32",
+        "data": "synthetic",
+        "config": {
+            "workload": "%s: m=%d x n=%d synthetic founder-mosaic DNA (sigma=%d), segment-length-bound L=%d, "
+                        "input resident in HBM column-major 1 B/cell; per rank one alignment"
+                        % (args.workload, m, n, 16 if w["kind"] else 4, L),
+            "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
+            "segments": int(res.segment_count), "dp_segments": int(res.dp_segment_count),
+            "max_segment_size": int(res.max_segment_size),
+            "phases_ms": {k: round(v / steps, 4) for k, v in phase.items()},
+            "pass2_cells": int(t["pass2_cells"]),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "k_columns (per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
+            "avg_launch_ms": ms_c / launches_c,
+        },
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(ctx, w, args.cpu_threads or min(os.cpu_count() or 1, 16))
+    else:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
