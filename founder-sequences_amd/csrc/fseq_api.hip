@@ -29,7 +29,7 @@ struct KernelSet {
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint32_t *, uint32_t *);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint2 *, uint4 *);
+	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *);
 	size_t lds_chain;
 	void (*chain)(hipStream_t, size_t lds, uint32_t const *, uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t *, uint32_t *);
 	hipError_t (*prepare)(size_t lds_columns);
@@ -58,9 +58,9 @@ struct Launch {
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr)
+	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, X, stride, ent, hdr);
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr);
 	}
 	static void chain(hipStream_t st, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nblocks, uint32_t *ba, uint32_t *bd)
@@ -243,6 +243,7 @@ int prepare_geometry(fseq_ctx *c)
 	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT)
 		return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 	HIP_TRY(c, c->ks.prepare(c->lds_columns));
+	HIP_TRY(c, allow_lds(k_dp, dp_lds_bytes()));
 	c->kernels_ready = true;
 	return FSEQ_OK;
 }
@@ -260,7 +261,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_bstate_a, ((size_t) c->nblocks + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bstate_d, ((size_t) c->nblocks + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
-		if ((rc = dev_alloc(c, &c->d_flags, 4))) return rc;
+		if ((rc = dev_alloc(c, &c->d_flags, 64))) return rc;
 		if (p.n >= 2 * p.segment_length)
 		{
 			c->dp_size = p.n - p.segment_length + 1;
@@ -268,16 +269,16 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if ((rc = dev_alloc(c, &c->dp.M, c->dp_size))) return rc;
 			if ((rc = dev_alloc(c, &c->dp.LB, c->dp_size))) return rc;
 			if ((rc = dev_alloc(c, &c->dp.SZ, c->dp_size))) return rc;
-			if ((rc = dev_alloc(c, &c->dp.P, c->dp_size))) return rc;
-			if ((rc = dev_alloc(c, &c->dp.S, c->dp_size + 64))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.K, c->dp_size + 64))) return rc;
 			if ((rc = dev_alloc(c, &c->dp.Tb, (size_t) 32 * c->dp.tstride))) return rc;
+			if ((rc = dev_alloc(c, &c->dp.Tbv, (size_t) 32 * c->dp.tstride))) return rc;
 		}
 	}
 	if (!c->d_ent || c->X != X)
 	{
 		c->X = X;
-		c->stride = (X + 1 + 1) & ~1u;            // X+1 entries, even
-		if ((rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride))) return rc;
+		c->stride = (X + 3) & ~1u;                // lump + up to X+1 entries, even
+		if ((rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256))) return rc;   // padded: the DP loads strips unconditionally
 	}
 	return FSEQ_OK;
 }
@@ -287,7 +288,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
-	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.P); dev_free(&c->dp.S); dev_free(&c->dp.Tb);
+	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_cols); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d);
 	c->cols_cap = c->gather_cap = c->snap_cap = 0;
@@ -388,9 +389,9 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		// ---- phase C + D
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, c->X, c->stride, c->d_ent, c->d_hdr);
+		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr);
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
-		hipLaunchKernelGGL((k_dp<1024>), dim3(1), dim3(1024), 0, st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
+		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
 		HIP_TRY(c, hipGetLastError());
 

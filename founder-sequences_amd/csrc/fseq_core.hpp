@@ -26,17 +26,43 @@ __device__ __forceinline__ uint32_t shfl_up_u32(uint32_t v, int delta) { return 
 __device__ __forceinline__ uint32_t shfl_dn_u32(uint32_t v, int delta) { return (uint32_t) __shfl_down((int) v, delta, WAVE); }
 __device__ __forceinline__ uint32_t shfl_u32(uint32_t v, int src) { return (uint32_t) __shfl((int) v, src, WAVE); }
 
+// ---- DPP cross-lane moves (VALU, no LDS traffic).  A lane whose source is outside its row, or
+// whose row is masked out, keeps `old` -- pass the operator's identity there.
+// wave64 inclusive scan = row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 into rows
+// 1 and 3, then row_bcast:31 into rows 2 and 3.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_mov(uint32_t old, uint32_t src)
+{
+	return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) src, CTRL, ROW_MASK, 0xF, false);
+}
+
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143, DPP_WAVE_SHR1 = 0x138;
+
+__device__ __forceinline__ uint32_t readlane_u32(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
+
 // inclusive add-scan over the 64 lanes of a wave
 __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
 {
-	uint32_t const lane = lane_id();
-#pragma unroll
-	for (int delta = 1; delta < WAVE; delta <<= 1)
-	{
-		uint32_t const o = shfl_up_u32(v, delta);
-		if (lane >= (uint32_t) delta) v += o;
-	}
+	v += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v);
+	v += dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, v);
 	return v;
+}
+
+// minimum over the 64 lanes of a wave (returned in every lane)
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+	v = min(v, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, v));
+	return readlane_u32(v, 63);
 }
 
 // Block-wide exclusive add-scan of one uint32 per thread. scratch: T/64 + 1 words of LDS.
@@ -48,7 +74,7 @@ __device__ __forceinline__ uint32_t block_excl_add(uint32_t v, uint32_t *scratch
 	uint32_t const inc = wave_incl_add(v);
 	if (NW == 1)
 	{
-		*total = shfl_u32(inc, 63);
+		*total = readlane_u32(inc, 63);
 		return inc - v;
 	}
 	__syncthreads();                       // protect scratch against the previous use
@@ -101,6 +127,30 @@ struct Summary {
 			val[x] = ((has >> x) & 1u) ? val[x] : mx;
 		}
 		has |= L.has;
+	}
+
+	// identity where the DPP source lane is invalid / the row is masked
+	template <int CTRL, int ROW_MASK>
+	__device__ __forceinline__ Summary dpp_shifted() const
+	{
+		Summary o;
+#pragma unroll
+		for (int i = 0; i < NC; ++i) o.cnt[i] = dpp_mov<CTRL, ROW_MASK>(0u, cnt[i]);
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) o.val[x] = dpp_mov<CTRL, ROW_MASK>(0u, val[x]);
+		o.has = dpp_mov<CTRL, ROW_MASK>(0u, has);
+		return o;
+	}
+
+	__device__ __forceinline__ Summary from_lane_uniform(int src) const
+	{
+		Summary o;
+#pragma unroll
+		for (int i = 0; i < NC; ++i) o.cnt[i] = readlane_u32(cnt[i], src);
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) o.val[x] = readlane_u32(val[x], src);
+		o.has = readlane_u32(has, src);
+		return o;
 	}
 
 	__device__ __forceinline__ Summary shifted_up(int delta) const
@@ -194,13 +244,13 @@ __device__ __forceinline__ void partition_step(
 	for (int x = 0; x < SIGMA; ++x) S.val[x] = run[x];
 	S.has = has;
 
-	// ---- wave-level inclusive scan
-#pragma unroll
-	for (int delta = 1; delta < WAVE; delta <<= 1)
-	{
-		Summary<SIGMA> const L = S.shifted_up(delta);
-		if (lane >= (uint32_t) delta) S.prepend(L);
-	}
+	// ---- wave-level inclusive scan (DPP; the identity summary is neutral for prepend)
+	S.prepend(S.template dpp_shifted<DPP_ROW_SHR1, 0xF>());
+	S.prepend(S.template dpp_shifted<DPP_ROW_SHR2, 0xF>());
+	S.prepend(S.template dpp_shifted<DPP_ROW_SHR4, 0xF>());
+	S.prepend(S.template dpp_shifted<DPP_ROW_SHR8, 0xF>());
+	S.prepend(S.template dpp_shifted<DPP_ROW_BCAST15, 0xA>());
+	S.prepend(S.template dpp_shifted<DPP_ROW_BCAST31, 0xC>());
 	if (NW > 1 && lane == 63)
 	{
 #pragma unroll
@@ -209,14 +259,13 @@ __device__ __forceinline__ void partition_step(
 		for (int x = 0; x < SIGMA; ++x) scr.val[wave][x] = S.val[x];
 		scr.has[wave] = S.has;
 	}
-	// exclusive within the wave
-	Summary<SIGMA> C = S.shifted_up(1);
-	if (lane == 0) C.clear();
+	// exclusive within the wave (wave_shr:1; lane 0 keeps the identity)
+	Summary<SIGMA> C = S.template dpp_shifted<DPP_WAVE_SHR1, 0xF>();
 
 	Summary<SIGMA> TOT;                     // whole-block totals (counts only are used)
 	if (NW == 1)
 	{
-		TOT = S.from_lane(63);
+		TOT = S.from_lane_uniform(63);
 		__syncthreads();
 	}
 	else

@@ -411,7 +411,7 @@ template <int T, int E, int SIGMA>
 __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr)
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -552,38 +552,47 @@ __global__ __launch_bounds__(T) void k_columns(
 		__syncthreads();
 
 		// ---- emit the top of the histogram for column k0+j (wave 0; the others run ahead into
-		// the next column and meet it again at the partition step's barrier)
+		// the next column and meet it again at the partition step's barrier).
+		// Entry 0 lumps every value >= thr = end+1-L (end = k+1): the DP clips all of them to the same
+		// cut bound (lp.cc:444-445), so only their total count matters.  Then the distinct values
+		// below thr, descending, until their cumulative count exceeds X (every DP cell is >= the lump's
+		// count, so the list always reaches X counts past the smallest value the cell can take).
 		if (wave_id() == 0)
 		{
 			uint32_t const lane = lane_id();
 			uint64_t const k = k0 + j;
+			uint32_t const thr = (k + 2 > (uint64_t) L) ? (uint32_t) (k + 2 - L) : 0u;
 			uint2 *out = ent + k * (size_t) stride;
 			int32_t const top = (int32_t) (D0 + j);
-			uint32_t cum = 0, nent = 0;
+			uint32_t cumN = 0, nent = 1, R = 0;       // cumN: count of the values below thr taken so far
 			for (int32_t base = top; base >= 0; base -= 64)
 			{
 				int32_t const i = base - (int32_t) lane;
 				uint32_t const c = (i >= 0) ? cnt_l[i] : 0u;
+				uint32_t const v = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
 				bool const nz = c > 0;
-				uint64_t const mask = __ballot(nz);
+				bool const rec = nz && v >= thr;
 				uint32_t const inc = wave_incl_add(c);
-				uint32_t const exc = cum + inc - c;
-				bool const take = nz && exc <= X;
-				uint32_t const pos = nent + (uint32_t) __popcll(mask & ((1ull << lane) - 1ull));
-				if (take)
-				{
-					uint32_t const v = ((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u);
-					out[pos] = make_uint2(v, c);
-				}
+				uint64_t const rmask = __ballot(rec);       // values descend with the lane: a prefix of the non-zero lanes
+				uint32_t const r_inc = rmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(rmask)) : 0u;
+				uint32_t const excN = cumN + (inc - r_inc) - c;
+				bool const take = nz && !rec && excN <= X;
+				uint64_t const omask = __ballot(nz && !rec);
+				uint32_t const pos = nent + (uint32_t) __popcll(omask & ((1ull << lane) - 1ull));
+				if (take) out[pos] = make_uint2(v, c);
 				uint64_t const tmask = __ballot(take);
 				nent += (uint32_t) __popcll(tmask);
-				// counts of the taken lanes: they are a prefix of the non-zero lanes
-				uint32_t const taken_inc = shfl_u32(inc, tmask ? 63 - (int) __builtin_clzll(tmask) : 0);
-				cum += tmask ? taken_inc : 0u;
-				if (tmask != mask || cum > X) break;
+				uint32_t const t_inc = tmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(tmask)) : r_inc;
+				cumN += t_inc - r_inc;
+				R += r_inc;
+				if (tmask != omask || cumN > X) break;
 			}
+			uint32_t const cum = R + cumN;
 			if (lane == 0)
+			{
+				out[0] = make_uint2((uint32_t) (k + 1), R);
 				hdr[k] = make_uint4(nent, zero_present ? cnt_l[0] : 0u, cum == m ? 1u : 0u, cum);
+			}
 		}
 	}
 }
@@ -595,206 +604,474 @@ __global__ __launch_bounds__(T) void k_columns(
 // rmq.hh semantics (block 64) via P (first-min of the block prefix), S (first-min of the block
 // suffix) and the sparse table Tb with the smp1 == smp2 quirk (rmq.hh:76-79).
 // ------------------------------------------------------------------------------------------------
+// K[t]: 64-bit mask over the 64-block of t; bit p (p <= t mod 64) is set iff M[p] <= min(M[p+1..t])
+// (the monotonic stack after scanning the block up to t, popping only strictly greater keys).
+// The first minimum of [b, t] inside one block (std::min_element, rmq.hh:116) is the lowest set
+// bit of K[t] at or above b -- every partial-block scan of rmq.hh in O(1).
+// Tb[p][j] / Tbv[p][j]: sparse-table sample (index / key) of rmq.hh's m_precalc[p][j].
 struct DpArrays {
-	uint32_t *M, *LB, *SZ, *P, *S, *Tb;
+	uint32_t *M, *LB, *SZ, *Tb, *Tbv;
+	unsigned long long *K;
 	uint32_t tstride;
 };
 
-__device__ __forceinline__ uint32_t rmq_naive(DpArrays const &A, uint32_t b, uint32_t e)
+// One workgroup of 16 waves, specialised: 14 compute waves that touch LDS only, one loader wave
+// that streams the per-column lists (and the old sparse-table samples the update needs) into LDS
+// two rounds ahead with LDS-DMA, one writer wave that flushes finished rounds to HBM.  A global
+// memory round trip costs ~1.5 us here, a round must cost about that in total, so no wave that
+// the round barriers wait for may ever wait on HBM.
+constexpr uint32_t DPW = 4096;            // DP entries mirrored in LDS (ring, slot = index mod DPW)
+constexpr uint32_t DP_RL = 56;            // cells per round (<= L)
+constexpr uint32_t DP_NWC = 14;           // compute waves
+constexpr int      DP_G = 4;              // cells per compute wave per round (14 * 4 = 56)
+constexpr uint32_t DP_STG = 512;          // staging ring for LB / SZ
+constexpr uint32_t DP_TRN = 64;           // sparse-table ring: last 64 samples of every level
+constexpr uint32_t DP_LEVELS = 32;
+constexpr uint32_t DP_HPMIN = 7;          // levels >= 7: input sample is older than the ring -> mailbox
+constexpr uint32_t DP_SLOTS = 3;          // list slots: rounds r, r+1, r+2
+constexpr uint32_t DP_Q = DP_RL / 2 + 1 + 2;   // LDS-DMA instructions the loader issues per round
+constexpr uint32_t DP_LOADER = 14, DP_WRITER = 15;
+
+// LDS pointers carry their address space so that a choice between an LDS and an HBM source stays
+// two different loads (ds_read vs global_load) instead of one flat load through a selected pointer
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+
+struct DpLds {
+	lds_u64 *Kr;
+	lds_u32 *Mr, *LBr, *SZr, *Tr, *Trv;
+	lds_u32 *LS;                          // [DP_SLOTS][DP_RL][64] x {value, count}
+	lds_u32 *H;                           // [DP_SLOTS][64] x {n_entries, cnt0, complete, cum}
+	lds_u32 *MBi, *MBv;                   // [DP_SLOTS][64]
+};
+
+__host__ __device__ inline size_t dp_lds_bytes()
 {
-	uint32_t const bb = b >> 6, eb = (e - 1u) >> 6;
+	return carve_bytes(DPW, 8) + carve_bytes(DPW, 4) + 2 * carve_bytes(DP_STG, 4) + 2 * carve_bytes((size_t) DP_LEVELS * DP_TRN, 4)
+	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_SLOTS * 64, 4);
+}
+
+// where a query may read: entries >= safe_lo and samples produced after block cb - DP_TRN live in LDS
+struct DpView {
+	uint32_t safe_lo;     // first DP entry guaranteed to be in the LDS ring during this round
+	uint32_t cb;          // complete (indexed) blocks at the start of this round
+};
+
+__device__ __forceinline__ uint32_t dp_key(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t i)
+{
+	return i >= V.safe_lo ? D.Mr[i & (DPW - 1u)] : A.M[i];
+}
+
+__device__ __forceinline__ unsigned long long dp_mask(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t i)
+{
+	return i >= V.safe_lo ? D.Kr[i & (DPW - 1u)] : A.K[i];
+}
+
+// sample (p, j) was produced when block j + 2^p - 1 completed
+__device__ __forceinline__ void dp_sample(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t p, uint32_t j, uint32_t *idx, uint32_t *val)
+{
+	if (j + (1u << p) + DP_TRN > V.cb + 2u)
+	{
+		*idx = D.Tr[p * DP_TRN + (j & (DP_TRN - 1u))];
+		*val = D.Trv[p * DP_TRN + (j & (DP_TRN - 1u))];
+	}
+	else
+	{
+		*idx = A.Tb[(size_t) p * A.tstride + j];
+		*val = A.Tbv[(size_t) p * A.tstride + j];
+	}
+}
+
+// rmq.hh:85-105 (operator()), every query of the DP has end <= number of indexed entries.
+// Returns the index; *val = its key.
+__device__ __forceinline__ uint32_t rmq_query(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t beg, uint32_t end, uint32_t *val)
+{
+	uint32_t const bb = beg >> 6, eb = (end - 1u) >> 6;
+	uint32_t const beg_block = bb + 1u, end_block = end >> 6;
+	uint32_t const ie = end - 1u;
+	unsigned long long const ke = dp_mask(A, D, V, ie);
 	if (bb == eb)
 	{
-		if ((b & 63u) == 0) return A.P[e - 1u];
-		if ((e & 63u) == 0) return A.S[b];
-		uint32_t best = b, bv = A.M[b];
-		for (uint32_t u = b + 1; u < e; ++u)
-		{
-			uint32_t const v = A.M[u];
-			if (v < bv) { bv = v; best = u; }
-		}
-		return best;
+		// beg_block >= end_block, one block: naive_min (rmq.hh:90-91)
+		uint32_t const idx = beg + (uint32_t) __builtin_ctzll(ke >> (beg & 63u));
+		*val = dp_key(A, D, V, idx);
+		return idx;
 	}
-	uint32_t const left = A.S[b], right = A.P[e - 1u];
-	return (A.M[right] < A.M[left]) ? right : left;
-}
-
-// rmq.hh:85-105
-__device__ __forceinline__ uint32_t rmq_query(DpArrays const &A, uint32_t beg, uint32_t end)
-{
-	uint32_t const beg_block = (beg >> 6) + 1u;
-	uint32_t const end_block = end >> 6;
-	if (beg_block >= end_block)
-		return rmq_naive(A, beg, end);
-	uint32_t const pow2 = 31u - (uint32_t) __builtin_clz(end_block - beg_block);
-	uint32_t const smp1 = A.Tb[(size_t) pow2 * A.tstride + beg_block];
-	uint32_t const smp2 = A.Tb[(size_t) pow2 * A.tstride + end_block - (1u << pow2)];
-	uint32_t smp = (A.M[smp2] < A.M[smp1]) ? smp2 : smp1;
-	uint32_t const left = A.S[beg];
-	smp = (A.M[left] < A.M[smp]) ? left : smp;
-	if (end == end_block * 64u)
-		return smp;
-	uint32_t const right = A.P[end - 1u];
-	return (A.M[right] < A.M[smp]) ? right : smp;
-}
-
-__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
-{
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1)
+	unsigned long long const kb = dp_mask(A, D, V, (bb << 6) + 63u);
+	uint32_t const il = beg + (uint32_t) __builtin_ctzll(kb >> (beg & 63u));   // naive_min(beg, beg_block*64)
+	uint32_t const ir = (ie & ~63u) + (uint32_t) __builtin_ctzll(ke);           // naive_min(end_block*64, end)
+	uint32_t const m_il = dp_key(A, D, V, il), m_ir = dp_key(A, D, V, ir);
+	uint32_t idx, v;
+	if (beg_block < end_block)
 	{
-		uint32_t const lo = (uint32_t) __shfl_xor((int) (uint32_t) v, off, WAVE);
-		uint32_t const hi = (uint32_t) __shfl_xor((int) (uint32_t) (v >> 32), off, WAVE);
-		uint64_t const o = ((uint64_t) hi << 32) | lo;
-		v = o < v ? o : v;
+		uint32_t const pow2 = 31u - (uint32_t) __builtin_clz(end_block - beg_block);
+		uint32_t t1, t2, m_t1, m_t2;
+		dp_sample(A, D, V, pow2, beg_block, &t1, &m_t1);
+		dp_sample(A, D, V, pow2, end_block - (1u << pow2), &t2, &m_t2);
+		idx = t1; v = m_t1;
+		if (m_t2 < v) { idx = t2; v = m_t2; }                   // rmq.hh:96
+		if (m_il < v) { idx = il; v = m_il; }                   // rmq.hh:97-98
+		if ((end & 63u) != 0 && m_ir < v) { idx = ir; v = m_ir; }   // rmq.hh:100-104
 	}
-	return v;
+	else
+	{
+		// two adjacent blocks: naive_min over [beg, block end) ++ [block start, end), first minimum
+		idx = il; v = m_il;
+		if (m_ir < v) { idx = ir; v = m_ir; }
+	}
+	*val = v;
+	return idx;
 }
 
-// One DP cell, evaluated by a whole wave (calculate_segmentation_lp_dp_arg, lp.cc:393-481, with the
+// State of one DP cell while a wave evaluates it (calculate_segmentation_lp_dp_arg, lp.cc:393-481,
 // candidate ranges visited in descending divergence order and pruned exactly).
-__device__ __forceinline__ void dp_cell(
-	DpArrays const &A, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t stride,
-	uint32_t m, uint32_t L, uint32_t end, bool part2, uint32_t *flags)
+struct CellState {
+	uint32_t best_v, best_lb, best_sz, cum_base;
+};
+
+// One strip of 64 list entries starting at entry s0; lanes < ncand are candidates (the lane's
+// range needs the next entry's value).  Returns true when the cell is decided (pruned).
+__device__ __forceinline__ bool dp_strip(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint2 en_in, uint32_t vnext_in, uint32_t nent, uint32_t s0,
+	uint32_t ncand, uint32_t L, uint32_t end, CellState &st)
 {
 	uint32_t const lane = lane_id();
-	uint32_t const k = end - 1u;
-	uint4 const h = hdr[k];
-	uint32_t const nent = h.x, cnt0 = h.y, complete = h.z;
-	uint32_t const t = end - L;
-	if (part2)
+	uint32_t const i = s0 + lane;
+	bool const valid = i < nent;
+	bool const have_next = i + 1 < nent && lane < ncand;
+	uint2 const en = valid ? en_in : make_uint2(0u, 0u);
+	uint32_t const vnext = have_next ? vnext_in : 0u;
+	bool const is0 = valid && en.x == 0u;
+	uint32_t const cc = (valid && !is0) ? en.y : 0u;
+	uint32_t const cum = st.cum_base + wave_incl_add(cc);
+	bool ok = valid && !is0 && have_next && vnext != 0u;
+	uint32_t lo = vnext;
+	uint32_t const c = min(en.x, end + 1u - L);              // lp.cc:444-445 (text_pos + 2 - L)
+	if (lo < L)                                              // lp.cc:449-455 (lb == 0)
 	{
-		// lp.cc:85-93
-		if (lane == 0) { uint32_t const sz = m - cnt0; A.M[t] = sz; A.LB[t] = 0; A.SZ[t] = sz; }
-		return;
+		if (L < c) lo = L; else ok = false;
 	}
-	uint2 const *list = ent + (size_t) k * stride;
-	uint32_t best_v = 0xFFFFFFFFu, best_lb = 0, best_sz = 0;
-	uint32_t cum_base = 0;
-	for (uint32_t s0 = 0; s0 < nent; s0 += 64)
+	ok = ok && lo < c;                                       // lp.cc:458
+	uint32_t val = 0xFFFFFFFFu, idx = 0;
+	if (ok)
 	{
-		uint32_t const i = s0 + lane;
-		bool const valid = i < nent;
-		uint2 const en = valid ? list[i] : make_uint2(0u, 0u);
-		uint32_t vnext = shfl_dn_u32(en.x, 1);
-		if (lane == 63) vnext = (s0 + 64 < nent) ? list[s0 + 64].x : 0u;
-		bool const have_next = i + 1 < nent;
-		bool const is0 = valid && en.x == 0u;
-		uint32_t const cc = (valid && !is0) ? en.y : 0u;
-		uint32_t const cum = cum_base + wave_incl_add(cc);
-
-		bool ok = valid && !is0 && have_next && vnext != 0u;
-		uint32_t lo = vnext;
-		uint32_t const c = min(en.x, end + 1u - L);          // lp.cc:444-445 (text_pos + 2 - L)
-		if (lo < L)                                          // lp.cc:449-455 (lb == 0)
-		{
-			if (L < c) lo = L; else ok = false;
-		}
-		ok = ok && lo < c;                                   // lp.cc:458
-		uint32_t val = 0xFFFFFFFFu, idx = 0;
-		if (ok)
-		{
-			idx = rmq_query(A, lo - L, c - L);               // lp.cc:465
-			val = max(A.M[idx], cum);                        // lp.cc:468-471
-		}
-		uint64_t const key = ok ? (((uint64_t) val << 32) | (uint64_t) (0xFFFFFFFFu - i)) : ~0ull;
-		uint64_t const kmin = wave_min_u64(key);
-		if (kmin != ~0ull)
-		{
-			uint32_t const v = (uint32_t) (kmin >> 32);
-			if (v <= best_v)
-			{
-				uint64_t const wmask = __ballot(key == kmin);
-				int const src = (int) __builtin_ctzll(wmask);
-				best_v = v;
-				best_lb = shfl_u32(idx, src) + L;
-				best_sz = shfl_u32(cum, src);
-			}
-		}
-		cum_base = shfl_u32(cum, 63);
-		if (best_v != 0xFFFFFFFFu && cum_base > best_v) break;
+		uint32_t mv;
+		idx = rmq_query(A, D, V, lo - L, c - L, &mv);        // lp.cc:465
+		val = max(mv, cum);                                  // lp.cc:468-471
 	}
-	bool const stopped = best_v != 0xFFFFFFFFu && cum_base > best_v;
-	if (!complete && !stopped)
+	// minimum value; among equal values the candidate the reference visits first = the largest i
+	// (lowest divergence value) = the highest lane of the strip
+	uint32_t const vmin = wave_min_u32(val);
+	if (vmin != 0xFFFFFFFFu && vmin <= st.best_v)
 	{
-		if (lane == 0) atomicOr(flags, 1u);                  // list too short to prove the result
+		uint64_t const wmask = __ballot(ok && val == vmin);
+		int const src = 63 - (int) __builtin_clzll(wmask);
+		st.best_v = vmin;
+		st.best_lb = shfl_u32(idx, src) + L;
+		st.best_sz = shfl_u32(cum, src);
 	}
-	if (complete && cnt0 > 0)
-	{
-		uint32_t const w = m - cnt0;                         // lp.cc:416-421, visited first by the reference
-		if (w <= best_v) { best_v = w; best_lb = 0; best_sz = w; }
-	}
-	if (m <= best_v) { best_v = m; best_lb = 0; best_sz = m; }   // initial min_arg, lp.cc:123
-	if (lane == 0) { A.M[t] = best_v; A.LB[t] = best_lb; A.SZ[t] = best_sz; }
+	bool const last = s0 + 64u >= nent;                       // strip reaches the end of the list
+	st.cum_base = readlane_u32(cum, 63);
+	if (!last && ncand < 64u) st.cum_base = readlane_u32(cum, 62);
+	return st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
 }
 
-template <int T>
-__global__ __launch_bounds__(T) void k_dp(
+// LDS-DMA: every lane names its own 16 (or 4) global bytes; they land at LDS address lds + lane * size.
+// Inline asm on purpose: the loader wave counts these itself (s_waitcnt vmcnt(DP_Q) = "the round
+// before the one just issued has landed"); issued through the builtin, hipcc would drain them
+// with vmcnt(0) in front of every barrier and LDS read that follows.  M0 carries the LDS base
+// and is restored (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma4(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
+struct DpRound {
+	uint32_t e0, len, t0, t1;
+	bool final_round;
+};
+
+__device__ __forceinline__ DpRound dp_round(uint32_t r, uint32_t L, uint32_t n, uint32_t RL, uint32_t nrounds)
+{
+	DpRound R;
+	uint32_t const last_end = n - L;
+	R.final_round = (r + 1u == nrounds);
+	R.e0 = R.final_round ? n : (L + r * RL);
+	R.len = R.final_round ? 1u : min(RL, last_end - R.e0 + 1u);
+	R.t0 = R.e0 - L;
+	R.t1 = R.t0 + R.len;
+	return R;
+}
+
+__device__ __forceinline__ void dp_barrier()
+{
+	// LDS traffic only; outstanding HBM loads / stores of the loader and writer waves stay in flight
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+__global__ __launch_bounds__(1024) void k_dp(
 	DpArrays const A, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t stride,
 	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags)
 {
-	constexpr uint32_t NW = T / WAVE;
-	uint32_t const wave = wave_id();
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	lds_char *const lds0 = (lds_char *) smem;
+	uint32_t const lds0_addr = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) lds0);   // LDS byte address of the carve base
+	uint32_t off = 0;
+	auto take = [&](size_t bytes) { uint32_t const o = off; off += (uint32_t) ((bytes + 15) & ~size_t(15)); return o; };
+	DpLds D;
+	D.Kr = (lds_u64 *) (lds0 + take((size_t) DPW * 8));
+	D.Mr = (lds_u32 *) (lds0 + take((size_t) DPW * 4));
+	D.LBr = (lds_u32 *) (lds0 + take((size_t) DP_STG * 4));
+	D.SZr = (lds_u32 *) (lds0 + take((size_t) DP_STG * 4));
+	D.Tr = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	D.Trv = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	uint32_t const off_LS = take((size_t) DP_SLOTS * DP_RL * 64 * 8);
+	uint32_t const off_H = take((size_t) DP_SLOTS * 64 * 16);
+	uint32_t const off_MBi = take((size_t) DP_SLOTS * 64 * 4);
+	uint32_t const off_MBv = take((size_t) DP_SLOTS * 64 * 4);
+	D.LS = (lds_u32 *) (lds0 + off_LS);
+	D.H = (lds_u32 *) (lds0 + off_H);
+	D.MBi = (lds_u32 *) (lds0 + off_MBi);
+	D.MBv = (lds_u32 *) (lds0 + off_MBv);
+
+	uint32_t const wave = __builtin_amdgcn_readfirstlane(wave_id());
 	uint32_t const lane = lane_id();
 	uint32_t const p2lim = min(2u * L, n - L) - 1u;          // lp.cc:72
 	uint32_t const last_end = n - L;                          // lp.cc:113
+	uint32_t const RL = min(L, DP_RL);
+	uint32_t const nrounds = (last_end - L) / RL + 1u + 1u;   // regular rounds + the final cell at rb = n (lp.cc:165-183)
 
-	for (uint32_t e0 = L; e0 <= last_end; e0 += L)
-	{
-		uint32_t const len = min(L, last_end - e0 + 1u);
-		for (uint32_t i = wave; i < len; i += NW)
+	// loader: all LDS-DMA of round R (exactly DP_Q instructions, so that vmcnt counts rounds)
+	auto load_round = [&](uint32_t r) {
+		DpRound const R = dp_round(r, L, n, RL, nrounds);
+		uint32_t const slot = r % DP_SLOTS;
+		for (uint32_t q = 0; q < DP_RL / 2; ++q)
 		{
-			uint32_t const end = e0 + i;
-			dp_cell(A, ent, hdr, stride, m, L, end, end <= p2lim, flags);
+			uint32_t const i = 2u * q + (lane >> 5);
+			uint32_t const k = (i < R.len) ? R.e0 + i - 1u : 0u;
+			dma16(ent + (size_t) k * stride + (lane & 31u) * 2u, __builtin_amdgcn_readfirstlane(lds0_addr + off_LS + (slot * DP_RL + 2u * q) * 512u));
 		}
-		__syncthreads();
-		if (wave == 0)
 		{
-			// rmq.update for the new entries [t0, t1)  (rmq.hh:61-81)
-			uint32_t const t0 = e0 - L, t1 = t0 + len;
-			for (uint32_t blk = t0 >> 6; blk <= (t1 - 1u) >> 6; ++blk)
+			uint32_t const k = (lane < R.len) ? R.e0 + lane - 1u : 0u;
+			dma16(hdr + k, __builtin_amdgcn_readfirstlane(lds0_addr + off_H + slot * 1024u));
+		}
+		{
+			// old sparse-table samples for the block that completes in round R (at most one: RL < 64)
+			uint32_t const blk = R.t0 >> 6;
+			uint32_t const bnum = blk + 1u;
+			bool const completes = !R.final_round && bnum * 64u <= R.t1;
+			size_t off = 0;
+			if (completes && lane >= DP_HPMIN && lane < DP_LEVELS && (1u << lane) <= bnum)
+				off = (size_t) (lane - 1u) * A.tstride + (bnum - (1u << lane));
+			dma4(A.Tb + off, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBi + slot * 256u));
+			dma4(A.Tbv + off, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBv + slot * 256u));
+		}
+	};
+
+	if (wave == DP_LOADER)
+	{
+		load_round(0);
+		if (nrounds > 1) load_round(1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	dp_barrier();
+
+	for (uint32_t r = 0; r < nrounds; ++r)
+	{
+		DpRound const R = dp_round(r, L, n, RL, nrounds);
+		uint32_t const slot = r % DP_SLOTS;
+		// entries < filled are indexed.  The ring keeps [t1 - DPW, t1); writes of this round land in
+		// [t0, t0 + RL), so anything >= filled + RL - DPW (+ margin) is safe to read from LDS.
+		uint32_t const filled = R.final_round ? (n - 2u * L + 1u) : R.t0;
+		DpView V;
+		V.safe_lo = (filled + RL + 128u > DPW) ? (filled + RL + 128u - DPW) : 0u;
+		V.cb = filled >> 6;
+
+		if (wave < DP_NWC)
+		{
+			// ---- compute: cells i = wave, wave + 14, ...
+#pragma unroll
+			for (int g = 0; g < DP_G; ++g)
 			{
-				uint32_t const idx = blk * 64u + lane;
-				bool const valid = idx < t1;
-				uint32_t const v = valid ? A.M[idx] : 0xFFFFFFFFu;
-				uint32_t pv = v, pi = idx;
-#pragma unroll
-				for (int delta = 1; delta < WAVE; delta <<= 1)
+				uint32_t const i = wave + (uint32_t) g * DP_NWC;
+				if (i >= R.len) continue;
+				uint32_t const end = R.e0 + i;
+				uint32_t const t = end - L;
+				lds_u32 const *hp = D.H + (slot * 64u + i) * 4u;
+				uint4 const h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+				CellState st;
+				st.best_v = 0xFFFFFFFFu; st.best_lb = 0; st.best_sz = 0; st.cum_base = 0;
+				if (!R.final_round && end <= p2lim)
 				{
-					uint32_t const ov = shfl_up_u32(pv, delta), oi = shfl_up_u32(pi, delta);
-					if (lane >= (uint32_t) delta && !(pv < ov)) { pv = ov; pi = oi; }
+					// part 2, lp.cc:85-93
+					st.best_v = m - h.y; st.best_lb = 0; st.best_sz = st.best_v;
 				}
-				if (valid) A.P[idx] = pi;
-				if (t1 >= blk * 64u + 64u)
+				else
 				{
-					uint32_t sv = v, si = idx;
-#pragma unroll
-					for (int delta = 1; delta < WAVE; delta <<= 1)
+					uint32_t const nent = h.x;
+					lds_u32 const *ls = D.LS + (slot * DP_RL + i) * 128u;
+					uint2 const en = make_uint2(ls[2u * lane], ls[2u * lane + 1u]);
+					uint32_t const vnext = ls[2u * ((lane + 1u) & 63u)];
+					bool done = dp_strip(A, D, V, en, vnext, nent, 0, 63, L, end, st);
+					// longer lists: continue from HBM (rare; only this wave waits)
+					uint2 const *list = ent + (size_t) (end - 1u) * stride;
+					for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)
 					{
-						uint32_t const ov = shfl_dn_u32(sv, delta), oi = shfl_dn_u32(si, delta);
-						if (lane + (uint32_t) delta < 64u && !(sv <= ov)) { sv = ov; si = oi; }
+						uint2 const e2 = list[s0 + lane];
+						uint32_t const v2 = list[s0 + lane + 1u].x;
+						done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
 					}
-					A.S[idx] = si;
-					uint32_t const new_smp = shfl_u32(si, 0);
-					uint32_t const new_val = shfl_u32(sv, 0);
-					uint32_t const bnum = blk + 1u;
-					if (lane == 0) A.Tb[blk] = new_smp;
-					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-					if (lane >= 1 && lane < 32 && (1u << lane) <= bnum)
+					uint32_t const cnt0 = h.y, complete = h.z;
+					bool const stopped = st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
+					if (!complete && !stopped && lane == 0) atomicOr(flags, 1u);   // list too short to prove the result
+					if (complete && cnt0 > 0)
 					{
-						uint32_t const j = bnum - (1u << lane);
-						uint32_t const smp = A.Tb[(size_t) (lane - 1u) * A.tstride + j];
-						A.Tb[(size_t) lane * A.tstride + j] = (new_val < A.M[smp]) ? new_smp : smp;
+						uint32_t const w = m - cnt0;             // lp.cc:416-421, visited first by the reference
+						if (w <= st.best_v) { st.best_v = w; st.best_lb = 0; st.best_sz = w; }
 					}
-					__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+					if (m <= st.best_v) { st.best_v = m; st.best_lb = 0; st.best_sz = m; }   // initial min_arg, lp.cc:123
+				}
+				if (lane == 0)
+				{
+					D.Mr[t & (DPW - 1u)] = st.best_v;
+					D.LBr[t & (DP_STG - 1u)] = st.best_lb;
+					D.SZr[t & (DP_STG - 1u)] = st.best_sz;
 				}
 			}
 		}
-		__syncthreads();
+		else if (wave == DP_LOADER)
+		{
+			// ---- loader: lists of round r+2; then make sure round r+1 has landed
+			if (r + 2u < nrounds)
+			{
+				load_round(r + 2u);
+				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DP_Q) : "memory");
+			}
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else
+		{
+			// ---- writer: flush round r-1 to HBM (stores only, never waited for)
+			if (r > 0)
+			{
+				DpRound const P = dp_round(r - 1u, L, n, RL, nrounds);
+				if (lane < P.len)
+				{
+					uint32_t const t = P.t0 + lane;
+					A.M[t] = D.Mr[t & (DPW - 1u)];
+					A.LB[t] = D.LBr[t & (DP_STG - 1u)];
+					A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
+					A.K[t] = D.Kr[t & (DPW - 1u)];
+				}
+				uint32_t const bnum = (P.t0 >> 6) + 1u;
+				if (bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
+				{
+					uint32_t const j = bnum - (1u << lane);
+					A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
+					A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
+				}
+			}
+		}
+		dp_barrier();
+		if (R.final_round) break;                             // no rmq.update after the last cell
+
+		// ---- rmq.update for the new entries [t0, t1) (rmq.hh:61-81): one wave per touched block
+		{
+			uint32_t const blkA = R.t0 >> 6, blkB = (R.t1 - 1u) >> 6;
+			if (wave <= blkB - blkA)
+			{
+				uint32_t const blk = blkA + wave;
+				uint32_t const base = blk * 64u;
+				uint32_t const idx = base + lane;
+				bool const fresh = idx >= R.t0 && idx < R.t1;
+				// stack mask of this lane's entry: walk the block leftwards with a running minimum;
+				// lane q looks at positions p < q only, the key of position p is broadcast from lane p
+				uint32_t const mine = D.Mr[idx & (DPW - 1u)];
+				uint32_t mlo = lane < 32 ? (1u << lane) : 0u, mhi = lane >= 32 ? (1u << (lane - 32u)) : 0u;
+				uint32_t runmin = mine;
+#pragma unroll
+				for (int p = 62; p >= 0; --p)
+				{
+					uint32_t const x = readlane_u32(mine, p);
+					bool const in = lane > (uint32_t) p;
+					bool const set = in && x <= runmin;
+					if (p < 32) mlo |= set ? (1u << p) : 0u; else mhi |= set ? (1u << (p - 32)) : 0u;
+					runmin = in ? min(runmin, x) : runmin;
+				}
+				unsigned long long const mask = ((unsigned long long) mhi << 32) | mlo;
+				if (fresh) D.Kr[idx & (DPW - 1u)] = mask;
+				if ((blk + 1u) * 64u <= R.t1)
+				{
+					// the block is complete: push its samples (rmq.hh:66-80)
+					uint32_t const klo = readlane_u32(mlo, 63), khi = readlane_u32(mhi, 63);
+					unsigned long long const k63 = ((unsigned long long) khi << 32) | klo;
+					uint32_t const off = (uint32_t) __builtin_ctzll(k63);
+					uint32_t const new_smp = base + off;
+					uint32_t const new_val = readlane_u32(mine, (int) off);
+					uint32_t const bnum = blk + 1u;
+					if (lane < DP_LEVELS && (1u << lane) <= bnum)
+					{
+						uint32_t const j = bnum - (1u << lane);
+						uint32_t res = new_smp, resv = new_val;
+						if (lane >= 1)
+						{
+							uint32_t smp, sval;
+							if (lane < DP_HPMIN)
+							{
+								smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+								sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+							}
+							else
+							{
+								smp = D.MBi[slot * 64u + lane];
+								sval = D.MBv[slot * 64u + lane];
+							}
+							if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
+						}
+						D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
+						D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
+					}
+				}
+			}
+		}
+		dp_barrier();
 	}
-	// final cell at rb = n (lp.cc:165-183); no rmq.update afterwards
-	if (wave == 0)
-		dp_cell(A, ent, hdr, stride, m, L, n, false, flags);
+
+	// the writer flushes the last regular round and the final cell
+	if (wave == DP_WRITER)
+	{
+		for (uint32_t r = (nrounds >= 2 ? nrounds - 2u : 0u); r < nrounds; ++r)
+		{
+			DpRound const P = dp_round(r, L, n, RL, nrounds);
+			if (lane < P.len)
+			{
+				uint32_t const t = P.t0 + lane;
+				A.M[t] = D.Mr[t & (DPW - 1u)];
+				A.LB[t] = D.LBr[t & (DP_STG - 1u)];
+				A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
+				if (!P.final_round) A.K[t] = D.Kr[t & (DPW - 1u)];
+			}
+			uint32_t const bnum = (P.t0 >> 6) + 1u;
+			if (!P.final_round && bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
+			{
+				uint32_t const j = bnum - (1u << lane);
+				A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
+				A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
+			}
+		}
+	}
 }
 
 // copy the lists of selected columns into a compact buffer (for the host-side merge)

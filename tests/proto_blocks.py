@@ -74,9 +74,10 @@ def phase_b_step(a, d, rank, keyd, D, digit_bits=4):
     return a, d
 
 
-def phase_c(codes, a, d, k0, nb, X):
-    """Returns per column (k0..k0+nb-1) a dict(vals, cnts, cnt0, complete): descending distinct
-    values with counts, truncated once the cumulative count exceeds X."""
+def phase_c(codes, a, d, k0, nb, X, L):
+    """Returns per column (k0..k0+nb-1) a dict(vals, cnts, cnt0, complete): entry 0 lumps every
+    value >= thr = (k+1)+1-L (the DP clips them all to the same cut bound, lp.cc:444-445); then the
+    distinct values below thr, descending, truncated once their cumulative count exceeds X."""
     V = np.unique(d)
     D0 = len(V)
     ids = np.searchsorted(V, d)
@@ -90,14 +91,19 @@ def phase_c(codes, a, d, k0, nb, X):
         cnt[:] = 0
         np.add.at(cnt, ids2, 1)
         ids = ids2
-        vals, cnts, cum, complete = [], [], 0, True
+        thr = max(0, k + 2 - L)
+        vals, cnts, cum, complete = [k + 1], [0], 0, True      # cum: counts below thr only
         for i in range(D0 + j, -1, -1):
             if cnt[i] == 0:
+                continue
+            v = int(V[i]) if i < D0 else k0 + (i - D0) + 1
+            if v >= thr:
+                cnts[0] += int(cnt[i])
                 continue
             if cum > X:
                 complete = False
                 break
-            vals.append(int(V[i]) if i < D0 else k0 + (i - D0) + 1)
+            vals.append(v)
             cnts.append(int(cnt[i]))
             cum += int(cnt[i])
         cnt0 = int(cnt[0]) if V[0] == 0 else 0
@@ -106,29 +112,36 @@ def phase_c(codes, a, d, k0, nb, X):
 
 
 class DeviceRmq:
-    """rmq.hh semantics (block 64) over M[], with O(1) partial-block answers:
-    P[t] = first-min index of [block_start(t), t], S[t] = first-min index of [t, block_end)."""
+    """rmq.hh semantics (block 64) over M[] with O(1) partial-block answers.
+
+    K[t] is a 64-bit mask over the block of t: bit p (p <= t mod 64) is set iff
+    M[p] <= min(M[p+1..t]) (the monotonic stack after scanning the block up to t, popping only
+    strictly greater keys).  The first minimum of [b, t] inside one block is the lowest set bit of
+    K[t] at or above b: stack keys are non-decreasing bottom to top and equal keys all stay, so the
+    lowest surviving position >= b is the leftmost minimum (std::min_element, rmq.hh:116)."""
 
     def __init__(self, n):
         self.M = np.full(n, U32MAX, dtype=np.int64)
-        self.P = np.zeros(n, dtype=np.int64)
-        self.S = np.zeros(n, dtype=np.int64)
+        self.K = [0] * n
         self.T = [[]]
         self.filled = 0
 
     def append(self, t, v):
         assert t == self.filled
-        M, P = self.M, self.P
+        M = self.M
         M[t] = v
-        P[t] = t if (t % 64 == 0 or v < M[P[t - 1]]) else P[t - 1]
+        base = t - (t % 64)
+        mask = 1 << (t - base)
+        runmin = v
+        for p in range(t - 1, base - 1, -1):
+            if M[p] <= runmin:
+                mask |= 1 << (p - base)
+            runmin = min(runmin, M[p])
+        self.K[t] = mask
         self.filled += 1
         if (t + 1) % 64 == 0:
-            b0 = t - 63
-            self.S[t] = t
-            for u in range(t - 1, b0 - 1, -1):
-                self.S[u] = u if M[u] <= M[self.S[u + 1]] else self.S[u + 1]
             bnum = (t + 1) // 64
-            new_smp = self.S[b0]
+            new_smp = base + self._ctz(mask)
             self.T[0].append(new_smp)
             p = 1
             while (1 << p) <= bnum:
@@ -138,21 +151,22 @@ class DeviceRmq:
                 self.T[p].append(new_smp if M[new_smp] < M[smp] else smp)
                 p += 1
 
+    @staticmethod
+    def _ctz(x):
+        return (x & -x).bit_length() - 1
+
+    def inblock(self, b, e):
+        """first minimum of [b, e), b and e-1 in the same block"""
+        assert b // 64 == (e - 1) // 64
+        return b + self._ctz(self.K[e - 1] >> (b % 64))
+
     def naive(self, b, e):
         M = self.M
         bb, eb = b // 64, (e - 1) // 64
         if bb == eb:
-            if b % 64 == 0:
-                return self.P[e - 1]
-            if e % 64 == 0:
-                return self.S[b]
-            best = b
-            for u in range(b + 1, e):
-                if M[u] < M[best]:
-                    best = u
-            return best
+            return self.inblock(b, e)
         assert eb == bb + 1
-        left, right = self.S[b], self.P[e - 1]
+        left, right = self.inblock(b, bb * 64 + 64), self.inblock(eb * 64, e)
         return right if M[right] < M[left] else left
 
     def query(self, beg, end):
@@ -165,11 +179,11 @@ class DeviceRmq:
         smp1 = self.T[pow2][beg_block]
         smp2 = self.T[pow2][end_block - (1 << pow2)]
         smp = smp2 if M[smp2] < M[smp1] else smp1
-        left = self.S[beg]
+        left = self.inblock(beg, beg_block * 64)
         smp = left if M[left] < M[smp] else smp
         if end == end_block * 64:
             return smp
-        right = self.P[end - 1]
+        right = self.inblock(end_block * 64, end)
         return right if M[right] < M[smp] else smp
 
 
@@ -232,7 +246,7 @@ def segment(codes, L, B, X, digit_bits=4):
     # phase C
     lists = []
     for (k0, nb), (sa, sd) in zip(blocks, bstate):
-        recs, a_end = phase_c(codes, sa, sd, k0, nb, X)
+        recs, a_end = phase_c(codes, sa, sd, k0, nb, X, L)
         lists.extend(recs)
     # phase D
     dp_size = n - L + 1

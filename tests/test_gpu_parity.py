@@ -101,9 +101,15 @@ def test_block_states_and_lists_match_oracle(pkg):
             if k % 7 == 0 or k > n - 5:
                 v, c = p.counts()
                 gv, gc, cnt0, complete = ctx.debug_column_list(k)
-                assert complete or gc.sum() > ctx.timings()["list_cap_used"]
-                assert np.array_equal(gv, v[::-1][:len(gv)]), k
-                assert np.array_equal(gc, c[::-1][:len(gc)]), k
+                assert complete or gc[1:].sum() > ctx.timings()["list_cap_used"]
+                # entry 0 lumps the values >= (k+1)+1-L; the rest are the distinct values below, descending
+                thr = max(0, k + 2 - L)
+                rec = v >= thr
+                ev = np.concatenate([[k + 1], v[~rec][::-1]])
+                ec = np.concatenate([[c[rec].sum()], c[~rec][::-1]])
+                assert np.array_equal(gv, ev[:len(gv)]), k
+                assert np.array_equal(gc, ec[:len(gc)]), k
+                assert complete == (len(gv) == len(ev))
                 assert cnt0 == (c[0] if v[0] == 0 else 0)
 
 
