@@ -31,7 +31,9 @@ struct KernelSet {
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *);
 	size_t lds_chain;
-	void (*chain)(hipStream_t, size_t lds, uint32_t const *, uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t *, uint32_t *);
+	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
+	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
+	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys);
 	hipError_t (*prepare)(size_t lds_columns);
 };
 
@@ -62,10 +64,12 @@ struct Launch {
 	{
 		hipLaunchKernelGGL((k_columns<T, E, SIGMA>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr);
 	}
-	static void chain(hipStream_t st, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
-	                  uint32_t nblocks, uint32_t *ba, uint32_t *bd)
+	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
+	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
+	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
 	{
-		hipLaunchKernelGGL((k_chain<T, E>), dim3(1), dim3(T), lds, st, rank_, keyd, nkeys, m, nblocks, ba, bd);
+		hipLaunchKernelGGL((k_chain<T, E>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
+		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
 	}
 	static hipError_t prepare(size_t lds_columns)
 	{
@@ -138,6 +142,8 @@ struct fseq_ctx {
 	// device work buffers
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
+	uint32_t *d_srank = nullptr, *d_skeyd = nullptr, *d_snkeys = nullptr, *d_sstate_a = nullptr, *d_sstate_d = nullptr;
+	uint32_t chain_G = 0, n_super = 0;
 	uint2 *d_ent = nullptr;
 	uint4 *d_hdr = nullptr;
 	uint32_t X = 0, stride = 0;
@@ -233,6 +239,13 @@ int prepare_geometry(fseq_ctx *c)
 	c->B = p.block_len ? p.block_len : auto_block_len(p.n);
 	if (c->B > p.n) c->B = (uint32_t) p.n;
 	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
+	{
+		// super-blocks of G ~ sqrt(nblocks) blocks: serial depth of phase B = G + nblocks/G + G key blocks
+		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) c->nblocks));
+		if (g < 1) g = 1;
+		c->chain_G = g;
+		c->n_super = (c->nblocks + g - 1) / g;
+	}
 	uint32_t n2 = 1;
 	while (n2 < p.m) n2 <<= 1;
 	if (n2 < 2) n2 = 2;
@@ -260,6 +273,11 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_nkeys, c->nblocks))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bstate_a, ((size_t) c->nblocks + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bstate_d, ((size_t) c->nblocks + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_srank, (size_t) c->n_super * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_skeyd, (size_t) c->n_super * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_snkeys, c->n_super))) return rc;
+		if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
 		if ((rc = dev_alloc(c, &c->d_flags, 64))) return rc;
 		if (p.n >= 2 * p.segment_length)
@@ -287,6 +305,7 @@ void free_work(fseq_ctx *c)
 {
 	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
+	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_cols); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
@@ -375,7 +394,23 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
 	ks.rank(st, c->nblocks, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
-	ks.chain(st, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, c->d_bstate_a, c->d_bstate_d);
+	{
+		// phase B, two-level: compose groups of G blocks into super-blocks (parallel), chain the
+		// super-blocks (one workgroup), expand every super-block to its block boundaries (parallel)
+		uint32_t const G = c->chain_G, NSB = c->n_super;
+		if (NSB <= 1)
+			ks.chain(st, 1, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, c->nblocks, c->B, nullptr, nullptr,
+			         c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
+		else
+		{
+			ks.chain(st, NSB, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, G, c->B, nullptr, nullptr,
+			         nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys);
+			ks.chain(st, 1, ks.lds_chain, c->d_srank, c->d_skeyd, c->d_snkeys, m, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
+			         c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
+			ks.chain(st, NSB, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
+			         c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
+		}
+	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
 

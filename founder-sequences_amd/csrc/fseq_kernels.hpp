@@ -4,9 +4,10 @@
 // (founder-sequences/segmentation_lp_context.cc:26-188 pass 1, update_pbwt_task.cc:13-35 pass 2):
 //   phase A  k_colblock<MODE_RANK>  per block of B columns: pBWT from the identity -> dense co-lex rank of
 //                                   every row's block key + divergence in front of each distinct key
-//   phase B  k_chain                serial over blocks, one workgroup: stable sort of the running order by
-//                                   block rank (4-bit LSD digit passes of the same partition step); emits
-//                                   the exact (a_k, d_k) at every block boundary
+//   phase B  k_chain (x3)           stable sort of the running order by block rank (4-bit LSD digit passes of
+//                                   the same partition step), two-level: compose groups of G blocks into
+//                                   super-blocks (parallel), chain the super-blocks (one workgroup), expand
+//                                   each super-block (parallel) -> exact (a_k, d_k) at every block boundary
 //   phase C  k_columns              per block from its boundary state: the true per-column update; per
 //                                   column the top of the divergence-value histogram (what
 //                                   calculate_segmentation_lp_dp_arg consumes, lp.cc:393-481)
@@ -248,7 +249,7 @@ template <int T, int E>
 __host__ __device__ inline size_t chain_lds_bytes()
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 4 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 16>));
+	return 4 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 16>)) + carve_bytes(T / WAVE + 1, 4);
 }
 
 __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
@@ -258,10 +259,25 @@ __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
 	return (bits + 3u) / 4u;
 }
 
+// One workgroup = one chain over the consecutive key blocks [b0, b1), b0 = blockIdx.x * G.
+// A "key block" is described by rank[b][row] (dense co-lex rank of the row's key), keyd[b][r]
+// (divergence in front of key r) and nkeys[b].  The chain applies, block after block, the stable
+// sort of the running order by block rank (4-bit LSD digit passes of partition_step; divergences
+// ride along; rows that start a new key take keyd).
+//   start:  start_a/start_d == nullptr : identity order, d = b0 * cols_per_block   (composition from scratch)
+//           else                        : state [blockIdx.x] of start_a/start_d     (exact state at the chain's first column)
+//   out_state_*: if set, the exact state in front of every block b (and behind the last block of
+//           the whole sequence, index nb_total)
+//   out_rank/out_keyd/out_nkeys: if set, the chain's composite key block [blockIdx.x]
+// Used three times: compose super-blocks (parallel), chain the super-blocks (one
+// workgroup), expand every super-block back to block boundaries (parallel).
 template <int T, int E>
 __global__ __launch_bounds__(T) void k_chain(
 	uint32_t const *__restrict__ rank, uint32_t const *__restrict__ keyd, uint32_t const *__restrict__ nkeys,
-	uint32_t m, uint32_t nblocks, uint32_t *__restrict__ bstate_a, uint32_t *__restrict__ bstate_d)
+	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block,
+	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
+	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -271,36 +287,45 @@ __global__ __launch_bounds__(T) void k_chain(
 	uint32_t *rk = cv.take<uint32_t>(CAP);
 	uint32_t *kd = cv.take<uint32_t>(CAP);
 	StepScratch<T, 16> &scr = *cv.take<StepScratch<T, 16>>(1);
+	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
 
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = tid * E;
-#pragma unroll
-	for (int i = 0; i < E; ++i)
+	uint32_t const b0 = blockIdx.x * G;
+	uint32_t const b1 = min(nb_total, b0 + G);
+	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * cols_per_block);
 	{
-		uint32_t const idx = tid + i * T;
-		a_l[idx] = idx < m ? idx : 0u;
-		d_l[idx] = 0u;
-		rk[idx] = idx < m ? rank[idx] : 0u;
-		kd[idx] = idx < m ? keyd[idx] : 0u;
+		size_t const sb = (size_t) blockIdx.x * m, rb = (size_t) b0 * m;
+#pragma unroll
+		for (int i = 0; i < E; ++i)
+		{
+			uint32_t const idx = tid + i * T;
+			bool const in = idx < m;
+			a_l[idx] = in ? (start_a ? start_a[sb + idx] : idx) : 0u;
+			d_l[idx] = in ? (start_d ? start_d[sb + idx] : kstart) : 0u;
+			rk[idx] = in ? rank[rb + idx] : 0u;
+			kd[idx] = in ? keyd[rb + idx] : 0u;
+		}
 	}
-	uint32_t D_cur = nkeys[0];
+	uint32_t D_cur = nkeys[b0];
 	__syncthreads();
 
-	for (uint32_t b = 0; b < nblocks; ++b)
+	for (uint32_t b = b0; b < b1; ++b)
 	{
-		// (1) publish the exact state at column b*B
+		// (1) publish the exact state in front of block b
+		if (out_state_a)
 		{
 			size_t const ob = (size_t) b * m;
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
 				uint32_t const idx = tid + i * T;
-				if (idx < m) { bstate_a[ob + idx] = a_l[idx]; bstate_d[ob + idx] = d_l[idx]; }
+				if (idx < m) { out_state_a[ob + idx] = a_l[idx]; out_state_d[ob + idx] = d_l[idx]; }
 			}
 		}
 		// (2) prefetch the next block's rank / keyd into registers
 		uint32_t pr[E], pk[E], D_next = 0;
-		bool const more = b + 1 < nblocks;
+		bool const more = b + 1 < b1;
 		if (more)
 		{
 			size_t const nbase = (size_t) (b + 1) * m;
@@ -362,14 +387,41 @@ __global__ __launch_bounds__(T) void k_chain(
 		__syncthreads();
 	}
 
+	if (out_state_a && b1 == nb_total)
 	{
-		size_t const ob = (size_t) nblocks * m;
+		size_t const ob = (size_t) nb_total * m;
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
 			uint32_t const idx = tid + i * T;
-			if (idx < m) { bstate_a[ob + idx] = a_l[idx]; bstate_d[ob + idx] = d_l[idx]; }
+			if (idx < m) { out_state_a[ob + idx] = a_l[idx]; out_state_d[ob + idx] = d_l[idx]; }
 		}
+	}
+	if (out_rank)
+	{
+		// composite key block of the chain: a row starts a new composite key iff its divergence is
+		// inside the chain's column range (> kstart); same epilogue as k_colblock<MODE_RANK>
+		uint32_t a[E], d[E];
+		read_chunk<T, E>(a_l, d_l, a, d);
+		uint32_t nf = 0;
+#pragma unroll
+		for (int e = 0; e < E; ++e) nf += (p0 + e < m && (p0 + e == 0 || d[e] > kstart)) ? 1u : 0u;
+		uint32_t total;
+		uint32_t r = block_excl_add<T>(nf, sscr, &total);
+		size_t const ob = (size_t) blockIdx.x * m;
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			uint32_t const pos = p0 + e;
+			if (pos < m)
+			{
+				bool const first = (pos == 0 || d[e] > kstart);
+				r += first ? 1u : 0u;
+				out_rank[ob + a[e]] = r - 1u;
+				if (first) out_keyd[ob + r - 1u] = d[e];
+			}
+		}
+		if (tid == 0) out_nkeys[blockIdx.x] = total;
 	}
 }
 
