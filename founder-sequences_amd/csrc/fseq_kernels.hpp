@@ -776,6 +776,42 @@ __device__ __forceinline__ uint32_t rmq_query(DpArrays const &A, DpLds const &D,
 	return idx;
 }
 
+// The same query when the whole range (and therefore every sample it needs) is inside the LDS
+// ring: beg >= safe_lo implies beg_block >= cb - DP_TRN + 3, so dp_sample would pick LDS anyway.
+// 32-bit address math only; this is the path practically every candidate takes.
+__device__ __forceinline__ uint32_t rmq_query_lds(DpLds const &D, uint32_t beg, uint32_t end, uint32_t *val)
+{
+	uint32_t const bb = beg >> 6, eb = (end - 1u) >> 6;
+	uint32_t const ie = end - 1u;
+	unsigned long long const ke = D.Kr[ie & (DPW - 1u)];
+	unsigned long long const kb = D.Kr[((bb << 6) + 63u) & (DPW - 1u)];
+	uint32_t const sh = beg & 63u;
+	// one block: first min of [beg, end) from the mask of the right end; else the two partial blocks
+	uint32_t const il = beg + (uint32_t) __builtin_ctzll((bb == eb ? ke : kb) >> sh);
+	uint32_t const ir = (ie & ~63u) + (uint32_t) __builtin_ctzll(ke);
+	uint32_t idx = il, v = D.Mr[il & (DPW - 1u)];
+	if (bb != eb)
+	{
+		uint32_t const m_ir = D.Mr[ir & (DPW - 1u)];
+		uint32_t const beg_block = bb + 1u, end_block = end >> 6;
+		if (beg_block < end_block)
+		{
+			uint32_t const pow2 = 31u - (uint32_t) __builtin_clz(end_block - beg_block);
+			uint32_t const s1 = pow2 * DP_TRN + (beg_block & (DP_TRN - 1u));
+			uint32_t const s2 = pow2 * DP_TRN + ((end_block - (1u << pow2)) & (DP_TRN - 1u));
+			uint32_t const t1 = D.Tr[s1], m_t1 = D.Trv[s1], t2 = D.Tr[s2], m_t2 = D.Trv[s2];
+			uint32_t const m_il = v;
+			idx = t1; v = m_t1;
+			if (m_t2 < v) { idx = t2; v = m_t2; }                   // rmq.hh:96
+			if (m_il < v) { idx = il; v = m_il; }                   // rmq.hh:97-98
+			if ((end & 63u) != 0 && m_ir < v) { idx = ir; v = m_ir; }   // rmq.hh:100-104
+		}
+		else if (m_ir < v) { idx = ir; v = m_ir; }                  // two adjacent blocks, first minimum
+	}
+	*val = v;
+	return idx;
+}
+
 // State of one DP cell while a wave evaluates it (calculate_segmentation_lp_dp_arg, lp.cc:393-481,
 // candidate ranges visited in descending divergence order and pruned exactly).
 struct CellState {
@@ -806,11 +842,22 @@ __device__ __forceinline__ bool dp_strip(
 	}
 	ok = ok && lo < c;                                       // lp.cc:458
 	uint32_t val = 0xFFFFFFFFu, idx = 0;
-	if (ok)
+	uint32_t const qb = lo - L, qe = c - L;
+	if (__ballot(ok && qb < V.safe_lo) == 0)
+	{
+		// every candidate of the strip lies inside the LDS ring
+		if (ok)
+		{
+			uint32_t mv;
+			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
+			val = max(mv, cum);                                  // lp.cc:468-471
+		}
+	}
+	else if (ok)
 	{
 		uint32_t mv;
-		idx = rmq_query(A, D, V, lo - L, c - L, &mv);        // lp.cc:465
-		val = max(mv, cum);                                  // lp.cc:468-471
+		idx = rmq_query(A, D, V, qb, qe, &mv);
+		val = max(mv, cum);
 	}
 	// minimum value; among equal values the candidate the reference visits first = the largest i
 	// (lowest divergence value) = the highest lane of the strip
@@ -939,8 +986,15 @@ __global__ __launch_bounds__(1024) void k_dp(
 	}
 	dp_barrier();
 
+#ifdef FSEQ_DP_STAMPS
+	unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#define DP_STAMP(x) unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define DP_STAMP(x)
+#endif
 	for (uint32_t r = 0; r < nrounds; ++r)
 	{
+		DP_STAMP(ts0);
 		DpRound const R = dp_round(r, L, n, RL, nrounds);
 		uint32_t const slot = r % DP_SLOTS;
 		// entries < filled are indexed.  The ring keeps [t1 - DPW, t1); writes of this round land in
@@ -980,6 +1034,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 					uint2 const *list = ent + (size_t) (end - 1u) * stride;
 					for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)
 					{
+#ifdef FSEQ_DP_STATS
+						if (lane == 0) atomicAdd(flags + 2, 1u);
+#endif
 						uint2 const e2 = list[s0 + lane];
 						uint32_t const v2 = list[s0 + lane + 1u].x;
 						done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
@@ -1036,7 +1093,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 				}
 			}
 		}
+		DP_STAMP(ts1);
 		dp_barrier();
+		DP_STAMP(ts2);
 		if (R.final_round) break;                             // no rmq.update after the last cell
 
 		// ---- rmq.update for the new entries [t0, t1) (rmq.hh:61-81): one wave per touched block
@@ -1098,8 +1157,22 @@ __global__ __launch_bounds__(1024) void k_dp(
 				}
 			}
 		}
+		DP_STAMP(ts3);
 		dp_barrier();
+#ifdef FSEQ_DP_STAMPS
+		{
+			DP_STAMP(ts4);
+			acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1;
+		}
+#endif
 	}
+#ifdef FSEQ_DP_STAMPS
+	if (lane == 0 && (wave == 0 || wave == DP_LOADER || wave == DP_WRITER || wave == 13))
+	{
+		unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 8) + (wave == 0 ? 0 : wave == 13 ? 5 : wave == DP_LOADER ? 10 : 15);
+		for (int q = 0; q < 5; ++q) o[q] = acc[q];
+	}
+#endif
 
 	// the writer flushes the last regular round and the final cell
 	if (wave == DP_WRITER)
