@@ -689,6 +689,7 @@ constexpr uint32_t DP_LOADER = 14, DP_WRITER = 15;
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
 
 struct DpLds {
 	lds_u64 *Kr;
@@ -876,6 +877,36 @@ __device__ __forceinline__ bool dp_strip(
 	return st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
 }
 
+// A whole cell, strip after strip (the general path: lists longer than one strip, or ranges that
+// reach behind the LDS ring).  Returns the finished state; sets the overflow flag when the list is
+// too short to prove the result.
+__device__ __forceinline__ CellState dp_cell_sequential(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint2 const *__restrict__ list, uint2 en0, uint32_t vnext0,
+	uint4 const h, uint32_t m, uint32_t L, uint32_t end, uint32_t *flags)
+{
+	uint32_t const lane = lane_id();
+	CellState st;
+	st.best_v = 0xFFFFFFFFu; st.best_lb = 0; st.best_sz = 0; st.cum_base = 0;
+	uint32_t const nent = h.x;
+	bool done = dp_strip(A, D, V, en0, vnext0, nent, 0, 63, L, end, st);
+	for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)     // continue from HBM (rare; only this wave waits)
+	{
+		uint2 const e2 = list[s0 + lane];
+		uint32_t const v2 = list[s0 + lane + 1u].x;
+		done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
+	}
+	uint32_t const cnt0 = h.y, complete = h.z;
+	bool const stopped = st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
+	if (!complete && !stopped && lane == 0) atomicOr(flags, 1u);   // list too short to prove the result
+	if (complete && cnt0 > 0)
+	{
+		uint32_t const w = m - cnt0;                         // lp.cc:416-421, visited first by the reference
+		if (w <= st.best_v) { st.best_v = w; st.best_lb = 0; st.best_sz = w; }
+	}
+	if (m <= st.best_v) { st.best_v = m; st.best_lb = 0; st.best_sz = m; }   // initial min_arg, lp.cc:123
+	return st;
+}
+
 // LDS-DMA: every lane names its own 16 (or 4) global bytes; they land at LDS address lds + lane * size.
 // Inline asm on purpose: the loader wave counts these itself (s_waitcnt vmcnt(DP_Q) = "the round
 // before the one just issued has landed"); issued through the builtin, hipcc would drain them
@@ -1006,7 +1037,8 @@ __global__ __launch_bounds__(1024) void k_dp(
 
 		if (wave < DP_NWC)
 		{
-			// ---- compute: cells i = wave, wave + 14, ...
+			// ---- compute: cells i = wave, wave + 14, ...  (one CU's VALU issue rate bounds this
+			// phase: a stage-interleaved, branch-free variant was measured slower)
 #pragma unroll
 			for (int g = 0; g < DP_G; ++g)
 			{
@@ -1017,39 +1049,17 @@ __global__ __launch_bounds__(1024) void k_dp(
 				lds_u32 const *hp = D.H + (slot * 64u + i) * 4u;
 				uint4 const h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
 				CellState st;
-				st.best_v = 0xFFFFFFFFu; st.best_lb = 0; st.best_sz = 0; st.cum_base = 0;
 				if (!R.final_round && end <= p2lim)
 				{
 					// part 2, lp.cc:85-93
-					st.best_v = m - h.y; st.best_lb = 0; st.best_sz = st.best_v;
+					st.best_v = m - h.y; st.best_lb = 0; st.best_sz = st.best_v; st.cum_base = 0;
 				}
 				else
 				{
-					uint32_t const nent = h.x;
 					lds_u32 const *ls = D.LS + (slot * DP_RL + i) * 128u;
 					uint2 const en = make_uint2(ls[2u * lane], ls[2u * lane + 1u]);
 					uint32_t const vnext = ls[2u * ((lane + 1u) & 63u)];
-					bool done = dp_strip(A, D, V, en, vnext, nent, 0, 63, L, end, st);
-					// longer lists: continue from HBM (rare; only this wave waits)
-					uint2 const *list = ent + (size_t) (end - 1u) * stride;
-					for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)
-					{
-#ifdef FSEQ_DP_STATS
-						if (lane == 0) atomicAdd(flags + 2, 1u);
-#endif
-						uint2 const e2 = list[s0 + lane];
-						uint32_t const v2 = list[s0 + lane + 1u].x;
-						done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
-					}
-					uint32_t const cnt0 = h.y, complete = h.z;
-					bool const stopped = st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
-					if (!complete && !stopped && lane == 0) atomicOr(flags, 1u);   // list too short to prove the result
-					if (complete && cnt0 > 0)
-					{
-						uint32_t const w = m - cnt0;             // lp.cc:416-421, visited first by the reference
-						if (w <= st.best_v) { st.best_v = w; st.best_lb = 0; st.best_sz = w; }
-					}
-					if (m <= st.best_v) { st.best_v = m; st.best_lb = 0; st.best_sz = m; }   // initial min_arg, lp.cc:123
+					st = dp_cell_sequential(A, D, V, ent + (size_t) (end - 1u) * stride, en, vnext, h, m, L, end, flags);
 				}
 				if (lane == 0)
 				{
@@ -1098,62 +1108,71 @@ __global__ __launch_bounds__(1024) void k_dp(
 		DP_STAMP(ts2);
 		if (R.final_round) break;                             // no rmq.update after the last cell
 
-		// ---- rmq.update for the new entries [t0, t1) (rmq.hh:61-81): one wave per touched block
+		// ---- rmq.update for the new entries [t0, t1) (rmq.hh:61-81).  At most two 64-blocks are touched
+		// and at most one completes (RL < 64).  Eight waves build the stack masks, each a 16-bit slice
+		// (positions p in [16c, 16c+16)) of one block; a ninth pushes the sparse-table samples.
 		{
 			uint32_t const blkA = R.t0 >> 6, blkB = (R.t1 - 1u) >> 6;
-			if (wave <= blkB - blkA)
+			uint32_t const nslices = 4u * (blkB - blkA + 1u);
+			if (wave < nslices)
 			{
-				uint32_t const blk = blkA + wave;
-				uint32_t const base = blk * 64u;
-				uint32_t const idx = base + lane;
+				uint32_t const blk = blkA + (wave >> 2), chunk = wave & 3u;
+				uint32_t const base = blk * 64u, idx = base + lane;
 				bool const fresh = idx >= R.t0 && idx < R.t1;
-				// stack mask of this lane's entry: walk the block leftwards with a running minimum;
-				// lane q looks at positions p < q only, the key of position p is broadcast from lane p
 				uint32_t const mine = D.Mr[idx & (DPW - 1u)];
-				uint32_t mlo = lane < 32 ? (1u << lane) : 0u, mhi = lane >= 32 ? (1u << (lane - 32u)) : 0u;
-				uint32_t runmin = mine;
+				uint32_t const plo = 16u * chunk, phi = plo + 16u;
+				// running minimum of the keys to the right of the slice, up to this lane: inclusive
+				// prefix-min over the lanes >= phi (the lane's own key included)
+				uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
+				pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+				pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+				pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+				pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+				pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+				pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+				uint32_t runmin = lane >= phi ? pm : mine;
+				uint32_t bits = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
 #pragma unroll
-				for (int p = 62; p >= 0; --p)
+				for (int pp = 15; pp >= 0; --pp)
 				{
-					uint32_t const x = readlane_u32(mine, p);
-					bool const in = lane > (uint32_t) p;
-					bool const set = in && x <= runmin;
-					if (p < 32) mlo |= set ? (1u << p) : 0u; else mhi |= set ? (1u << (p - 32)) : 0u;
+					uint32_t const p = plo + (uint32_t) pp;
+					uint32_t const x = readlane_u32(mine, (int) p);
+					bool const in = lane > p;
+					bits |= (in && x <= runmin) ? (1u << pp) : 0u;
 					runmin = in ? min(runmin, x) : runmin;
 				}
-				unsigned long long const mask = ((unsigned long long) mhi << 32) | mlo;
-				if (fresh) D.Kr[idx & (DPW - 1u)] = mask;
-				if ((blk + 1u) * 64u <= R.t1)
+				if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
+			}
+			else if (wave == 8 && (blkA + 1u) * 64u <= R.t1)
+			{
+				// block blkA is complete: push its samples (rmq.hh:66-80).  Its first minimum =
+				// lowest lane holding the minimum key.
+				uint32_t const base = blkA * 64u;
+				uint32_t const mine = D.Mr[(base + lane) & (DPW - 1u)];
+				uint32_t const new_val = wave_min_u32(mine);
+				uint32_t const new_smp = base + (uint32_t) __builtin_ctzll(__ballot(mine == new_val));
+				uint32_t const bnum = blkA + 1u;
+				if (lane < DP_LEVELS && (1u << lane) <= bnum)
 				{
-					// the block is complete: push its samples (rmq.hh:66-80)
-					uint32_t const klo = readlane_u32(mlo, 63), khi = readlane_u32(mhi, 63);
-					unsigned long long const k63 = ((unsigned long long) khi << 32) | klo;
-					uint32_t const off = (uint32_t) __builtin_ctzll(k63);
-					uint32_t const new_smp = base + off;
-					uint32_t const new_val = readlane_u32(mine, (int) off);
-					uint32_t const bnum = blk + 1u;
-					if (lane < DP_LEVELS && (1u << lane) <= bnum)
+					uint32_t const j = bnum - (1u << lane);
+					uint32_t res = new_smp, resv = new_val;
+					if (lane >= 1)
 					{
-						uint32_t const j = bnum - (1u << lane);
-						uint32_t res = new_smp, resv = new_val;
-						if (lane >= 1)
+						uint32_t smp, sval;
+						if (lane < DP_HPMIN)
 						{
-							uint32_t smp, sval;
-							if (lane < DP_HPMIN)
-							{
-								smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
-								sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
-							}
-							else
-							{
-								smp = D.MBi[slot * 64u + lane];
-								sval = D.MBv[slot * 64u + lane];
-							}
-							if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
+							smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+							sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
 						}
-						D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
-						D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
+						else
+						{
+							smp = D.MBi[slot * 64u + lane];
+							sval = D.MBv[slot * 64u + lane];
+						}
+						if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
 					}
+					D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
+					D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
 				}
 			}
 		}
