@@ -93,35 +93,46 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("founder-sequences_amd")
+    fdist = importlib.import_module("founder-sequences_amd.dist")
     w = dict(WORKLOADS[args.workload])
     m, n, L = w["m"], w["n"], w["L"]
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
-    ctx.generate_synthetic(w["seed"] + 0x1000 * rank, w["K"], w["B"], w["mu"], w["kind"])
+    # one alignment per rank (alignment id = rank), generated on the device
+    ctx.generate_synthetic(fdist.seed_for_alignment(w["seed"], rank), w["K"], w["B"], w["mu"], w["kind"])
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    phase = {}
+    counted = {"on": False}
+
+    def step():
+        ctx.run()
+        if counted["on"]:
+            t = ctx.timings()
+            for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
+                phase[k] = phase.get(k, 0.0) + t[k]
 
     for _ in range(args.warmup):
-        ctx.run()
-    barrier()
-    t0 = time.perf_counter()
-    phase = {}
-    for _ in range(args.steps):
-        ctx.run()
-        t = ctx.timings()
-        for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
-            phase[k] = phase.get(k, 0.0) + t[k]
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        step()
+    counted["on"] = True
+    # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, max over ranks
+    dt = fdist.timed_steps(step, args.steps, 0, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
+                           tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cuda"))
 
     t = ctx.timings()
     res = ctx.result
+    # HBM bytes per k_columns launch from the PMC passes committed under profiles/ (rocprofv3 cannot
+    # run inside this process); only quoted when it was taken on this workload
+    traffic, traffic_src = None, None
+    try:
+        prof = os.path.join(ROOT, "profiles", "r01_b_pmc_traffic.json")
+        if args.workload == "C2" and os.path.exists(prof):
+            with open(prof) as f:
+                pk = json.load(f)["kernels"]
+            for name, d in pk.items():
+                if "k_columns" in name and "hbm_bytes_per_launch_corrected" in d:
+                    traffic = d["hbm_bytes_per_launch_corrected"]
+                    traffic_src = "profiles/r01_b_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"
+    except Exception:
+        traffic = None
     steps = max(1, args.steps)
     ms_c = phase["ms_phase_c"] / steps          # one k_columns launch per step (plus retries, if any)
     launches_c = 1 + t["retries"]
@@ -156,7 +167,8 @@ def main():
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
             "avg_launch_ms": ms_c / launches_c,
         },
