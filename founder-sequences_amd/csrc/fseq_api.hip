@@ -26,7 +26,7 @@ struct KernelSet {
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	             uint32_t *, uint32_t *, uint32_t *);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	             uint32_t const *, uint32_t const *, uint64_t const *, uint32_t *, uint32_t *);
+	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *);
@@ -50,13 +50,14 @@ struct Launch {
 	                 uint32_t nblocks, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, rank_, keyd, nkeys,
-		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr);
+		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint32_t *sa, uint32_t *sd)
+	                 uint32_t nblocks, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, sa, sd);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
@@ -104,7 +105,8 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 	FSEQ_TRY(64, 1)
 	FSEQ_TRY(64, 7)
 	FSEQ_TRY(256, 5)
-	FSEQ_TRY(256, 11)
+	FSEQ_TRY(512, 5)
+	FSEQ_TRY(512, 7)
 	FSEQ_TRY(1024, 7)
 #undef FSEQ_TRY
 	return false;
@@ -152,6 +154,8 @@ struct fseq_ctx {
 	uint64_t dp_size = 0;
 	uint64_t *d_cols = nullptr;           // scratch: column / rb lists
 	size_t cols_cap = 0;
+	uint2 *d_grp = nullptr;
+	size_t grp_cap = 0;
 	uint2 *d_gent = nullptr;
 	uint4 *d_ghdr = nullptr;
 	size_t gather_cap = 0, gather_stride = 0;
@@ -308,9 +312,9 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
-	dev_free(&c->d_cols); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
+	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d);
-	c->cols_cap = c->gather_cap = c->snap_cap = 0;
+	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = 0;
 }
 
 int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t cs)
@@ -548,16 +552,29 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			if ((rc = dev_alloc(c, &c->d_snap_d, S2 * (size_t) m))) return rc;
 			c->snap_cap = S2;
 		}
+		// one sweep per column block that holds boundaries (boundaries ascending -> blocks ascending)
 		std::vector<uint64_t> rbs(S2);
+		std::vector<uint2> grp;
 		for (size_t i = 0; i < S2; ++i)
 		{
 			rbs[i] = c->segments[i].rb;
-			uint64_t blk = std::min<uint64_t>(rbs[i] / c->B, c->nblocks);
-			pass2_cells += (rbs[i] - blk * c->B) * m;
+			uint64_t const blk = std::min<uint64_t>(rbs[i] / c->B, c->nblocks);
+			if (grp.empty() || std::min<uint64_t>(rbs[grp.back().x] / c->B, c->nblocks) != blk)
+				grp.push_back(make_uint2((uint32_t) i, 1u));
+			else
+				++grp.back().y;
 		}
+		for (auto const &g : grp)
+		{
+			uint64_t const blk = std::min<uint64_t>(rbs[g.x] / c->B, c->nblocks);
+			pass2_cells += (rbs[g.x + g.y - 1] - blk * c->B) * m;
+		}
+		if (c->grp_cap < grp.size()) { if ((rc = dev_alloc(c, &c->d_grp, grp.size()))) return rc; c->grp_cap = grp.size(); }
 		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
-		ks.snap(st, (uint32_t) S2, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_snap_a, c->d_snap_d);
+		ks.snap(st, (uint32_t) grp.size(), ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
+		        c->d_snap_a, c->d_snap_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));

@@ -109,7 +109,9 @@ __device__ __forceinline__ void read_chunk(uint32_t const *a_l, uint32_t const *
 }
 
 // MODE_RANK: start from the identity at column k0 = blockIdx.x * B, emit block ranks (phase A).
-// MODE_SNAP: start from the block boundary state below task_rb[blockIdx.x], emit (a,d) at that column.
+// MODE_SNAP: workgroup j sweeps one column block once, from its boundary state, and emits (a,d) at
+//            every requested column task_rb[first .. first+count) inside it (task_grp[j] = {first, count},
+//            task_rb ascending) -- pass 2 costs at most one more sweep of the alignment.
 enum { MODE_RANK = 0, MODE_SNAP = 1 };
 
 template <int T, int E, int SIGMA>
@@ -126,7 +128,8 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	// MODE_SNAP inputs / outputs
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint64_t const *__restrict__ task_rb, uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d)
+	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
+	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -141,6 +144,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = tid * E;
 	uint64_t k0, kend;
+	uint32_t t_first = 0, t_count = 0, t_next = 0;
 	if (MODE == MODE_RANK)
 	{
 		k0 = (uint64_t) blockIdx.x * B;
@@ -155,11 +159,12 @@ __global__ __launch_bounds__(T) void k_colblock(
 	}
 	else
 	{
-		uint64_t const rb = task_rb[blockIdx.x];
-		uint64_t blk = rb / B;
+		uint2 const grp = task_grp[blockIdx.x];
+		t_first = grp.x; t_count = grp.y;
+		uint64_t blk = task_rb[t_first] / B;
 		if (blk > nblocks) blk = nblocks;
 		k0 = blk * B;
-		kend = rb;
+		kend = task_rb[t_first + t_count - 1u];
 		uint32_t const *sa = bstate_a + blk * (size_t) m;
 		uint32_t const *sd = bstate_d + blk * (size_t) m;
 #pragma unroll
@@ -180,6 +185,22 @@ __global__ __launch_bounds__(T) void k_colblock(
 		*reinterpret_cast<uint4 *>(sym0 + tid * 16u) = nxt;
 	}
 	__syncthreads();
+
+	// MODE_SNAP: the state in LDS is (a_k, d_k) for k = k0 + (columns done); copy it out when k is requested
+	auto snapshot_if_requested = [&](uint64_t k) {
+		if (MODE == MODE_SNAP && t_next < t_count && task_rb[t_first + t_next] == k)
+		{
+			size_t const ob = (size_t) (t_first + t_next) * m;
+#pragma unroll
+			for (int i = 0; i < E; ++i)
+			{
+				uint32_t const idx = tid + i * T;
+				if (idx < m) { snap_a[ob + idx] = a_l[idx]; snap_d[ob + idx] = d_l[idx]; }
+			}
+			++t_next;
+		}
+	};
+	snapshot_if_requested(k0);
 
 	for (uint32_t j = 0; j < nb; ++j)
 	{
@@ -202,6 +223,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 		if (more && has_chunk)
 			*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
 		__syncthreads();
+		snapshot_if_requested(k0 + j + 1);
 	}
 
 	if (MODE == MODE_RANK)
@@ -229,16 +251,6 @@ __global__ __launch_bounds__(T) void k_colblock(
 			}
 		}
 		if (tid == 0) nkeys[blockIdx.x] = total;
-	}
-	else
-	{
-		size_t const ob = (size_t) blockIdx.x * m;
-#pragma unroll
-		for (int i = 0; i < E; ++i)
-		{
-			uint32_t const idx = tid + i * T;
-			if (idx < m) { snap_a[ob + idx] = a_l[idx]; snap_d[ob + idx] = d_l[idx]; }
-		}
 	}
 }
 
