@@ -35,6 +35,7 @@ WORKLOADS = {
     "C1": dict(m=8, n=1000, L=10, K=3, B=100, mu=5e-3, seed=0x5EED0001, kind=0),
     "C2": dict(m=2500, n=100000, L=50, K=16, B=2000, mu=1e-4, seed=0x5EED0002, kind=0),
     "C3": dict(m=2504, n=1000000, L=100, K=24, B=5000, mu=1e-4, seed=0x5EED0003, kind=0),
+    "C5": dict(m=10000, n=1000000, L=100, K=32, B=5000, mu=1e-4, seed=0x5EED0005, kind=1),
 }
 
 

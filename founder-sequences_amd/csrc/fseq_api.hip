@@ -22,7 +22,7 @@ namespace {
 
 struct KernelSet {
 	uint32_t T, E, sigma, cap;
-	size_t lds_colblock;
+	size_t lds_colblock, lds_snap;
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	             uint32_t *, uint32_t *, uint32_t *);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
@@ -44,50 +44,51 @@ hipError_t allow_lds(K kernel, size_t bytes)
 	return hipFuncSetAttribute(reinterpret_cast<void const *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
 }
 
-template <int T, int E, int SIGMA>
+template <int T, int E, int SIGMA, bool PK>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                 uint32_t nblocks, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, rank_, keyd, nkeys,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                 uint32_t nblocks, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd);
 	}
-	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA>(B); }
+	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr);
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr);
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
 	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
 	{
-		hipLaunchKernelGGL((k_chain<T, E>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
+		hipLaunchKernelGGL((k_chain<T, E, PK>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
 		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
 	}
 	static hipError_t prepare(size_t lds_columns)
 	{
 		hipError_t e;
-		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK>, colblock_lds_bytes<T, E, SIGMA>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP>, colblock_lds_bytes<T, E, SIGMA>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_columns<T, E, SIGMA>, lds_columns)) != hipSuccess) return e;
-		if ((e = allow_lds(k_chain<T, E>, chain_lds_bytes<T, E>())) != hipSuccess) return e;
+		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>())) != hipSuccess) return e;
+		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>())) != hipSuccess) return e;
+		if ((e = allow_lds(k_columns<T, E, SIGMA, PK>, lds_columns)) != hipSuccess) return e;
+		if ((e = allow_lds(k_chain<T, E, PK>, chain_lds_bytes<T, E, PK>())) != hipSuccess) return e;
 		return hipSuccess;
 	}
 	static KernelSet make()
 	{
 		KernelSet k;
 		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
-		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA>();
+		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
+		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
 		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns;
-		k.lds_chain = chain_lds_bytes<T, E>();
+		k.lds_chain = chain_lds_bytes<T, E, PK>();
 		k.chain = &chain; k.prepare = &prepare;
 		return k;
 	}
@@ -95,19 +96,20 @@ struct Launch {
 
 bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 {
-#define FSEQ_TRY(T_, E_)                                                             \
-	if (m <= (uint32_t) (T_) * (E_))                                                 \
-	{                                                                                \
-		*out = (sigma <= 4) ? Launch<T_, E_, 4>::make() : Launch<T_, E_, 16>::make(); \
-		return true;                                                                 \
+#define FSEQ_TRY(T_, E_, PK_)                                                                  \
+	if (m <= (uint32_t) (T_) * (E_))                                                           \
+	{                                                                                          \
+		*out = (sigma <= 4) ? Launch<T_, E_, 4, PK_>::make() : Launch<T_, E_, 16, PK_>::make(); \
+		return true;                                                                           \
 	}
 	if (sigma > 16) return false;
-	FSEQ_TRY(64, 1)
-	FSEQ_TRY(64, 7)
-	FSEQ_TRY(256, 5)
-	FSEQ_TRY(512, 5)
-	FSEQ_TRY(512, 7)
-	FSEQ_TRY(1024, 7)
+	FSEQ_TRY(64, 1, false)
+	FSEQ_TRY(64, 7, false)
+	FSEQ_TRY(256, 5, false)
+	FSEQ_TRY(512, 5, false)
+	FSEQ_TRY(512, 7, false)
+	FSEQ_TRY(1024, 7, false)
+	FSEQ_TRY(1024, 11, true)      // 16-bit LDS state: m <= 11,264 (BASELINE config C5)
 #undef FSEQ_TRY
 	return false;
 }
@@ -255,9 +257,9 @@ int prepare_geometry(fseq_ctx *c)
 	if (n2 < 2) n2 = 2;
 	c->N2 = n2;
 	if (!select_kernels(p.m, c->sigma, &c->ks))
-		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 7168, sigma <= 16 in this build)");
+		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 11264, sigma <= 16 in this build)");
 	c->lds_columns = c->ks.columns_lds(c->B);
-	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT)
+	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
 		return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 	HIP_TRY(c, c->ks.prepare(c->lds_columns));
 	HIP_TRY(c, allow_lds(k_dp, dp_lds_bytes()));
@@ -573,7 +575,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
-		ks.snap(st, (uint32_t) grp.size(), ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
+		ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
 		        c->d_snap_a, c->d_snap_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());

@@ -18,6 +18,8 @@
 
 #include "fseq_core.hpp"
 
+#include <type_traits>
+
 namespace fseq {
 
 constexpr uint32_t PAD_KEY = 0xFFFFFFFFu;
@@ -100,8 +102,10 @@ __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__res
 // ------------------------------------------------------------------------------------------------
 // Shared pieces of the column kernels
 // ------------------------------------------------------------------------------------------------
-template <int T, int E>
-__device__ __forceinline__ void read_chunk(uint32_t const *a_l, uint32_t const *d_l, uint32_t (&a)[E], uint32_t (&d)[E])
+// PK ("packed") kernels keep row ids -- and, where the values allow it, divergences -- as 16-bit
+// LDS words: m <= 65535 rows then fit the 160 KiB of a CU (BASELINE config C5: m = 10,000).
+template <int T, int E, typename PA, typename PD>
+__device__ __forceinline__ void read_chunk(PA const *a_l, PD const *d_l, uint32_t (&a)[E], uint32_t (&d)[E])
 {
 	uint32_t const p0 = threadIdx.x * E;
 #pragma unroll
@@ -114,14 +118,15 @@ __device__ __forceinline__ void read_chunk(uint32_t const *a_l, uint32_t const *
 //            task_rb ascending) -- pass 2 costs at most one more sweep of the alignment.
 enum { MODE_RANK = 0, MODE_SNAP = 1 };
 
-template <int T, int E, int SIGMA>
+template <int T, int E, int SIGMA, int MODE, bool PK>
 __host__ __device__ inline size_t colblock_lds_bytes()
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 2 * carve_bytes(CAP, 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4);
+	return carve_bytes(CAP, PK ? 2 : 4) + carve_bytes(CAP, (PK && MODE == 0) ? 2 : 4) + 2 * carve_bytes(CAP, 1)
+	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4);
 }
 
-template <int T, int E, int SIGMA, int MODE>
+template <int T, int E, int SIGMA, int MODE, bool PK>
 __global__ __launch_bounds__(T) void k_colblock(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks,
 	// MODE_RANK outputs
@@ -133,9 +138,12 @@ __global__ __launch_bounds__(T) void k_colblock(
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// MODE_RANK keeps divergences relative to the block start (0..B: 16 bits when PK)
+	using AT = std::conditional_t<PK, uint16_t, uint32_t>;
+	using DT = std::conditional_t<(PK && MODE == MODE_RANK), uint16_t, uint32_t>;
 	Carver cv{smem};
-	uint32_t *a_l = cv.take<uint32_t>(CAP);
-	uint32_t *d_l = cv.take<uint32_t>(CAP);
+	AT *a_l = cv.take<AT>(CAP);
+	DT *d_l = cv.take<DT>(CAP);
 	uint8_t *sym0 = cv.take<uint8_t>(CAP);
 	uint8_t *sym1 = cv.take<uint8_t>(CAP);
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
@@ -153,8 +161,8 @@ __global__ __launch_bounds__(T) void k_colblock(
 		for (int e = 0; e < E; ++e)
 		{
 			uint32_t const pos = p0 + e;
-			a_l[pos] = pos < m ? pos : 0u;
-			d_l[pos] = pos < m ? (uint32_t) k0 : 0u;
+			a_l[pos] = (AT) (pos < m ? pos : 0u);
+			d_l[pos] = 0;
 		}
 	}
 	else
@@ -171,11 +179,12 @@ __global__ __launch_bounds__(T) void k_colblock(
 		for (int i = 0; i < E; ++i)
 		{
 			uint32_t const idx = tid + i * T;
-			a_l[idx] = idx < m ? sa[idx] : 0u;
-			d_l[idx] = idx < m ? sd[idx] : 0u;
+			a_l[idx] = (AT) (idx < m ? sa[idx] : 0u);
+			d_l[idx] = (DT) (idx < m ? sd[idx] : 0u);
 		}
 	}
 	uint32_t const nb = (uint32_t) (kend - k0);
+	uint32_t const dbase = (MODE == MODE_RANK) ? (uint32_t) k0 : 0u;
 
 	bool const has_chunk = tid * 16u < m;
 	uint4 nxt = make_uint4(0, 0, 0, 0);
@@ -215,11 +224,11 @@ __global__ __launch_bounds__(T) void k_colblock(
 #pragma unroll
 		for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (uint32_t) symc[a[e]] : (uint32_t) SIGMA;
 
-		partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1), scr, dst, dnew);
+		partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 
 #pragma unroll
 		for (int e = 0; e < E; ++e)
-			if (p0 + e < m) { a_l[dst[e]] = a[e]; d_l[dst[e]] = dnew[e]; }
+			if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = (DT) dnew[e]; }
 		if (more && has_chunk)
 			*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
 		__syncthreads();
@@ -234,7 +243,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 		read_chunk<T, E>(a_l, d_l, a, d);
 		uint32_t nf = 0;
 #pragma unroll
-		for (int e = 0; e < E; ++e) nf += (p0 + e < m && (p0 + e == 0 || d[e] > (uint32_t) k0)) ? 1u : 0u;
+		for (int e = 0; e < E; ++e) nf += (p0 + e < m && (p0 + e == 0 || d[e] > 0u)) ? 1u : 0u;
 		uint32_t total;
 		uint32_t r = block_excl_add<T>(nf, sscr, &total);
 		size_t const ob = (size_t) blockIdx.x * m;
@@ -244,10 +253,10 @@ __global__ __launch_bounds__(T) void k_colblock(
 			uint32_t const pos = p0 + e;
 			if (pos < m)
 			{
-				bool const first = (pos == 0 || d[e] > (uint32_t) k0);
+				bool const first = (pos == 0 || d[e] > 0u);
 				r += first ? 1u : 0u;
 				rank[ob + a[e]] = r - 1u;
-				if (first) keyd[ob + r - 1u] = d[e];
+				if (first) keyd[ob + r - 1u] = d[e] + dbase;
 			}
 		}
 		if (tid == 0) nkeys[blockIdx.x] = total;
@@ -257,11 +266,11 @@ __global__ __launch_bounds__(T) void k_colblock(
 // ------------------------------------------------------------------------------------------------
 // Phase B: the serial chain over blocks (one workgroup).
 // ------------------------------------------------------------------------------------------------
-template <int T, int E>
+template <int T, int E, bool PK>
 __host__ __device__ inline size_t chain_lds_bytes()
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 4 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 16>)) + carve_bytes(T / WAVE + 1, 4);
+	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 16>)) + carve_bytes(T / WAVE + 1, 4);
 }
 
 __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
@@ -283,7 +292,7 @@ __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
 //   out_rank/out_keyd/out_nkeys: if set, the chain's composite key block [blockIdx.x]
 // Used three times: compose super-blocks (parallel), chain the super-blocks (one
 // workgroup), expand every super-block back to block boundaries (parallel).
-template <int T, int E>
+template <int T, int E, bool PK>
 __global__ __launch_bounds__(T) void k_chain(
 	uint32_t const *__restrict__ rank, uint32_t const *__restrict__ keyd, uint32_t const *__restrict__ nkeys,
 	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block,
@@ -293,10 +302,11 @@ __global__ __launch_bounds__(T) void k_chain(
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	using AT = std::conditional_t<PK, uint16_t, uint32_t>;     // row ids and ranks are < m
 	Carver cv{smem};
-	uint32_t *a_l = cv.take<uint32_t>(CAP);
+	AT *a_l = cv.take<AT>(CAP);
+	AT *rk = cv.take<AT>(CAP);
 	uint32_t *d_l = cv.take<uint32_t>(CAP);
-	uint32_t *rk = cv.take<uint32_t>(CAP);
 	uint32_t *kd = cv.take<uint32_t>(CAP);
 	StepScratch<T, 16> &scr = *cv.take<StepScratch<T, 16>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
@@ -313,9 +323,9 @@ __global__ __launch_bounds__(T) void k_chain(
 		{
 			uint32_t const idx = tid + i * T;
 			bool const in = idx < m;
-			a_l[idx] = in ? (start_a ? start_a[sb + idx] : idx) : 0u;
+			a_l[idx] = (AT) (in ? (start_a ? start_a[sb + idx] : idx) : 0u);
 			d_l[idx] = in ? (start_d ? start_d[sb + idx] : kstart) : 0u;
-			rk[idx] = in ? rank[rb + idx] : 0u;
+			rk[idx] = (AT) (in ? rank[rb + idx] : 0u);
 			kd[idx] = in ? keyd[rb + idx] : 0u;
 		}
 	}
@@ -360,11 +370,11 @@ __global__ __launch_bounds__(T) void k_chain(
 			read_chunk<T, E>(a_l, d_l, a, d);
 #pragma unroll
 			for (int e = 0; e < E; ++e)
-				s[e] = (p0 + e < m) ? ((rk[a[e]] >> (4u * p)) & 15u) : 16u;
+				s[e] = (p0 + e < m) ? (((uint32_t) rk[a[e]] >> (4u * p)) & 15u) : 16u;
 			partition_step<T, E, 16>(d, s, 0u, scr, dst, dnew);
 #pragma unroll
 			for (int e = 0; e < E; ++e)
-				if (p0 + e < m) { a_l[dst[e]] = a[e]; d_l[dst[e]] = dnew[e]; }
+				if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = dnew[e]; }
 			__syncthreads();
 		}
 
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(T) void k_chain(
 			for (int i = 0; i < E; ++i)
 			{
 				uint32_t const idx = tid + i * T;
-				rk[idx] = pr[i];
+				rk[idx] = (AT) pr[i];
 				kd[idx] = pk[i];
 			}
 		}
@@ -442,12 +452,28 @@ __global__ __launch_bounds__(T) void k_chain(
 // Divergence values are replaced by order-preserving ids (sorted distinct boundary values first,
 // then one new id per column), so the histogram is a dense LDS table updated incrementally.
 // ------------------------------------------------------------------------------------------------
-template <int T, int E, int SIGMA>
+template <int T, int E, int SIGMA, bool PK>
 __host__ __device__ inline size_t columns_lds_bytes(uint32_t B)
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return carve_bytes(2 * CAP, 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(CAP + B, 4) + carve_bytes(CAP, 4)
+	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(PK ? (CAP + B + 1) / 2 : CAP + B, 4) + carve_bytes(CAP, 4)
 	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4);
+}
+
+// divergence-value histogram: one counter per id; PK: two 16-bit counters per word, updated with
+// 32-bit LDS atomics (word = hi * 65536 + lo holds exactly once every update of a column has landed:
+// the counts themselves are in [0, m], m <= 65535)
+template <bool PK> __device__ __forceinline__ uint32_t cnt_get(uint32_t const *cnt_l, uint32_t i)
+{
+	return PK ? ((cnt_l[i >> 1] >> ((i & 1u) * 16u)) & 0xFFFFu) : cnt_l[i];
+}
+template <bool PK> __device__ __forceinline__ void cnt_inc(uint32_t *cnt_l, uint32_t i)
+{
+	if (PK) atomicAdd(&cnt_l[i >> 1], 1u << ((i & 1u) * 16u)); else atomicAdd(&cnt_l[i], 1u);
+}
+template <bool PK> __device__ __forceinline__ void cnt_dec(uint32_t *cnt_l, uint32_t i)
+{
+	if (PK) atomicSub(&cnt_l[i >> 1], 1u << ((i & 1u) * 16u)); else atomicSub(&cnt_l[i], 1u);
 }
 
 template <int T>
@@ -471,7 +497,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 }
 
 // header of a per-column list: {n_entries, cnt0, complete, cum}
-template <int T, int E, int SIGMA>
+template <int T, int E, int SIGMA, bool PK>
 __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
@@ -479,12 +505,14 @@ __global__ __launch_bounds__(T) void k_columns(
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// [a_l][d_l][sym0][sym1][cnt_l] are contiguous: the prologue's sort buffer (N2 < 2m words) overlays them
+	using AT = std::conditional_t<PK, uint16_t, uint32_t>;     // row ids < m, value ids < m + B
 	Carver cv{smem};
-	uint32_t *a_l = cv.take<uint32_t>(2 * CAP);
-	uint32_t *d_l = a_l + CAP;
+	AT *a_l = cv.take<AT>(CAP);
+	AT *d_l = cv.take<AT>(CAP);
 	uint8_t *sym0 = cv.take<uint8_t>(CAP);
 	uint8_t *sym1 = cv.take<uint8_t>(CAP);
-	uint32_t *cnt_l = cv.take<uint32_t>(CAP + B);
+	uint32_t *cnt_l = cv.take<uint32_t>(PK ? (CAP + B + 1) / 2 : CAP + B);
 	uint32_t *V_l = cv.take<uint32_t>(CAP);
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
@@ -495,24 +523,22 @@ __global__ __launch_bounds__(T) void k_columns(
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	uint32_t const nb = (uint32_t) (kend - k0);
 
-	// ---- prologue: boundary state -> registers
+	// ---- prologue
+	// boundary state straight into registers (chunk ownership: positions tid*E .. tid*E+E-1)
+	uint32_t a[E], d[E];
 	{
 		size_t const ob = (size_t) blockIdx.x * m;
 #pragma unroll
-		for (int i = 0; i < E; ++i)
+		for (int e = 0; e < E; ++e)
 		{
-			uint32_t const idx = tid + i * T;
-			a_l[idx] = idx < m ? bstate_a[ob + idx] : 0u;
-			d_l[idx] = idx < m ? bstate_d[ob + idx] : 0u;
+			uint32_t const pos = p0 + e;
+			a[e] = pos < m ? bstate_a[ob + pos] : 0u;
+			d[e] = pos < m ? bstate_d[ob + pos] : 0u;
 		}
 	}
-	__syncthreads();
-	uint32_t a[E], d[E];
-	read_chunk<T, E>(a_l, d_l, a, d);
-	__syncthreads();
 
 	// ---- sorted distinct divergence values -> V_l[0..D0)
-	uint32_t *sb = a_l;                       // N2 <= 2*CAP words
+	uint32_t *sb = reinterpret_cast<uint32_t *>(a_l);   // N2 < 2m words, overlays a_l .. cnt_l
 	for (uint32_t i = tid; i < N2; i += T) sb[i] = PAD_KEY;
 	__syncthreads();
 #pragma unroll
@@ -545,7 +571,8 @@ __global__ __launch_bounds__(T) void k_columns(
 			}
 		}
 	}
-	for (uint32_t i = tid; i < D0 + nb; i += T) cnt_l[i] = 0;
+	__syncthreads();                          // the sort buffer (overlaying cnt_l) is dead from here
+	for (uint32_t i = tid; i < (PK ? (D0 + nb + 1u) / 2u : D0 + nb); i += T) cnt_l[i] = 0;
 	__syncthreads();
 
 	// ---- ids + initial histogram
@@ -564,12 +591,11 @@ __global__ __launch_bounds__(T) void k_columns(
 				if (V_l[mid] < key) lo = mid + 1; else hi = mid;
 			}
 			id[e] = lo;
-			atomicAdd(&cnt_l[lo], 1u);
+			cnt_inc<PK>(cnt_l, lo);
 		}
 	}
-	__syncthreads();                          // everyone is done with sb (aliases a_l/d_l)
 #pragma unroll
-	for (int e = 0; e < E; ++e) { a_l[p0 + e] = a[e]; d_l[p0 + e] = id[e]; }
+	for (int e = 0; e < E; ++e) { a_l[p0 + e] = (AT) a[e]; d_l[p0 + e] = (AT) id[e]; }
 
 	bool const has_chunk = tid * 16u < m;
 	uint4 nxt = make_uint4(0, 0, 0, 0);
@@ -602,12 +628,12 @@ __global__ __launch_bounds__(T) void k_columns(
 		{
 			if (p0 + e < m)
 			{
-				a_l[dst[e]] = a[e];
-				d_l[dst[e]] = dnew[e];
+				a_l[dst[e]] = (AT) a[e];
+				d_l[dst[e]] = (AT) dnew[e];
 				if (dnew[e] != d[e])
 				{
-					atomicSub(&cnt_l[d[e]], 1u);
-					atomicAdd(&cnt_l[dnew[e]], 1u);
+					cnt_dec<PK>(cnt_l, d[e]);
+					cnt_inc<PK>(cnt_l, dnew[e]);
 				}
 			}
 		}
@@ -632,7 +658,7 @@ __global__ __launch_bounds__(T) void k_columns(
 			for (int32_t base = top; base >= 0; base -= 64)
 			{
 				int32_t const i = base - (int32_t) lane;
-				uint32_t const c = (i >= 0) ? cnt_l[i] : 0u;
+				uint32_t const c = (i >= 0) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
 				uint32_t const v = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
 				bool const nz = c > 0;
 				bool const rec = nz && v >= thr;
@@ -655,7 +681,7 @@ __global__ __launch_bounds__(T) void k_columns(
 			if (lane == 0)
 			{
 				out[0] = make_uint2((uint32_t) (k + 1), R);
-				hdr[k] = make_uint4(nent, zero_present ? cnt_l[0] : 0u, cum == m ? 1u : 0u, cum);
+				hdr[k] = make_uint4(nent, zero_present ? cnt_get<PK>(cnt_l, 0u) : 0u, cum == m ? 1u : 0u, cum);
 			}
 		}
 	}

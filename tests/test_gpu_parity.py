@@ -75,6 +75,8 @@ CASES = [
     (30, 300, 8, 4, 50, 1e-2, 5, 1, 32),                 # sigma = 16
     (600, 1500, 20, 8, 300, 2e-3, 25, 1, 64),            # sigma = 16, T = 256
     (1, 50, 5, 1, 10, 0.0, 26, 0, 8),                    # single row: cannot reduce
+    (9000, 1200, 40, 16, 400, 2e-4, 27, 0, 128),         # 16-bit LDS state (m > 7168), sigma = 4
+    (10000, 2500, 100, 32, 500, 1e-4, 0x5EED0005, 1, 0), # BASELINE config C5 rows (m = 10,000, sigma = 16), shortened columns
 ]
 
 
