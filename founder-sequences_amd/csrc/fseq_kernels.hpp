@@ -904,10 +904,10 @@ __device__ __forceinline__ bool dp_strip(
 	if (vmin != 0xFFFFFFFFu && vmin <= st.best_v)
 	{
 		uint64_t const wmask = __ballot(ok && val == vmin);
-		int const src = 63 - (int) __builtin_clzll(wmask);
+		int const src = 63 - (int) __builtin_clzll(wmask);       // wave-uniform: v_readlane, no LDS round trip
 		st.best_v = vmin;
-		st.best_lb = shfl_u32(idx, src) + L;
-		st.best_sz = shfl_u32(cum, src);
+		st.best_lb = readlane_u32(idx, src) + L;
+		st.best_sz = readlane_u32(cum, src);
 	}
 	bool const last = s0 + 64u >= nent;                       // strip reaches the end of the list
 	st.cum_base = readlane_u32(cum, 63);
