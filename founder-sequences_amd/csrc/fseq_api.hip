@@ -23,13 +23,13 @@ namespace {
 struct KernelSet {
 	uint32_t T, E, sigma, cap;
 	size_t lds_colblock, lds_snap;
-	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
+	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
 	             uint32_t *, uint32_t *, uint32_t *);
-	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
+	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *);
+	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass);
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -47,23 +47,23 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int T, int E, int SIGMA, bool PK>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
+	                 uint32_t nblocks, uint32_t npass, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, rank_, keyd, nkeys,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd)
+	                 uint32_t nblocks, uint32_t npass, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr)
+	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr);
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass);
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -99,10 +99,10 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 #define FSEQ_TRY(T_, E_, PK_)                                                                  \
 	if (m <= (uint32_t) (T_) * (E_))                                                           \
 	{                                                                                          \
-		*out = (sigma <= 4) ? Launch<T_, E_, 4, PK_>::make() : Launch<T_, E_, 16, PK_>::make(); \
+		*out = Launch<T_, E_, 4, PK_>::make();                                                  \
 		return true;                                                                           \
 	}
-	if (sigma > 16) return false;
+	if (sigma > 256) return false;
 	FSEQ_TRY(64, 1, false)
 	FSEQ_TRY(64, 7, false)
 	FSEQ_TRY(256, 5, false)
@@ -138,7 +138,7 @@ struct fseq_ctx {
 	uint8_t code_to_byte[256]{};
 
 	// geometry
-	uint32_t B = 0, nblocks = 0, N2 = 0;
+	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
 	KernelSet ks{};
 	bool kernels_ready = false;
 	size_t lds_columns = 0;
@@ -256,8 +256,13 @@ int prepare_geometry(fseq_ctx *c)
 	while (n2 < p.m) n2 <<= 1;
 	if (n2 < 2) n2 = 2;
 	c->N2 = n2;
+	{
+		uint32_t bits = 1;
+		while ((1u << bits) < c->sigma) ++bits;
+		c->npass = (bits + 1) / 2;               // 2-bit digit passes per column
+	}
 	if (!select_kernels(p.m, c->sigma, &c->ks))
-		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 11264, sigma <= 16 in this build)");
+		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 11264 in this build)");
 	c->lds_columns = c->ks.columns_lds(c->B);
 	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
 		return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
@@ -398,7 +403,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 
 	// ---- phase A + B (independent of X)
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
-	ks.rank(st, c->nblocks, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
+	ks.rank(st, c->nblocks, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_rank, c->d_keyd, c->d_nkeys);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	{
 		// phase B, two-level: compose groups of G blocks into super-blocks (parallel), chain the
@@ -430,7 +435,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		// ---- phase C + D
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr);
+		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass);
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
 		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
@@ -575,7 +580,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
-		ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
+		ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
 		        c->d_snap_a, c->d_snap_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
@@ -621,7 +626,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
 	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
 	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
-	c->ks.rank(st, 1, c->ks.lds_colblock, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
+	c->ks.rank(st, 1, c->ks.lds_colblock, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, 1, c->npass, d_rank, d_keyd, d_nk);
 	std::vector<uint32_t> rank(m);
 	uint32_t nk = 0;
 	hipError_t e1 = hipMemcpyAsync(rank.data(), d_rank, (size_t) m * 4, hipMemcpyDeviceToHost, st);

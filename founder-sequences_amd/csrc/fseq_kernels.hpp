@@ -126,9 +126,13 @@ __host__ __device__ inline size_t colblock_lds_bytes()
 	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4);
 }
 
+// A column with alphabet size sigma is npass = ceil(log2(sigma) / 2) stable partitions by 2-bit digits,
+// least significant first, every pass with the same first-in-bucket value k+1: rows whose
+// predecessor differs in a lower digit already carry k+1 (the largest value there is) through the
+// range maximum of the later passes, so the result equals the single sigma-bucket partition.
 template <int T, int E, int SIGMA, int MODE, bool PK>
 __global__ __launch_bounds__(T) void k_colblock(
-	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks,
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass,
 	// MODE_RANK outputs
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	// MODE_SNAP inputs / outputs
@@ -219,19 +223,22 @@ __global__ __launch_bounds__(T) void k_colblock(
 		if (more && has_chunk)
 			nxt = *reinterpret_cast<uint4 const *>(msa + (k0 + j + 1) * ld + tid * 16u);
 
-		uint32_t a[E], d[E], s[E], dst[E], dnew[E];
-		read_chunk<T, E>(a_l, d_l, a, d);
+		for (uint32_t pass = 0; pass < npass; ++pass)
+		{
+			uint32_t a[E], d[E], s[E], dst[E], dnew[E];
+			read_chunk<T, E>(a_l, d_l, a, d);
 #pragma unroll
-		for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (uint32_t) symc[a[e]] : (uint32_t) SIGMA;
+			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (((uint32_t) symc[a[e]] >> (2u * pass)) & 3u) : (uint32_t) SIGMA;
 
-		partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
+			partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 
 #pragma unroll
-		for (int e = 0; e < E; ++e)
-			if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = (DT) dnew[e]; }
-		if (more && has_chunk)
-			*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
-		__syncthreads();
+			for (int e = 0; e < E; ++e)
+				if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = (DT) dnew[e]; }
+			if (pass + 1 == npass && more && has_chunk)
+				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
+			__syncthreads();
+		}
 		snapshot_if_requested(k0 + j + 1);
 	}
 
@@ -270,20 +277,20 @@ template <int T, int E, bool PK>
 __host__ __device__ inline size_t chain_lds_bytes()
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 16>)) + carve_bytes(T / WAVE + 1, 4);
+	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 4>)) + carve_bytes(T / WAVE + 1, 4);
 }
 
 __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
 {
 	if (D <= 1) return 0;
 	uint32_t const bits = 32u - (uint32_t) __builtin_clz(D - 1u);
-	return (bits + 3u) / 4u;
+	return (bits + 1u) / 2u;
 }
 
 // One workgroup = one chain over the consecutive key blocks [b0, b1), b0 = blockIdx.x * G.
 // A "key block" is described by rank[b][row] (dense co-lex rank of the row's key), keyd[b][r]
 // (divergence in front of key r) and nkeys[b].  The chain applies, block after block, the stable
-// sort of the running order by block rank (4-bit LSD digit passes of partition_step; divergences
+// sort of the running order by block rank (2-bit LSD digit passes of partition_step; divergences
 // ride along; rows that start a new key take keyd).
 //   start:  start_a/start_d == nullptr : identity order, d = b0 * cols_per_block   (composition from scratch)
 //           else                        : state [blockIdx.x] of start_a/start_d     (exact state at the chain's first column)
@@ -308,7 +315,7 @@ __global__ __launch_bounds__(T) void k_chain(
 	AT *rk = cv.take<AT>(CAP);
 	uint32_t *d_l = cv.take<uint32_t>(CAP);
 	uint32_t *kd = cv.take<uint32_t>(CAP);
-	StepScratch<T, 16> &scr = *cv.take<StepScratch<T, 16>>(1);
+	StepScratch<T, 4> &scr = *cv.take<StepScratch<T, 4>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
 
 	uint32_t const tid = threadIdx.x;
@@ -362,7 +369,7 @@ __global__ __launch_bounds__(T) void k_chain(
 		}
 		__syncthreads();
 
-		// (3) LSD digit passes over the block rank
+		// (3) LSD 2-bit digit passes over the block rank
 		uint32_t const nd = rank_digits(D_cur);
 		for (uint32_t p = 0; p < nd; ++p)
 		{
@@ -370,8 +377,8 @@ __global__ __launch_bounds__(T) void k_chain(
 			read_chunk<T, E>(a_l, d_l, a, d);
 #pragma unroll
 			for (int e = 0; e < E; ++e)
-				s[e] = (p0 + e < m) ? (((uint32_t) rk[a[e]] >> (4u * p)) & 15u) : 16u;
-			partition_step<T, E, 16>(d, s, 0u, scr, dst, dnew);
+				s[e] = (p0 + e < m) ? (((uint32_t) rk[a[e]] >> (2u * p)) & 3u) : 4u;
+			partition_step<T, E, 4>(d, s, 0u, scr, dst, dnew);
 #pragma unroll
 			for (int e = 0; e < E; ++e)
 				if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = dnew[e]; }
@@ -501,7 +508,7 @@ template <int T, int E, int SIGMA, bool PK>
 __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr)
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -616,30 +623,33 @@ __global__ __launch_bounds__(T) void k_columns(
 		if (more && has_chunk)
 			nxt = *reinterpret_cast<uint4 const *>(msa + (k0 + j + 1) * ld + tid * 16u);
 
-		uint32_t s[E], dst[E], dnew[E];
-		read_chunk<T, E>(a_l, d_l, a, d);
-#pragma unroll
-		for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (uint32_t) symc[a[e]] : (uint32_t) SIGMA;
-
-		partition_step<T, E, SIGMA>(d, s, D0 + j, scr, dst, dnew);
-
-#pragma unroll
-		for (int e = 0; e < E; ++e)
+		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
-			if (p0 + e < m)
+			uint32_t s[E], dst[E], dnew[E];
+			read_chunk<T, E>(a_l, d_l, a, d);
+#pragma unroll
+			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (((uint32_t) symc[a[e]] >> (2u * pass)) & 3u) : (uint32_t) SIGMA;
+
+			partition_step<T, E, SIGMA>(d, s, D0 + j, scr, dst, dnew);
+
+#pragma unroll
+			for (int e = 0; e < E; ++e)
 			{
-				a_l[dst[e]] = (AT) a[e];
-				d_l[dst[e]] = (AT) dnew[e];
-				if (dnew[e] != d[e])
+				if (p0 + e < m)
 				{
-					cnt_dec<PK>(cnt_l, d[e]);
-					cnt_inc<PK>(cnt_l, dnew[e]);
+					a_l[dst[e]] = (AT) a[e];
+					d_l[dst[e]] = (AT) dnew[e];
+					if (dnew[e] != d[e])
+					{
+						cnt_dec<PK>(cnt_l, d[e]);
+						cnt_inc<PK>(cnt_l, dnew[e]);
+					}
 				}
 			}
+			if (pass + 1 == npass && more && has_chunk)
+				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
+			__syncthreads();
 		}
-		if (more && has_chunk)
-			*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
-		__syncthreads();
 
 		// ---- emit the top of the histogram for column k0+j (wave 0; the others run ahead into
 		// the next column and meet it again at the partition step's barrier).

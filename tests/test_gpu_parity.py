@@ -86,6 +86,22 @@ def test_long_path_matches_oracle(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     compare_long(pkg, msa, L, block_len=B)
 
 
+@pytest.mark.parametrize("sigma,m,n,L", [(3, 90, 600, 10), (40, 120, 800, 12), (200, 300, 500, 8), (256, 64, 300, 5)])
+def test_wide_and_odd_alphabets(pkg, sigma, m, n, L):
+    """Any byte alphabet: a column is ceil(log2(sigma)/2) two-bit partition passes."""
+    rng = np.random.default_rng(sigma)
+    founders = rng.integers(0, sigma, size=(5, n))
+    pick = rng.integers(0, 5, size=(m, (n + 99) // 100))
+    msa = np.empty((m, n), dtype=np.uint8)
+    for b in range(pick.shape[1]):
+        msa[:, b * 100:(b + 1) * 100] = founders[pick[:, b], b * 100:(b + 1) * 100]
+    noise = rng.random((m, n)) < 2e-3
+    msa[noise] = rng.integers(0, sigma, size=int(noise.sum()))
+    if sigma < 256:
+        msa = (msa.astype(np.uint16) * (255 // sigma)).astype(np.uint8)      # spread over the byte range
+    compare_long(pkg, msa, L, block_len=48)
+
+
 def test_block_states_and_lists_match_oracle(pkg):
     m, n, L, B = 200, 1200, 15, 100
     msa = fso.synth_msa(fso.synth_spec(31, 6, 150, 3e-3), m, n)
