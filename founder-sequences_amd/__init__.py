@@ -68,7 +68,7 @@ EXPORTS = [
     "fseq_abi_version", "fseq_strerror", "fseq_create", "fseq_destroy", "fseq_last_error",
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
-    "fseq_short_path_runs", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+    "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
 ]
 
 _lib = None
@@ -102,6 +102,9 @@ def load_library():
     L.fseq_get_segments.argtypes = [vp, vp]
     L.fseq_boundary_state.argtypes = [vp, u64, vp, vp]
     L.fseq_short_path_runs.argtypes = [vp, vp, vp]
+    L.fseq_join_greedy.argtypes = [vp, vp]
+    L.fseq_greedy_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp]
+    L.fseq_write_founders.argtypes = [vp, C.POINTER(vp), vp, C.c_char_p]
     L.fseq_debug_dp.argtypes = [vp, vp, vp, vp]
     L.fseq_debug_block_state.argtypes = [vp, u64, vp, vp]
     L.fseq_debug_column_list.argtypes = [vp, u64, vp, vp, vp, vp, vp]
@@ -117,6 +120,20 @@ def synth_threshold(mu):
     if mu >= 1.0:
         return 0xFFFFFFFFFFFFFFFF
     return int(mu * 18446744073709551616.0)
+
+
+def greedy_match_host(m, max_segment_size, lb, rb, a, d):
+    """greedy_matcher::match on caller-supplied boundary states (host only, no GPU needed)."""
+    L = load_library()
+    lb = np.ascontiguousarray(lb, dtype=np.uint64)
+    rb = np.ascontiguousarray(rb, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    d = np.ascontiguousarray(d, dtype=np.uint32)
+    perm = np.zeros((len(lb), max_segment_size), dtype=np.uint32)
+    rc = L.fseq_greedy_match_host(m, max_segment_size, len(lb), lb.ctypes.data, rb.ctypes.data, a.ctypes.data, d.ctypes.data, perm.ctypes.data)
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return perm
 
 
 class SegmentationContext:
@@ -215,6 +232,20 @@ class SegmentationContext:
         r = np.zeros(k, dtype=np.uint32)
         self._check(self.L.fseq_short_path_runs(self.h, f.ctypes.data, r.ctypes.data))
         return f, r
+
+    # ---- joining (join_context / greedy_matcher, host side)
+    def join_greedy(self):
+        """permutations[s, r]: input row whose segment-s substring is founder r's content."""
+        perm = np.zeros((self.result.segment_count, self.result.max_segment_size), dtype=np.uint32)
+        self._check(self.L.fseq_join_greedy(self.h, perm.ctypes.data))
+        return perm
+
+    def write_founders(self, msa, permutations, path):
+        """msa: the raw input rows as a C-contiguous uint8 array [m, n]."""
+        assert msa.dtype == np.uint8 and msa.flags["C_CONTIGUOUS"] and msa.shape == (self.m, self.n)
+        rows = (C.c_void_p * self.m)(*[msa.ctypes.data + r * msa.strides[0] for r in range(self.m)])
+        perm = np.ascontiguousarray(permutations, dtype=np.uint32)
+        self._check(self.L.fseq_write_founders(self.h, rows, perm.ctypes.data, path.encode() if path else None))
 
     # ---- debug / parity of intermediate state
     def debug_dp(self):

@@ -34,5 +34,22 @@ def build(force=False, verbose=False):
     return OUT
 
 
+CLI_SRC = os.path.join(HERE, "host", "founder_sequences.cpp")
+CLI_OUT = os.path.join(HERE, "bin", "founder_sequences")
+
+
+def build_cli(force=False):
+    """Host C++17 front end (same option surface as the reference CLI), linked against the C ABI."""
+    build()
+    if not force and os.path.exists(CLI_OUT) and os.path.getmtime(CLI_OUT) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(OUT)):
+        return CLI_OUT
+    os.makedirs(os.path.dirname(CLI_OUT), exist_ok=True)
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(os.path.dirname(HERE), "include"), CLI_SRC,
+           "-o", CLI_OUT, "-L", HERE, "-lfseq_hip", "-Wl,-rpath,$ORIGIN/..", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True)
+    return CLI_OUT
+
+
 if __name__ == "__main__":
+    build_cli(force="--force" in sys.argv)
     print(build(force="--force" in sys.argv, verbose=True))

@@ -7,6 +7,7 @@
 // unavailable the call fails with an error code.
 #include "../../include/fseq.h"
 #include "fseq_kernels.hpp"
+#include "fseq_join.hpp"
 
 #include <algorithm>
 #include <chrono>
@@ -883,6 +884,52 @@ int fseq_debug_column_list(fseq_ctx *c, uint64_t col, uint32_t *values, uint32_t
 	if (n_entries) *n_entries = h.x;
 	if (cnt0) *cnt0 = h.y;
 	if (complete) *complete = h.z;
+	return FSEQ_OK;
+}
+
+int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
+{
+	if (!c || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
+	(void) hipSetDevice(c->p.device);
+	size_t const m = c->p.m, S = c->segments.size();
+	std::vector<uint32_t> A(S * m), D(S * m);
+	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
+	std::vector<JoinSegment> segs(S);
+	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
+	greedy_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations);
+	return FSEQ_OK;
+}
+
+int fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                           uint32_t const *a, uint32_t const *d, uint32_t *permutations)
+{
+	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
+	std::vector<JoinSegment> segs(n_segments);
+	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
+	greedy_match(m, max_segment_size, segs, a, d, permutations);
+	return FSEQ_OK;
+}
+
+int fseq_write_founders(fseq_ctx *c, uint8_t const *const *rows, uint32_t const *permutations, char const *path)
+{
+	if (!c || !rows || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
+	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the founders output file");
+	size_t const X = c->res.max_segment_size, S = c->segments.size();
+	for (size_t row = 0; row < X; ++row)                       // join_context.cc:341-356
+	{
+		for (size_t s = 0; s < S; ++s)
+		{
+			uint32_t const idx = permutations[s * X + row];
+			fseq_segment const &sg = c->segments[s];
+			fwrite(rows[idx] + sg.lb, 1, sg.rb - sg.lb, f);
+		}
+		fputc('\n', f);
+	}
+	fflush(f);
+	if (f != stdout) fclose(f);
 	return FSEQ_OK;
 }
 

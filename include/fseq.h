@@ -136,6 +136,21 @@ int  fseq_boundary_state(fseq_ctx *ctx, uint64_t i, uint32_t *a_out, uint32_t *d
  * row in pBWT order; returns max_segment_size entries. */
 int  fseq_short_path_runs(fseq_ctx *ctx, uint32_t *first_idx, uint32_t *run_len);
 
+/* ---- segment joining on the host ----
+ * replaces: join_context::join_greedy -> greedy_matcher::match (join_context.cc:211-229,
+ * greedy_matcher.cc:204-465).  permutations: segment_count x max_segment_size uint32, row-major;
+ * permutations[s][r] = index of the input sequence whose [lb_s, rb_s) substring is founder r's
+ * content in segment s. */
+int  fseq_join_greedy(fseq_ctx *ctx, uint32_t *permutations);
+/* The same matcher on caller-supplied boundary states (no context, no device): segments given as
+ * lb[i], rb[i]; a, d: n_segments x m.  Used by the CPU tests of the host logic. */
+int  fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                            uint32_t const *a, uint32_t const *d, uint32_t *permutations);
+/* replaces: join_context::output_in_permutation_order (join_context.cc:333-356): max_segment_size
+ * lines; line r = concatenation over segments of rows[permutations[s][r]][lb_s, rb_s).  rows = the
+ * raw input sequences.  path NULL or "-" = stdout. */
+int  fseq_write_founders(fseq_ctx *ctx, uint8_t const *const *rows, uint32_t const *permutations, char const *path);
+
 /* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
 int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
 /* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */
