@@ -76,6 +76,9 @@ def main():
     ap.add_argument("--list-cap", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-alignments-in-flight measurement")
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
     args = ap.parse_args()
 
     import torch
@@ -100,12 +103,27 @@ def main():
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
     # one alignment per rank (alignment id = rank), generated on the device
     ctx.generate_synthetic(fdist.seed_for_alignment(w["seed"], rank), w["K"], w["B"], w["mu"], w["kind"])
+    # optional: more alignments in flight on the same GPU (the DP of one alignment occupies one CU)
+    extra = []
+    for j in range(1, max(1, args.concurrent)):
+        e = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
+        e.generate_synthetic(fdist.seed_for_alignment(w["seed"], world * j + rank), w["K"], w["B"], w["mu"], w["kind"])
+        extra.append(e)
 
     phase = {}
     counted = {"on": False}
 
     def step():
-        ctx.run()
+        if extra:
+            import threading
+            ths = [threading.Thread(target=e.run) for e in extra]
+            for th in ths:
+                th.start()
+            ctx.run()
+            for th in ths:
+                th.join()
+        else:
+            ctx.run()
         if counted["on"]:
             t = ctx.timings()
             for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
@@ -140,7 +158,7 @@ def main():
     achieved = BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9
     out = {
         "metric": "alignment cells/s (m*n/T) through pBWT+DP",
-        "value": world * m * n * steps / dt,
+        "value": world * max(1, args.concurrent) * m * n * steps / dt,
         "unit": "cells/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -155,6 +173,7 @@ def main():
             "workload": "%s: m=%d x n=%d synthetic founder-mosaic DNA (sigma=%d), segment-length-bound L=%d, "
                         "input resident in HBM column-major 1 B/cell; per rank one alignment"
                         % (args.workload, m, n, 16 if w["kind"] else 4, L),
+            "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "segments": int(res.segment_count), "dp_segments": int(res.dp_segment_count),
             "max_segment_size": int(res.max_segment_size),
@@ -174,6 +193,30 @@ def main():
             "avg_launch_ms": ms_c / launches_c,
         },
     }
+    # secondary figure (not `value`): the DP of one alignment occupies one CU for ~2/3 of a step, so
+    # several alignments (chromosomes) in flight share the chip; measured with 4 contexts / host threads
+    if world == 1 and args.concurrent == 1 and not args.no_batched:
+        import threading
+        others = []
+        for j in range(1, 4):
+            e = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
+            e.generate_synthetic(fdist.seed_for_alignment(w["seed"], j), w["K"], w["B"], w["mu"], w["kind"])
+            others.append(e)
+
+        def bstep():
+            ths = [threading.Thread(target=e.run) for e in others]
+            for th in ths:
+                th.start()
+            ctx.run()
+            for th in ths:
+                th.join()
+
+        bdt = fdist.timed_steps(bstep, 3, 1, dist=None, device_sync=torch.cuda.synchronize, tensor_factory=None)
+        out["batched_throughput"] = {"alignments_in_flight": 4, "value": 4 * m * n * 3 / bdt, "unit": "cells/s",
+                                     "ms_per_step": bdt / 3 * 1e3,
+                                     "note": "4 alignments of the same shape processed concurrently on the one GPU (one context, stream and host thread each); not the headline metric"}
+        for e in others:
+            e.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(ctx, w, args.cpu_threads or min(os.cpu_count() or 1, 16))
     else:
