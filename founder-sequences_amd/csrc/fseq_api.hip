@@ -291,7 +291,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
-		if ((rc = dev_alloc(c, &c->d_flags, 128))) return rc;
+		if ((rc = dev_alloc(c, &c->d_flags, 256))) return rc;
 		if (p.n >= 2 * p.segment_length)
 		{
 			c->dp_size = p.n - p.segment_length + 1;
@@ -456,14 +456,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 #ifdef FSEQ_DP_STAMPS
 		{
-			unsigned long long stamps[20];
+			unsigned long long stamps[48];
 			HIP_TRY(c, hipMemcpy(stamps, c->d_flags + 8, sizeof(stamps), hipMemcpyDeviceToHost));
-			char const *names[4] = {"wave0", "wave13", "loader", "writer"};
-			for (int w = 0; w < 4; ++w)
+			for (int w = 0; w < 16; ++w)
 			{
-				unsigned long long const *q = stamps + 5 * w;
-				double const nr = (double) (q[4] ? q[4] : 1);
-				fprintf(stderr, "[dp stamps] %s rounds=%llu cycles/round: work=%.0f bar1=%.0f update=%.0f bar2=%.0f\n", names[w], q[4], q[0] / nr, q[1] / nr, q[2] / nr, q[3] / nr);
+				unsigned long long const *q = stamps + 3 * w;
+				double const nr = (double) (q[2] ? q[2] : 1);
+				fprintf(stderr, "[dp stamps] wave %2d rounds=%llu cycles/round: work=%.0f waits=%.0f\n", w, q[2], q[0] / nr, q[1] / nr);
 			}
 		}
 #endif

@@ -729,6 +729,7 @@ constexpr uint32_t DP_TRN = 64;           // sparse-table ring: last 64 samples 
 constexpr uint32_t DP_LEVELS = 32;
 constexpr uint32_t DP_HPMIN = 7;          // levels >= 7: input sample is older than the ring -> mailbox
 constexpr uint32_t DP_SLOTS = 3;          // list slots: rounds r, r+1, r+2
+constexpr uint32_t DP_MBSLOTS = 4;        // mailbox slots (read one round later in pipelined mode)
 constexpr uint32_t DP_Q = DP_RL / 2 + 1 + 2;   // LDS-DMA instructions the loader issues per round
 constexpr uint32_t DP_LOADER = 14, DP_WRITER = 15;
 
@@ -750,7 +751,7 @@ struct DpLds {
 __host__ __device__ inline size_t dp_lds_bytes()
 {
 	return carve_bytes(DPW, 8) + carve_bytes(DPW, 4) + 2 * carve_bytes(DP_STG, 4) + 2 * carve_bytes((size_t) DP_LEVELS * DP_TRN, 4)
-	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_SLOTS * 64, 4);
+	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_MBSLOTS * 64, 4);
 }
 
 // where a query may read: entries >= safe_lo and samples produced after block cb - DP_TRN live in LDS
@@ -978,14 +979,37 @@ struct DpRound {
 	bool final_round;
 };
 
-__device__ __forceinline__ DpRound dp_round(uint32_t r, uint32_t L, uint32_t n, uint32_t RL, uint32_t nrounds)
+// s_waitcnt vmcnt(N) takes an immediate: wait until at most N (4..31) of this wave's LDS-DMA loads are in flight
+__device__ __forceinline__ void dp_wait_all_but(uint32_t n)
+{
+#define FSEQ_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+	switch (n)
+	{
+		FSEQ_W(4) FSEQ_W(5) FSEQ_W(6) FSEQ_W(7) FSEQ_W(8) FSEQ_W(9) FSEQ_W(10) FSEQ_W(11) FSEQ_W(12) FSEQ_W(13) FSEQ_W(14)
+		FSEQ_W(15) FSEQ_W(16) FSEQ_W(17) FSEQ_W(18) FSEQ_W(19) FSEQ_W(20) FSEQ_W(21) FSEQ_W(22) FSEQ_W(23) FSEQ_W(24)
+		FSEQ_W(25) FSEQ_W(26) FSEQ_W(27) FSEQ_W(28) FSEQ_W(29) FSEQ_W(30) FSEQ_W(31)
+		default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+	}
+#undef FSEQ_W
+}
+
+// Round schedule.  nreg regular rounds of <= RL cells (end = L + r*RL + i), then -- pipelined mode
+// only -- one empty drain round (the update of the last regular round), then the final cell at
+// rb = n (lp.cc:165-183).
+struct DpSchedule {
+	uint32_t L, n, RL, nreg, nrounds;
+	bool pipe;
+};
+
+__device__ __forceinline__ DpRound dp_round(DpSchedule const &S, uint32_t r)
 {
 	DpRound R;
-	uint32_t const last_end = n - L;
-	R.final_round = (r + 1u == nrounds);
-	R.e0 = R.final_round ? n : (L + r * RL);
-	R.len = R.final_round ? 1u : min(RL, last_end - R.e0 + 1u);
-	R.t0 = R.e0 - L;
+	uint32_t const last_end = S.n - S.L;
+	R.final_round = (r + 1u == S.nrounds);
+	bool const regular = r < S.nreg;
+	R.e0 = R.final_round ? S.n : (regular ? S.L + r * S.RL : last_end + 1u);
+	R.len = R.final_round ? 1u : (regular ? min(S.RL, last_end - R.e0 + 1u) : 0u);
+	R.t0 = R.e0 - S.L;
 	R.t1 = R.t0 + R.len;
 	return R;
 }
@@ -996,6 +1020,112 @@ __device__ __forceinline__ void dp_barrier()
 	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
 	__builtin_amdgcn_s_barrier();
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// rmq.update, part 1 (rmq.hh:61-68 made O(1) to query): one 16-bit slice (positions [16c, 16c+16)
+// of the block) of the stack masks of the fresh entries of block blk.
+__device__ __forceinline__ void dp_mask_slice(DpLds const &D, DpRound const &R, uint32_t blk, uint32_t chunk)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u, idx = base + lane;
+	bool const fresh = idx >= R.t0 && idx < R.t1;
+	uint32_t const mine = D.Mr[idx & (DPW - 1u)];
+	uint32_t const plo = 16u * chunk, phi = plo + 16u;
+	// running minimum of the keys to the right of the slice, up to this lane: inclusive prefix-min
+	// over the lanes >= phi (the lane's own key included)
+	uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
+	pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+	uint32_t runmin = lane >= phi ? pm : mine;
+	uint32_t bits = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
+#pragma unroll
+	for (int pp = 15; pp >= 0; --pp)
+	{
+		uint32_t const p = plo + (uint32_t) pp;
+		uint32_t const x = readlane_u32(mine, (int) p);
+		bool const in = lane > p;
+		bits |= (in && x <= runmin) ? (1u << pp) : 0u;
+		runmin = in ? min(runmin, x) : runmin;
+	}
+	if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
+}
+
+// All four slices of one block by one wave: four independent dependency chains that interleave
+// (pipelined schedule, where only two waves do the update).
+__device__ __forceinline__ void dp_mask_block(DpLds const &D, DpRound const &R, uint32_t blk)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u, idx = base + lane;
+	bool const fresh = idx >= R.t0 && idx < R.t1;
+	uint32_t const mine = D.Mr[idx & (DPW - 1u)];
+	uint32_t runmin[4], bits[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+	{
+		uint32_t const plo = 16u * c, phi = plo + 16u;
+		uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
+		pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+		runmin[c] = lane >= phi ? pm : mine;
+		bits[c] = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
+	}
+#pragma unroll
+	for (int pp = 15; pp >= 0; --pp)
+	{
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			uint32_t const p = 16u * c + (uint32_t) pp;
+			uint32_t const x = readlane_u32(mine, (int) p);
+			bool const in = lane > p;
+			bits[c] |= (in && x <= runmin[c]) ? (1u << pp) : 0u;
+			runmin[c] = in ? min(runmin[c], x) : runmin[c];
+		}
+	}
+	if (fresh)
+		D.Kr[idx & (DPW - 1u)] = (unsigned long long) (bits[0] | (bits[1] << 16)) | ((unsigned long long) (bits[2] | (bits[3] << 16)) << 32);
+}
+
+// rmq.update, part 2 (rmq.hh:66-80): block blk is complete, push its samples on every level.
+// mb: mailbox slot holding the old level-(p-1) samples for the levels whose input is older than the ring.
+__device__ __forceinline__ void dp_push_samples(DpLds const &D, uint32_t blk, uint32_t mb)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u;
+	uint32_t const mine = D.Mr[(base + lane) & (DPW - 1u)];
+	uint32_t const new_val = wave_min_u32(mine);
+	uint32_t const new_smp = base + (uint32_t) __builtin_ctzll(__ballot(mine == new_val));   // first minimum of the block
+	uint32_t const bnum = blk + 1u;
+	if (lane < DP_LEVELS && (1u << lane) <= bnum)
+	{
+		uint32_t const j = bnum - (1u << lane);
+		uint32_t res = new_smp, resv = new_val;
+		if (lane >= 1)
+		{
+			uint32_t smp, sval;
+			if (lane < DP_HPMIN)
+			{
+				smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+				sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+			}
+			else
+			{
+				smp = D.MBi[mb * 64u + lane];
+				sval = D.MBv[mb * 64u + lane];
+			}
+			if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
+		}
+		D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
+		D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
+	}
 }
 
 __global__ __launch_bounds__(1024) void k_dp(
@@ -1016,8 +1146,8 @@ __global__ __launch_bounds__(1024) void k_dp(
 	D.Trv = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
 	uint32_t const off_LS = take((size_t) DP_SLOTS * DP_RL * 64 * 8);
 	uint32_t const off_H = take((size_t) DP_SLOTS * 64 * 16);
-	uint32_t const off_MBi = take((size_t) DP_SLOTS * 64 * 4);
-	uint32_t const off_MBv = take((size_t) DP_SLOTS * 64 * 4);
+	uint32_t const off_MBi = take((size_t) DP_MBSLOTS * 64 * 4);
+	uint32_t const off_MBv = take((size_t) DP_MBSLOTS * 64 * 4);
 	D.LS = (lds_u32 *) (lds0 + off_LS);
 	D.H = (lds_u32 *) (lds0 + off_H);
 	D.MBi = (lds_u32 *) (lds0 + off_MBi);
@@ -1027,18 +1157,35 @@ __global__ __launch_bounds__(1024) void k_dp(
 	uint32_t const lane = lane_id();
 	uint32_t const p2lim = min(2u * L, n - L) - 1u;          // lp.cc:72
 	uint32_t const last_end = n - L;                          // lp.cc:113
-	uint32_t const RL = min(L, DP_RL);
-	uint32_t const nrounds = (last_end - L) / RL + 1u + 1u;   // regular rounds + the final cell at rb = n (lp.cc:165-183)
+
+	// Two schedules.  Classic: rounds of <= min(L, 56) cells, the rmq.update of a round between two
+	// barriers.  Pipelined (L >= 96): rounds of 48 cells -- a round then never reads
+	// what the previous round wrote (a cell reads entries <= end - 2L), so two dedicated waves do
+	// the update of round r-1 while the compute waves are already in round r: one barrier a round.
+	DpSchedule S;
+	S.L = L; S.n = n;
+	S.pipe = L >= 96u;                                        // measured: pays only with 4 cells per compute wave
+	S.RL = S.pipe ? (min(L / 2u, 48u) / 12u) * 12u : min(L, DP_RL);   // pipelined: whole cells per compute wave
+	S.nreg = (last_end - L) / S.RL + 1u;
+	S.nrounds = S.nreg + (S.pipe ? 2u : 1u);
+	uint32_t const NWC = S.pipe ? 12u : DP_NWC;               // compute waves
+	uint32_t const nrounds = S.nrounds, RL = S.RL;
+	uint32_t const npairs = (RL + 1u) / 2u;                    // list DMA instructions per round (+3: headers, mailbox)
 
 	// loader: all LDS-DMA of round R (exactly DP_Q instructions, so that vmcnt counts rounds)
 	auto load_round = [&](uint32_t r) {
-		DpRound const R = dp_round(r, L, n, RL, nrounds);
+		DpRound const R = dp_round(S, r);
 		uint32_t const slot = r % DP_SLOTS;
-		for (uint32_t q = 0; q < DP_RL / 2; ++q)
+		// (RL + 1) / 2 list loads (two cells each) whatever the round's own length, so that every
+		// round issues the same number of instructions and vmcnt counts rounds
+		uint2 const *src = ent + (size_t) (R.e0 - 1u + (lane >> 5)) * stride + (lane & 31u) * 2u;
+		uint32_t dst = lds0_addr + off_LS + slot * DP_RL * 512u;
+		for (uint32_t q = 0; q < npairs; ++q)
 		{
 			uint32_t const i = 2u * q + (lane >> 5);
-			uint32_t const k = (i < R.len) ? R.e0 + i - 1u : 0u;
-			dma16(ent + (size_t) k * stride + (lane & 31u) * 2u, __builtin_amdgcn_readfirstlane(lds0_addr + off_LS + (slot * DP_RL + 2u * q) * 512u));
+			dma16(i < R.len ? (void const *) src : (void const *) ent, __builtin_amdgcn_readfirstlane(dst));
+			src += 2u * (size_t) stride;
+			dst += 1024u;
 		}
 		{
 			uint32_t const k = (lane < R.len) ? R.e0 + lane - 1u : 0u;
@@ -1048,12 +1195,32 @@ __global__ __launch_bounds__(1024) void k_dp(
 			// old sparse-table samples for the block that completes in round R (at most one: RL < 64)
 			uint32_t const blk = R.t0 >> 6;
 			uint32_t const bnum = blk + 1u;
-			bool const completes = !R.final_round && bnum * 64u <= R.t1;
-			size_t off = 0;
+			bool const completes = R.len > 0 && !R.final_round && bnum * 64u <= R.t1;
+			size_t o = 0;
 			if (completes && lane >= DP_HPMIN && lane < DP_LEVELS && (1u << lane) <= bnum)
-				off = (size_t) (lane - 1u) * A.tstride + (bnum - (1u << lane));
-			dma4(A.Tb + off, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBi + slot * 256u));
-			dma4(A.Tbv + off, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBv + slot * 256u));
+				o = (size_t) (lane - 1u) * A.tstride + (bnum - (1u << lane));
+			uint32_t const mb = r % DP_MBSLOTS;
+			dma4(A.Tb + o, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBi + mb * 256u));
+			dma4(A.Tbv + o, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBv + mb * 256u));
+		}
+	};
+	// writer: round P to HBM (stores only, never waited for)
+	auto flush_round = [&](uint32_t r) {
+		DpRound const P = dp_round(S, r);
+		if (lane < P.len)
+		{
+			uint32_t const t = P.t0 + lane;
+			A.M[t] = D.Mr[t & (DPW - 1u)];
+			A.LB[t] = D.LBr[t & (DP_STG - 1u)];
+			A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
+			if (!P.final_round) A.K[t] = D.Kr[t & (DPW - 1u)];
+		}
+		uint32_t const bnum = (P.t0 >> 6) + 1u;
+		if (P.len > 0 && !P.final_round && bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
+		{
+			uint32_t const j = bnum - (1u << lane);
+			A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
+			A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
 		}
 	};
 
@@ -1074,23 +1241,28 @@ __global__ __launch_bounds__(1024) void k_dp(
 	for (uint32_t r = 0; r < nrounds; ++r)
 	{
 		DP_STAMP(ts0);
-		DpRound const R = dp_round(r, L, n, RL, nrounds);
+		DpRound const R = dp_round(S, r);
 		uint32_t const slot = r % DP_SLOTS;
-		// entries < filled are indexed.  The ring keeps [t1 - DPW, t1); writes of this round land in
-		// [t0, t0 + RL), so anything >= filled + RL - DPW (+ margin) is safe to read from LDS.
-		uint32_t const filled = R.final_round ? (n - 2u * L + 1u) : R.t0;
+		// Entries < filled are indexed (masks + samples).  The ring keeps the last DPW entries and
+		// this round's (pipelined: this and the previous round's) results land above `filled`, so
+		// anything >= filled + (writes in flight) - DPW (+ margin) is safe to read from LDS.
+		uint32_t filled;
+		if (R.final_round) filled = n - 2u * L + 1u;
+		else if (!S.pipe) filled = R.t0;
+		else filled = (r == 0) ? 0u : dp_round(S, r - 1u).t0;
+		uint32_t const inflight = S.pipe ? 2u * RL : RL;
 		DpView V;
-		V.safe_lo = (filled + RL + 128u > DPW) ? (filled + RL + 128u - DPW) : 0u;
+		V.safe_lo = (filled + inflight + 128u > DPW) ? (filled + inflight + 128u - DPW) : 0u;
 		V.cb = filled >> 6;
 
-		if (wave < DP_NWC)
+		if (wave < NWC)
 		{
-			// ---- compute: cells i = wave, wave + 14, ...  (one CU's VALU issue rate bounds this
+			// ---- compute: cells i = wave, wave + NWC, ...  (one CU's VALU issue rate bounds this
 			// phase: a stage-interleaved, branch-free variant was measured slower)
 #pragma unroll
 			for (int g = 0; g < DP_G; ++g)
 			{
-				uint32_t const i = wave + (uint32_t) g * DP_NWC;
+				uint32_t const i = wave + (uint32_t) g * NWC;
 				if (i >= R.len) continue;
 				uint32_t const end = R.e0 + i;
 				uint32_t const t = end - L;
@@ -1123,31 +1295,33 @@ __global__ __launch_bounds__(1024) void k_dp(
 			if (r + 2u < nrounds)
 			{
 				load_round(r + 2u);
-				asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DP_Q) : "memory");
+				dp_wait_all_but(npairs + 3u);                  // = everything but the round just issued
 			}
 			else
 				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
+		else if (wave == DP_WRITER)
+		{
+			// ---- writer: a finished *and indexed* round to HBM
+			uint32_t const lag = S.pipe ? 2u : 1u;
+			if (r >= lag) flush_round(r - lag);
+		}
 		else
 		{
-			// ---- writer: flush round r-1 to HBM (stores only, never waited for)
-			if (r > 0)
+			// ---- pipelined mode, waves 12 and 13: rmq.update of round r-1 (rmq.hh:61-81)
+			if (r >= 1u)
 			{
-				DpRound const P = dp_round(r - 1u, L, n, RL, nrounds);
-				if (lane < P.len)
+				DpRound const P = dp_round(S, r - 1u);
+				if (P.len > 0 && !P.final_round)
 				{
-					uint32_t const t = P.t0 + lane;
-					A.M[t] = D.Mr[t & (DPW - 1u)];
-					A.LB[t] = D.LBr[t & (DP_STG - 1u)];
-					A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
-					A.K[t] = D.Kr[t & (DPW - 1u)];
-				}
-				uint32_t const bnum = (P.t0 >> 6) + 1u;
-				if (bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
-				{
-					uint32_t const j = bnum - (1u << lane);
-					A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
-					A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
+					uint32_t const blkA = P.t0 >> 6, blkB = (P.t1 - 1u) >> 6;
+					if (wave == 12u)
+					{
+						dp_mask_block(D, P, blkA);
+						if ((blkA + 1u) * 64u <= P.t1) dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
+					}
+					else if (blkB != blkA)
+						dp_mask_block(D, P, blkB);
 				}
 			}
 		}
@@ -1155,74 +1329,24 @@ __global__ __launch_bounds__(1024) void k_dp(
 		dp_barrier();
 		DP_STAMP(ts2);
 		if (R.final_round) break;                             // no rmq.update after the last cell
+		if (S.pipe)
+		{
+#ifdef FSEQ_DP_STAMPS
+			acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[4] += 1;
+#endif
+			continue;
+		}
 
-		// ---- rmq.update for the new entries [t0, t1) (rmq.hh:61-81).  At most two 64-blocks are touched
-		// and at most one completes (RL < 64).  Eight waves build the stack masks, each a 16-bit slice
-		// (positions p in [16c, 16c+16)) of one block; a ninth pushes the sparse-table samples.
+		// ---- classic mode: rmq.update for the new entries [t0, t1) (rmq.hh:61-81).  At most two
+		// 64-blocks are touched and at most one completes (RL < 64).  Eight waves build the stack
+		// masks, each a 16-bit slice of one block; a ninth pushes the sparse-table samples.
 		{
 			uint32_t const blkA = R.t0 >> 6, blkB = (R.t1 - 1u) >> 6;
 			uint32_t const nslices = 4u * (blkB - blkA + 1u);
 			if (wave < nslices)
-			{
-				uint32_t const blk = blkA + (wave >> 2), chunk = wave & 3u;
-				uint32_t const base = blk * 64u, idx = base + lane;
-				bool const fresh = idx >= R.t0 && idx < R.t1;
-				uint32_t const mine = D.Mr[idx & (DPW - 1u)];
-				uint32_t const plo = 16u * chunk, phi = plo + 16u;
-				// running minimum of the keys to the right of the slice, up to this lane: inclusive
-				// prefix-min over the lanes >= phi (the lane's own key included)
-				uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
-				pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
-				pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
-				pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
-				pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
-				pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
-				pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
-				uint32_t runmin = lane >= phi ? pm : mine;
-				uint32_t bits = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
-#pragma unroll
-				for (int pp = 15; pp >= 0; --pp)
-				{
-					uint32_t const p = plo + (uint32_t) pp;
-					uint32_t const x = readlane_u32(mine, (int) p);
-					bool const in = lane > p;
-					bits |= (in && x <= runmin) ? (1u << pp) : 0u;
-					runmin = in ? min(runmin, x) : runmin;
-				}
-				if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
-			}
+				dp_mask_slice(D, R, blkA + (wave >> 2), wave & 3u);
 			else if (wave == 8 && (blkA + 1u) * 64u <= R.t1)
-			{
-				// block blkA is complete: push its samples (rmq.hh:66-80).  Its first minimum =
-				// lowest lane holding the minimum key.
-				uint32_t const base = blkA * 64u;
-				uint32_t const mine = D.Mr[(base + lane) & (DPW - 1u)];
-				uint32_t const new_val = wave_min_u32(mine);
-				uint32_t const new_smp = base + (uint32_t) __builtin_ctzll(__ballot(mine == new_val));
-				uint32_t const bnum = blkA + 1u;
-				if (lane < DP_LEVELS && (1u << lane) <= bnum)
-				{
-					uint32_t const j = bnum - (1u << lane);
-					uint32_t res = new_smp, resv = new_val;
-					if (lane >= 1)
-					{
-						uint32_t smp, sval;
-						if (lane < DP_HPMIN)
-						{
-							smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
-							sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
-						}
-						else
-						{
-							smp = D.MBi[slot * 64u + lane];
-							sval = D.MBv[slot * 64u + lane];
-						}
-						if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
-					}
-					D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
-					D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
-				}
-			}
+				dp_push_samples(D, blkA, r % DP_MBSLOTS);
 		}
 		DP_STAMP(ts3);
 		dp_barrier();
@@ -1234,35 +1358,18 @@ __global__ __launch_bounds__(1024) void k_dp(
 #endif
 	}
 #ifdef FSEQ_DP_STAMPS
-	if (lane == 0 && (wave == 0 || wave == DP_LOADER || wave == DP_WRITER || wave == 13))
+	if (lane == 0)
 	{
-		unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 8) + (wave == 0 ? 0 : wave == 13 ? 5 : wave == DP_LOADER ? 10 : 15);
-		for (int q = 0; q < 5; ++q) o[q] = acc[q];
+		unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 8) + wave * 3u;
+		o[0] = acc[0]; o[1] = acc[1] + acc[2] + acc[3]; o[2] = acc[4];
 	}
 #endif
 
-	// the writer flushes the last regular round and the final cell
+	// the writer flushes what is still only in LDS
 	if (wave == DP_WRITER)
 	{
-		for (uint32_t r = (nrounds >= 2 ? nrounds - 2u : 0u); r < nrounds; ++r)
-		{
-			DpRound const P = dp_round(r, L, n, RL, nrounds);
-			if (lane < P.len)
-			{
-				uint32_t const t = P.t0 + lane;
-				A.M[t] = D.Mr[t & (DPW - 1u)];
-				A.LB[t] = D.LBr[t & (DP_STG - 1u)];
-				A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
-				if (!P.final_round) A.K[t] = D.Kr[t & (DPW - 1u)];
-			}
-			uint32_t const bnum = (P.t0 >> 6) + 1u;
-			if (!P.final_round && bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
-			{
-				uint32_t const j = bnum - (1u << lane);
-				A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
-				A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
-			}
-		}
+		uint32_t const lag = S.pipe ? 2u : 1u;
+		for (uint32_t r = (nrounds >= lag ? nrounds - lag : 0u); r < nrounds; ++r) flush_round(r);
 	}
 }
 
