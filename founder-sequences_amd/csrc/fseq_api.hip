@@ -325,6 +325,49 @@ void free_work(fseq_ctx *c)
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = 0;
 }
 
+// Device-side input path (row N2): rows go up as they are (one copy per row), the alphabet scan
+// (consecutive_alphabet_as_builder, generate_context.cc:135-147: dense codes in ascending byte order,
+// Appendix B A2) and the row-major -> column-major transpose run on the GPU.
+int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
+{
+	fseq_params const &p = c->p;
+	size_t const total = (size_t) p.m * p.n;
+	uint8_t *d_raw = nullptr;
+	uint32_t *d_present = nullptr;
+	int rc;
+	if ((rc = dev_alloc(c, &d_raw, total + 16))) return rc;
+	if ((rc = dev_alloc(c, &d_present, 8))) { dev_free(&d_raw); return rc; }
+	auto cleanup = [&]() { dev_free(&d_raw); dev_free(&d_present); };
+	for (uint32_t r = 0; r < p.m; ++r)
+	{
+		hipError_t const e = hipMemcpyAsync(d_raw + (size_t) r * p.n, rows[r], p.n, hipMemcpyHostToDevice, c->stream);
+		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "row upload", e); }
+	}
+	(void) hipMemsetAsync(d_present, 0, 32, c->stream);
+	hipLaunchKernelGGL(k_presence, dim3(1024), dim3(256), 0, c->stream, d_raw, total, d_present);
+	uint32_t present[8];
+	hipError_t e = hipMemcpyAsync(present, d_present, 32, hipMemcpyDeviceToHost, c->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "alphabet scan", e); }
+	CodeTable tab;
+	memset(&tab, 0, sizeof(tab));
+	uint32_t sigma = 0;
+	for (int b = 0; b < 256; ++b)
+		if ((present[b >> 5] >> (b & 31)) & 1u) { tab.code_of[b] = (uint8_t) sigma; c->code_to_byte[sigma] = (uint8_t) b; ++sigma; }
+	c->sigma = sigma;
+	if ((rc = alloc_msa(c))) { cleanup(); return rc; }
+	dim3 const grid((uint32_t) ((p.n + 63) / 64), (uint32_t) ((c->ld + 63) / 64));
+	hipLaunchKernelGGL(k_encode_transpose, grid, dim3(256), 0, c->stream, d_raw, tab, p.m, p.n, c->d_msa, c->ld);
+	e = hipGetLastError();
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	cleanup();
+	if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "encode + transpose", e);
+	c->have_input = true;
+	c->have_result = false;
+	c->kernels_ready = false;
+	return FSEQ_OK;
+}
+
 int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t cs)
 {
 	fseq_params const &p = c->p;
@@ -718,22 +761,23 @@ int fseq_set_matrix(fseq_ctx *c, uint8_t const *base, size_t row_stride, size_t 
 {
 	if (!c || !base) return FSEQ_E_ARG;
 	(void) hipSetDevice(c->p.device);
-	return set_alphabet_and_upload(c, base, row_stride, col_stride);
+	if (1 == col_stride)
+	{
+		// row-major view: the same device path as fseq_set_rows
+		std::vector<uint8_t const *> rows(c->p.m);
+		for (uint32_t r = 0; r < c->p.m; ++r) rows[r] = base + (size_t) r * row_stride;
+		return upload_rows_device(c, rows.data());
+	}
+	return set_alphabet_and_upload(c, base, row_stride, col_stride);     // any other layout: host encode + transpose
 }
 
 int fseq_set_rows(fseq_ctx *c, uint8_t const *const *rows)
 {
 	if (!c || !rows) return FSEQ_E_ARG;
 	(void) hipSetDevice(c->p.device);
-	// gather into one row-major staging buffer view by view (rows need not be contiguous)
-	fseq_params const &p = c->p;
-	std::vector<uint8_t> tmp((size_t) p.m * p.n);
-	for (uint32_t r = 0; r < p.m; ++r)
-	{
+	for (uint32_t r = 0; r < c->p.m; ++r)
 		if (!rows[r]) return fail(c, FSEQ_E_ARG, "null row pointer");
-		memcpy(tmp.data() + (size_t) r * p.n, rows[r], p.n);
-	}
-	return set_alphabet_and_upload(c, tmp.data(), p.n, 1);
+	return upload_rows_device(c, rows);
 }
 
 int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_t sigma)

@@ -100,6 +100,74 @@ __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Input side: raw sequence bytes -> dense codes, row-major -> column-major.
+// consecutive_alphabet_as_builder (generate_context.cc:135-147): which byte values occur ...
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ raw, size_t total, uint32_t *__restrict__ present /* 8 words */)
+{
+	__shared__ uint32_t bm[8];
+	if (threadIdx.x < 8) bm[threadIdx.x] = 0;
+	__syncthreads();
+	uint32_t loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+	size_t const stride = (size_t) gridDim.x * blockDim.x * 16;
+	for (size_t i = ((size_t) blockIdx.x * blockDim.x + threadIdx.x) * 16; i < total; i += stride)
+	{
+		if (i + 16 <= total)
+		{
+			uint4 const v = *reinterpret_cast<uint4 const *>(raw + i);
+			uint32_t const w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int q = 0; q < 4; ++q)
+#pragma unroll
+				for (int b = 0; b < 4; ++b)
+				{
+					uint32_t const c = (w[q] >> (8 * b)) & 255u;
+#pragma unroll
+					for (int k = 0; k < 8; ++k) loc[k] |= ((c >> 5) == (uint32_t) k) ? (1u << (c & 31u)) : 0u;
+				}
+		}
+		else
+			for (size_t j = i; j < total; ++j)
+			{
+				uint32_t const c = raw[j];
+#pragma unroll
+				for (int k = 0; k < 8; ++k) loc[k] |= ((c >> 5) == (uint32_t) k) ? (1u << (c & 31u)) : 0u;
+			}
+	}
+#pragma unroll
+	for (int k = 0; k < 8; ++k)
+		if (loc[k]) atomicOr(&bm[k], loc[k]);
+	__syncthreads();
+	if (threadIdx.x < 8 && bm[threadIdx.x]) atomicOr(&present[threadIdx.x], bm[threadIdx.x]);
+}
+
+struct CodeTable { uint8_t code_of[256]; };
+
+// ... and the encode + transpose: raw[r * n + c] -> msa[c * ld + r] = code_of[byte]; 64 x 64 tiles through LDS,
+// reads coalesced along a row, writes coalesced down a column.
+__global__ __launch_bounds__(256) void k_encode_transpose(
+	uint8_t const *__restrict__ raw, CodeTable const tab, uint32_t m, uint64_t n, uint8_t *__restrict__ msa, size_t ld)
+{
+	__shared__ uint8_t tile[64][65];
+	uint64_t const c0 = (uint64_t) blockIdx.x * 64;
+	uint32_t const r0 = blockIdx.y * 64;
+	uint32_t const tx = threadIdx.x & 63u, ty = threadIdx.x >> 6;
+	for (uint32_t rr = ty; rr < 64; rr += 4)
+	{
+		uint32_t const r = r0 + rr;
+		uint64_t const c = c0 + tx;
+		tile[rr][tx] = (r < m && c < n) ? tab.code_of[raw[(size_t) r * n + c]] : (uint8_t) 0;
+	}
+	__syncthreads();
+	for (uint32_t cc = ty; cc < 64; cc += 4)
+	{
+		uint64_t const c = c0 + cc;
+		uint32_t const r = r0 + tx;
+		if (c < n && r < ld) msa[c * ld + r] = (r < m) ? tile[tx][cc] : (uint8_t) 0;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
 // Shared pieces of the column kernels
 // ------------------------------------------------------------------------------------------------
 // PK ("packed") kernels keep row ids -- and, where the values allow it, divergences -- as 16-bit

@@ -172,6 +172,19 @@ def test_device_generator_matches_host_generator(pkg):
         assert np.array_equal(ctx.get_sequences(10, 50), host[:, 10:50])
 
 
+@pytest.mark.parametrize("m,n", [(1, 1), (7, 130), (65, 64), (100, 1000), (257, 333)])
+def test_device_input_path_roundtrip(pkg, m, n):
+    """Row-major input: alphabet scan + encode + transpose on the device; reading the alignment
+    back must give the same bytes, for any byte alphabet and sizes off the 64 x 64 tile grid."""
+    rng = np.random.default_rng(m * 1000 + n)
+    msa = rng.choice(np.array([0, 1, 45, 65, 67, 71, 84, 200, 255], dtype=np.uint8), size=(m, n))
+    ctx = pkg.SegmentationContext(m, n, max(1, n // 4))
+    ctx.set_sequences(np.ascontiguousarray(msa))          # C order -> device path
+    assert np.array_equal(ctx.get_sequences(), msa)
+    ctx.set_sequences(np.asfortranarray(msa))             # F order -> host path
+    assert np.array_equal(ctx.get_sequences(), msa)
+
+
 def test_row_major_and_column_major_inputs_agree(pkg):
     msa = fso.synth_msa(fso.synth_spec(9, 4, 80, 5e-3), 33, 700)
     c1 = run_gpu(pkg, np.asfortranarray(msa), 12)
