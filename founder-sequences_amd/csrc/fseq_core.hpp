@@ -304,14 +304,13 @@ __device__ __forceinline__ void partition_step(
 				for (int x = 0; x < SIGMA; ++x) W.val[x] = scr.val[lane][x];
 				W.has = scr.has[lane];
 			}
-#pragma unroll
-			for (int delta = 1; delta < NW; delta <<= 1)
-			{
-				Summary<SIGMA> const L = W.shifted_up(delta);
-				if (lane >= (uint32_t) delta) W.prepend(L);
-			}
-			TOT = W.from_lane(NW - 1);
-			Summary<SIGMA> P = W.from_lane(wave == 0 ? 0 : (int) wave - 1);
+			// NW <= 16: the totals sit in lanes 0..NW-1 of DPP row 0; lanes >= NW hold the identity
+			W.prepend(W.template dpp_shifted<DPP_ROW_SHR1, 0xF>());
+			if (NW > 2) W.prepend(W.template dpp_shifted<DPP_ROW_SHR2, 0xF>());
+			if (NW > 4) W.prepend(W.template dpp_shifted<DPP_ROW_SHR4, 0xF>());
+			if (NW > 8) W.prepend(W.template dpp_shifted<DPP_ROW_SHR8, 0xF>());
+			TOT = W.from_lane_uniform(NW - 1);
+			Summary<SIGMA> P = W.from_lane_uniform(wave == 0 ? 0 : (int) __builtin_amdgcn_readfirstlane(wave) - 1);
 			if (wave == 0) P.clear();
 			C.prepend(P);
 		}

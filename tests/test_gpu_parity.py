@@ -102,6 +102,22 @@ def test_wide_and_odd_alphabets(pkg, sigma, m, n, L):
     compare_long(pkg, msa, L, block_len=48)
 
 
+@pytest.mark.parametrize("m", [2, 63, 64, 65, 448, 449, 1280, 1281, 2560, 2561, 3584, 3585, 7168, 7169])
+def test_kernel_configuration_boundaries(pkg, m):
+    """Row counts on both sides of every <T,E> capacity (64, 448, 1280, 2560, 3584, 7168 | packed)."""
+    n, L = 160, 8
+    msa = fso.synth_msa(fso.synth_spec(1000 + m, 7, 40, 4e-3), m, n)
+    compare_long(pkg, msa, L, check_dp=True, block_len=33)
+
+
+def test_unsupported_shape_fails_loudly(pkg):
+    ctx = pkg.SegmentationContext(20000, 64, 8)          # more rows than any LDS-resident configuration
+    ctx.generate_synthetic(1, 4, 16, 1e-3, 0)
+    with pytest.raises(pkg.FseqError) as e:
+        ctx.run()
+    assert e.value.code == pkg.FSEQ_E_UNSUPPORTED
+
+
 def test_block_states_and_lists_match_oracle(pkg):
     m, n, L, B = 200, 1200, 15, 100
     msa = fso.synth_msa(fso.synth_spec(31, 6, 150, 3e-3), m, n)
