@@ -36,6 +36,8 @@ WORKLOADS = {
     "C2": dict(m=2500, n=100000, L=50, K=16, B=2000, mu=1e-4, seed=0x5EED0002, kind=0),
     "C3": dict(m=2504, n=1000000, L=100, K=24, B=5000, mu=1e-4, seed=0x5EED0003, kind=0),
     "C5": dict(m=10000, n=1000000, L=100, K=32, B=5000, mu=1e-4, seed=0x5EED0005, kind=1),
+    # BASELINE C4's rows (m = 100,000: HBM-streamed block state) on a column prefix that fits one GPU at 1 B/cell
+    "C4cols50k": dict(m=100000, n=50000, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0),
 }
 
 

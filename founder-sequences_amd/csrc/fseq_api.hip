@@ -7,6 +7,7 @@
 // unavailable the call fails with an error code.
 #include "../../include/fseq.h"
 #include "fseq_kernels.hpp"
+#include "fseq_stream.hpp"
 #include "fseq_join.hpp"
 
 #include <algorithm>
@@ -142,6 +143,9 @@ struct fseq_ctx {
 	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
 	KernelSet ks{};
 	bool kernels_ready = false;
+	bool use_stream = false;             // m too large for an LDS-resident order: HBM-streamed kernels (fseq_stream.hpp)
+	uint32_t *d_ws = nullptr;            // their per-block workspaces
+	size_t ws_words = 0;
 	size_t lds_columns = 0;
 
 	// device work buffers
@@ -262,12 +266,26 @@ int prepare_geometry(fseq_ctx *c)
 		while ((1u << bits) < c->sigma) ++bits;
 		c->npass = (bits + 1) / 2;               // 2-bit digit passes per column
 	}
-	if (!select_kernels(p.m, c->sigma, &c->ks))
-		return fail(c, FSEQ_E_UNSUPPORTED, "no LDS-resident kernel configuration for this m / alphabet size (m <= 11264 in this build)");
-	c->lds_columns = c->ks.columns_lds(c->B);
-	if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
-		return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
-	HIP_TRY(c, c->ks.prepare(c->lds_columns));
+	if (c->sigma > 256) return fail(c, FSEQ_E_UNSUPPORTED, "alphabet larger than 256 symbols");
+	c->use_stream = !select_kernels(p.m, c->sigma, &c->ks);
+	if (c->use_stream)
+	{
+		// rows beyond the LDS-resident configurations: the order streams through HBM / L2
+		if (p.m > STREAM_MAX_M)
+			return fail(c, FSEQ_E_UNSUPPORTED, "more rows than this build handles (m <= 147456: one column must fit LDS)");
+		size_t const lds = stream_lds_bytes(p.m);
+		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK>, lds));
+		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
+		HIP_TRY(c, allow_lds(k_columns_stream, lds));
+		HIP_TRY(c, allow_lds(k_chain_stream, carve_bytes(1, sizeof(StreamLds))));
+	}
+	else
+	{
+		c->lds_columns = c->ks.columns_lds(c->B);
+		if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
+			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
+		HIP_TRY(c, c->ks.prepare(c->lds_columns));
+	}
 	HIP_TRY(c, allow_lds(k_dp, dp_lds_bytes()));
 	c->kernels_ready = true;
 	return FSEQ_OK;
@@ -304,6 +322,12 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if ((rc = dev_alloc(c, &c->dp.Tbv, (size_t) 32 * c->dp.tstride))) return rc;
 		}
 	}
+	if (c->use_stream && !c->d_ws)
+	{
+		size_t const per_block = std::max<size_t>(columns_stream_ws_words(p.m, c->B), (size_t) 4 * m);
+		c->ws_words = per_block * std::max<size_t>(c->nblocks, 1);
+		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) return rc;
+	}
 	if (!c->d_ent || c->X != X)
 	{
 		c->X = X;
@@ -321,7 +345,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
-	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d);
+	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = 0;
 }
 
@@ -426,6 +450,30 @@ void follow_traceback(fseq_ctx *c)
 	std::reverse(c->traceback.begin(), c->traceback.end());
 }
 
+// ---- launches: LDS-resident kernels, or their HBM-streamed counterparts for large m
+void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys)
+{
+	fseq_params const &p = c->p;
+	if (c->use_stream)
+		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(p.m), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
+		                   c->npass, c->d_ws, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
+		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr);
+	else
+		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, rank, keyd, nkeys);
+}
+
+void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t nb_total, uint32_t G,
+                  uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d, uint32_t *out_a, uint32_t *out_d,
+                  uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
+{
+	if (c->use_stream)
+		hipLaunchKernelGGL(k_chain_stream, dim3(grid), dim3(ST), carve_bytes(1, sizeof(StreamLds)), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
+		                   cols_per_block, c->d_ws, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
+	else
+		c->ks.chain(c->stream, grid, c->ks.lds_chain, rank, keyd, nkeys, c->p.m, nb_total, G, cols_per_block, start_a, start_d, out_a, out_d,
+		            out_rank, out_keyd, out_nkeys);
+}
+
 int run_long_path(fseq_ctx *c, fseq_result *res)
 {
 	fseq_params const &p = c->p;
@@ -447,23 +495,23 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 
 	// ---- phase A + B (independent of X)
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
-	ks.rank(st, c->nblocks, ks.lds_colblock, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_rank, c->d_keyd, c->d_nkeys);
+	launch_rank(c, c->nblocks, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	{
 		// phase B, two-level: compose groups of G blocks into super-blocks (parallel), chain the
 		// super-blocks (one workgroup), expand every super-block to its block boundaries (parallel)
 		uint32_t const G = c->chain_G, NSB = c->n_super;
 		if (NSB <= 1)
-			ks.chain(st, 1, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, c->nblocks, c->B, nullptr, nullptr,
-			         c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
+			launch_chain(c, 1, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, c->nblocks, c->B, nullptr, nullptr,
+			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
 		else
 		{
-			ks.chain(st, NSB, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, G, c->B, nullptr, nullptr,
-			         nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys);
-			ks.chain(st, 1, ks.lds_chain, c->d_srank, c->d_skeyd, c->d_snkeys, m, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
-			         c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
-			ks.chain(st, NSB, ks.lds_chain, c->d_rank, c->d_keyd, c->d_nkeys, m, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
-			         c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
+			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, nullptr, nullptr,
+			             nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys);
+			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
+			             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
+			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
+			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
 		}
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
@@ -479,7 +527,11 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		// ---- phase C + D
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass);
+		if (c->use_stream)
+			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->d_ws,
+			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr);
+		else
+			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass);
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
 		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
@@ -623,8 +675,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
-		ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
-		        c->d_snap_a, c->d_snap_d);
+		if (c->use_stream)
+			hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) grp.size()), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B,
+			                   c->nblocks, c->npass, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
+			                   c->d_cols, c->d_grp, c->d_snap_a, c->d_snap_d);
+		else
+			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
+			        c->d_snap_a, c->d_snap_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));
@@ -669,7 +726,12 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
 	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
 	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
-	c->ks.rank(st, 1, c->ks.lds_colblock, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, 1, c->npass, d_rank, d_keyd, d_nk);
+	if (c->use_stream && !c->d_ws)
+	{
+		c->ws_words = (size_t) 4 * m;
+		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+	}
+	launch_rank(c, 1, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
 	std::vector<uint32_t> rank(m);
 	uint32_t nk = 0;
 	hipError_t e1 = hipMemcpyAsync(rank.data(), d_rank, (size_t) m * 4, hipMemcpyDeviceToHost, st);

@@ -187,14 +187,24 @@ struct StepScratch {
 	uint32_t has[NW];
 };
 
+// Running state of a partition that is fed tile by tile (orders too long for LDS): what all the tiles
+// to the left contributed (32-bit counts: the order may hold more than 65535 rows), and the bucket
+// starts of the whole order.
+struct TileCarry {
+	uint32_t cnt[4], val[4], has, start[4];
+};
+
 // One partition step.  In: d[e], s[e] for the thread's E consecutive positions (s >= SIGMA marks an
 // unused tail position; its d must be 0).  Out: dst[e], dnew[e].  Contains exactly one
 // __syncthreads(); the caller must barrier again before the scratch is reused.
-template <int T, int E, int SIGMA>
+// TILE: the T*E positions are one tile of a longer order; *tc carries the prefix of the tiles
+// before it (and is advanced past this tile), bucket starts come from tc->start.
+template <int T, int E, int SIGMA, bool TILE = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
-	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E])
+	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr)
 {
+	static_assert(!TILE || (SIGMA == 4 && T / WAVE > 4), "tile mode: 4 buckets, second-level scan path");
 	static_assert(E <= 15, "local counts are nibble-packed");
 	static_assert(SIGMA == 4 || SIGMA == 16, "sigma instantiations");
 	constexpr int NW = T / WAVE;
@@ -318,6 +328,25 @@ __device__ __forceinline__ void partition_step(
 
 	// ---- bucket bases and resolution of the pending (first-in-thread) rows
 	uint32_t base[SIGMA];
+	if (TILE)
+	{
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			base[x] = tc->start[x & 3] + tc->cnt[x & 3] + C.count(x);
+			// prefix seen by this thread = (tiles to the left) (+) (threads to the left in this tile)
+			C.val[x] = ((C.has >> x) & 1u) ? C.val[x] : max(tc->val[x & 3], C.val[x]);
+		}
+		C.has |= tc->has;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			tc->cnt[x & 3] += TOT.count(x);
+			tc->val[x & 3] = ((TOT.has >> x) & 1u) ? TOT.val[x] : max(tc->val[x & 3], TOT.val[x]);
+		}
+		tc->has |= TOT.has;
+	}
+	else
 	{
 		uint32_t acc = 0;
 #pragma unroll

@@ -1,0 +1,429 @@
+// fseq_stream.hpp -- the column kernels for orders that do not fit LDS (m > 11,264 rows; BASELINE
+// config C4 has m = 100,000).  Same algorithm and the same partition_step as fseq_kernels.hpp, but
+// the order (a, d) of a block lives in a per-block HBM/L2 workspace (two buffers, ping-pong) and a
+// partition pass streams it through the workgroup tile by tile (T*E = 8192 rows) with a running
+// TileCarry.  A pass = one counting sweep (bucket starts) + one partition sweep: 2 reads of a, one of
+// d, one write of each -- this is the regime where SURVEY.md's 17 B/cell is real HBM traffic.
+// Only the current column (m bytes) is staged in LDS.
+#pragma once
+
+#include "fseq_kernels.hpp"
+
+namespace fseq {
+
+constexpr int ST = 1024, SE = 8;
+constexpr uint32_t SCAP = ST * SE;
+constexpr uint32_t STREAM_MAX_M = 147456;          // column staging: m bytes of LDS
+
+struct StreamLds {
+	StepScratch<ST, 4> scr;
+	uint32_t red[4 * (ST / WAVE) + 8];
+};
+
+__host__ __device__ inline size_t stream_lds_bytes(uint32_t m)
+{
+	return carve_bytes((size_t) m + 16, 1) + carve_bytes(1, sizeof(StreamLds));
+}
+
+struct DigitColumn {
+	uint8_t const *sym; uint32_t shift;
+	__device__ __forceinline__ uint32_t operator()(uint32_t a) const { return ((uint32_t) sym[a] >> shift) & 3u; }
+};
+struct DigitRank {
+	uint32_t const *rank; uint32_t shift;
+	__device__ __forceinline__ uint32_t operator()(uint32_t a) const { return (rank[a] >> shift) & 3u; }
+};
+struct DigitKey {
+	uint32_t shift;
+	__device__ __forceinline__ uint32_t operator()(uint32_t a) const { return (a >> shift) & 3u; }
+};
+struct NoHook {
+	__device__ __forceinline__ void operator()(uint32_t, uint32_t) const {}
+};
+
+// block-wide sum of four counters; every thread gets the totals
+__device__ __forceinline__ void block_sum4(uint32_t (&c)[4], uint32_t *red)
+{
+	uint32_t const lane = lane_id(), wave = wave_id();
+#pragma unroll
+	for (int x = 0; x < 4; ++x) c[x] = readlane_u32(wave_incl_add(c[x]), 63);
+	__syncthreads();
+	if (lane == 0)
+#pragma unroll
+		for (int x = 0; x < 4; ++x) red[wave * 4 + x] = c[x];
+	__syncthreads();
+#pragma unroll
+	for (int x = 0; x < 4; ++x) c[x] = 0;
+	for (int w = 0; w < ST / WAVE; ++w)
+#pragma unroll
+		for (int x = 0; x < 4; ++x) c[x] += red[w * 4 + x];
+}
+
+// One stable 4-bucket partition pass over an order of m rows held in global memory:
+// (a_src, d_src) -> (a_dst, d_dst).  KEYS: sort keys only (no divergences).  Ends with a barrier.
+template <bool KEYS, typename DF, typename HOOK>
+__device__ __forceinline__ void stream_pass(
+	uint32_t m, uint32_t const *a_src, uint32_t const *d_src, uint32_t *a_dst, uint32_t *d_dst,
+	uint32_t first_val, DF const digit, HOOK const hook, StreamLds &L)
+{
+	uint32_t const tid = threadIdx.x;
+	// ---- sweep 1: bucket sizes
+	uint32_t cnt[4] = {0, 0, 0, 0};
+	for (uint32_t base = 0; base < m; base += SCAP)
+	{
+#pragma unroll
+		for (int e = 0; e < SE; ++e)
+		{
+			uint32_t const pos = base + tid * SE + e;
+			if (pos < m)
+			{
+				uint32_t const g = digit(a_src[pos]);
+#pragma unroll
+				for (int x = 0; x < 4; ++x) cnt[x] += (g == (uint32_t) x) ? 1u : 0u;
+			}
+		}
+	}
+	block_sum4(cnt, L.red);
+	TileCarry tc;
+	{
+		uint32_t acc = 0;
+#pragma unroll
+		for (int x = 0; x < 4; ++x) { tc.cnt[x] = 0; tc.val[x] = 0; tc.start[x] = acc; acc += cnt[x]; }
+		tc.has = 0;
+	}
+	// ---- sweep 2: the partition, tile by tile
+	for (uint32_t base = 0; base < m; base += SCAP)
+	{
+		uint32_t a[SE], d[SE], s[SE], dst[SE], dnew[SE];
+#pragma unroll
+		for (int e = 0; e < SE; ++e)
+		{
+			uint32_t const pos = base + tid * SE + e;
+			bool const in = pos < m;
+			a[e] = in ? a_src[pos] : 0u;
+			d[e] = (in && !KEYS) ? d_src[pos] : 0u;
+			s[e] = in ? digit(a[e]) : 4u;
+		}
+		partition_step<ST, SE, 4, true>(d, s, first_val, L.scr, dst, dnew, &tc);
+#pragma unroll
+		for (int e = 0; e < SE; ++e)
+		{
+			if (base + tid * SE + e < m)
+			{
+				a_dst[dst[e]] = a[e];
+				if (!KEYS) { d_dst[dst[e]] = dnew[e]; hook(d[e], dnew[e]); }
+			}
+		}
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ void stage_column(uint8_t *sym, uint8_t const *col, uint32_t m)
+{
+	for (uint32_t i = threadIdx.x * 16u; i < m; i += ST * 16u)
+		*reinterpret_cast<uint4 *>(sym + i) = *reinterpret_cast<uint4 const *>(col + i);
+}
+
+// rank / keyd / nkeys of the order in (a, d): a row starts a new key iff d > dlow (position 0 always).
+__device__ __forceinline__ void stream_emit_ranks(
+	uint32_t m, uint32_t const *a, uint32_t const *d, uint32_t dlow, uint32_t *rank_out, uint32_t *keyd_out, uint32_t *nkeys_out,
+	StreamLds &L)
+{
+	uint32_t const tid = threadIdx.x;
+	uint32_t running = 0;
+	for (uint32_t base = 0; base < m; base += SCAP)
+	{
+		uint32_t av[SE], dv[SE], nf = 0;
+#pragma unroll
+		for (int e = 0; e < SE; ++e)
+		{
+			uint32_t const pos = base + tid * SE + e;
+			av[e] = pos < m ? a[pos] : 0u;
+			dv[e] = pos < m ? d[pos] : 0u;
+			nf += (pos < m && (pos == 0 || dv[e] > dlow)) ? 1u : 0u;
+		}
+		uint32_t total;
+		uint32_t r = running + block_excl_add<ST>(nf, L.red, &total);
+#pragma unroll
+		for (int e = 0; e < SE; ++e)
+		{
+			uint32_t const pos = base + tid * SE + e;
+			if (pos < m)
+			{
+				bool const first = (pos == 0 || dv[e] > dlow);
+				r += first ? 1u : 0u;
+				rank_out[av[e]] = r - 1u;
+				if (first) keyd_out[r - 1u] = dv[e];
+			}
+		}
+		running += total;
+		__syncthreads();
+	}
+	if (tid == 0) *nkeys_out = running;
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase A (MODE_RANK) and pass 2 (MODE_SNAP), streamed.  ws: [gridDim.x][4][m] words (a0, d0, a1, d1).
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(ST) void k_colblock_stream(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t *ws,
+	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
+	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
+	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
+	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	uint8_t *sym = cv.take<uint8_t>((size_t) m + 16);
+	StreamLds &L = *cv.take<StreamLds>(1);
+	uint32_t const tid = threadIdx.x;
+	uint32_t *buf[2][2];
+	{
+		uint32_t *w = ws + (size_t) blockIdx.x * 4u * m;
+		buf[0][0] = w; buf[0][1] = w + m; buf[1][0] = w + 2u * (size_t) m; buf[1][1] = w + 3u * (size_t) m;
+	}
+	uint64_t k0, kend;
+	uint32_t t_first = 0, t_count = 0, t_next = 0;
+	if (MODE == MODE_RANK)
+	{
+		k0 = (uint64_t) blockIdx.x * B;
+		kend = (k0 + B < n) ? k0 + B : n;
+		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = i; buf[0][1][i] = (uint32_t) k0; }
+	}
+	else
+	{
+		uint2 const grp = task_grp[blockIdx.x];
+		t_first = grp.x; t_count = grp.y;
+		uint64_t blk = task_rb[t_first] / B;
+		if (blk > nblocks) blk = nblocks;
+		k0 = blk * B;
+		kend = task_rb[t_first + t_count - 1u];
+		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = bstate_a[blk * (size_t) m + i]; buf[0][1][i] = bstate_d[blk * (size_t) m + i]; }
+	}
+	__syncthreads();
+	uint32_t cur = 0;
+	auto snapshot_if_requested = [&](uint64_t k) {
+		if (MODE == MODE_SNAP && t_next < t_count && task_rb[t_first + t_next] == k)
+		{
+			size_t const ob = (size_t) (t_first + t_next) * m;
+			for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = buf[cur][0][i]; snap_d[ob + i] = buf[cur][1][i]; }
+			++t_next;
+		}
+	};
+	snapshot_if_requested(k0);
+	for (uint64_t k = k0; k < kend; ++k)
+	{
+		stage_column(sym, msa + k * ld, m);
+		__syncthreads();
+		for (uint32_t pass = 0; pass < npass; ++pass)
+		{
+			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], (uint32_t) (k + 1),
+			                   DigitColumn{sym, 2u * pass}, NoHook{}, L);
+			cur ^= 1u;
+		}
+		snapshot_if_requested(k + 1);
+	}
+	if (MODE == MODE_RANK)
+		stream_emit_ranks(m, buf[cur][0], buf[cur][1], (uint32_t) k0, rank + (size_t) blockIdx.x * m, keyd + (size_t) blockIdx.x * m,
+		                  nkeys + blockIdx.x, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase B, streamed (same contract as k_chain).  ws: [gridDim.x][4][m] words.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ST) void k_chain_stream(
+	uint32_t const *__restrict__ rank, uint32_t const *__restrict__ keyd, uint32_t const *__restrict__ nkeys,
+	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t *ws,
+	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
+	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	StreamLds &L = *cv.take<StreamLds>(1);
+	uint32_t const tid = threadIdx.x;
+	uint32_t *buf[2][2];
+	{
+		uint32_t *w = ws + (size_t) blockIdx.x * 4u * m;
+		buf[0][0] = w; buf[0][1] = w + m; buf[1][0] = w + 2u * (size_t) m; buf[1][1] = w + 3u * (size_t) m;
+	}
+	uint32_t const b0 = blockIdx.x * G;
+	uint32_t const b1 = min(nb_total, b0 + G);
+	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * cols_per_block);
+	for (uint32_t i = tid; i < m; i += ST)
+	{
+		buf[0][0][i] = start_a ? start_a[(size_t) blockIdx.x * m + i] : i;
+		buf[0][1][i] = start_d ? start_d[(size_t) blockIdx.x * m + i] : kstart;
+	}
+	__syncthreads();
+	uint32_t cur = 0;
+	for (uint32_t b = b0; b < b1; ++b)
+	{
+		uint32_t const *rk = rank + (size_t) b * m, *kd = keyd + (size_t) b * m;
+		if (out_state_a)
+			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = buf[cur][0][i]; out_state_d[(size_t) b * m + i] = buf[cur][1][i]; }
+		uint32_t const nd = rank_digits(nkeys[b]);
+		for (uint32_t p = 0; p < nd; ++p)
+		{
+			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], 0u, DigitRank{rk, 2u * p}, NoHook{}, L);
+			cur ^= 1u;
+		}
+		// rows that start a new block key take the in-block divergence of that key
+		for (uint32_t pos = tid; pos < m; pos += ST)
+		{
+			uint32_t const r = rk[buf[cur][0][pos]];
+			uint32_t const rprev = pos ? rk[buf[cur][0][pos - 1u]] : PAD_KEY;
+			if (r != rprev) buf[cur][1][pos] = kd[r];
+		}
+		__syncthreads();
+	}
+	if (out_state_a && b1 == nb_total)
+		for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) nb_total * m + i] = buf[cur][0][i]; out_state_d[(size_t) nb_total * m + i] = buf[cur][1][i]; }
+	if (out_rank)
+		stream_emit_ranks(m, buf[cur][0], buf[cur][1], kstart, out_rank + (size_t) blockIdx.x * m, out_keyd + (size_t) blockIdx.x * m,
+		                  out_nkeys + blockIdx.x, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase C, streamed.  Per block workspace (words): state 4m | keys 2m | V m | Vpos m | cnt m + B.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t columns_stream_ws_words(uint32_t m, uint32_t B) { return (size_t) 9 * m + B + 16; }
+
+struct HistHook {
+	uint32_t *cnt;
+	__device__ __forceinline__ void operator()(uint32_t dold, uint32_t dnew) const
+	{
+		if (dold != dnew) { atomicSub(&cnt[dold], 1u); atomicAdd(&cnt[dnew], 1u); }
+	}
+};
+
+__global__ __launch_bounds__(ST) void k_columns_stream(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t *ws,
+	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
+	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	uint8_t *sym = cv.take<uint8_t>((size_t) m + 16);
+	StreamLds &L = *cv.take<StreamLds>(1);
+	uint32_t const tid = threadIdx.x;
+	uint32_t *w = ws + (size_t) blockIdx.x * columns_stream_ws_words(m, B);
+	uint32_t *buf[2][2] = {{w, w + m}, {w + 2u * (size_t) m, w + 3u * (size_t) m}};
+	uint32_t *keys[2] = {w + 4u * (size_t) m, w + 5u * (size_t) m};
+	uint32_t *V = w + 6u * (size_t) m, *Vpos = w + 7u * (size_t) m, *cnt = w + 8u * (size_t) m;
+
+	uint64_t const k0 = (uint64_t) blockIdx.x * B;
+	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
+	uint32_t const nb = (uint32_t) (kend - k0);
+	uint32_t const *sa = bstate_a + (size_t) blockIdx.x * m, *sd = bstate_d + (size_t) blockIdx.x * m;
+
+	// ---- prologue: sort the boundary divergences (2-bit LSD passes), distinct values -> V, counts, ids
+	for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = sa[i]; keys[0][i] = sd[i]; }
+	__syncthreads();
+	uint32_t kc = 0;
+	{
+		uint32_t bits = 1;
+		while (bits < 32u && (k0 >> bits) != 0) ++bits;          // divergences at the boundary are <= k0
+		for (uint32_t sh = 0; sh < bits; sh += 2)
+		{
+			stream_pass<true>(m, keys[kc], nullptr, keys[kc ^ 1u], nullptr, 0u, DigitKey{sh}, NoHook{}, L);
+			kc ^= 1u;
+		}
+	}
+	uint32_t D0 = 0;
+	{
+		uint32_t const *sk = keys[kc];
+		for (uint32_t base = 0; base < m; base += SCAP)
+		{
+			uint32_t kv[SE], nf = 0;
+#pragma unroll
+			for (int e = 0; e < SE; ++e)
+			{
+				uint32_t const pos = base + tid * SE + e;
+				kv[e] = pos < m ? sk[pos] : 0u;
+				nf += (pos < m && (pos == 0 || kv[e] != sk[pos - 1u])) ? 1u : 0u;
+			}
+			uint32_t total;
+			uint32_t wv = D0 + block_excl_add<ST>(nf, L.red, &total);
+#pragma unroll
+			for (int e = 0; e < SE; ++e)
+			{
+				uint32_t const pos = base + tid * SE + e;
+				if (pos < m && (pos == 0 || kv[e] != sk[pos - 1u])) { V[wv] = kv[e]; Vpos[wv] = pos; ++wv; }
+			}
+			D0 += total;
+			__syncthreads();
+		}
+	}
+	for (uint32_t i = tid; i < D0 + nb; i += ST)
+		cnt[i] = i < D0 ? ((i + 1u < D0 ? Vpos[i + 1u] : m) - Vpos[i]) : 0u;
+	for (uint32_t i = tid; i < m; i += ST)
+	{
+		uint32_t lo = 0, hi = D0;
+		uint32_t const key = sd[i];
+		while (lo < hi)
+		{
+			uint32_t const mid = (lo + hi) >> 1;
+			if (V[mid] < key) lo = mid + 1; else hi = mid;
+		}
+		buf[0][1][i] = lo;
+	}
+	__syncthreads();
+	bool const zero_present = (V[0] == 0u);
+	uint32_t cur = 0;
+
+	for (uint32_t j = 0; j < nb; ++j)
+	{
+		stage_column(sym, msa + (k0 + j) * ld, m);
+		__syncthreads();
+		for (uint32_t pass = 0; pass < npass; ++pass)
+		{
+			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, 2u * pass}, HistHook{cnt}, L);
+			cur ^= 1u;
+		}
+		// ---- emit the top of the histogram (same list format as k_columns); counters were updated
+		// with device-scope atomics, read them past L1
+		if (wave_id() == 0)
+		{
+			uint32_t const lane = lane_id();
+			uint64_t const k = k0 + j;
+			uint32_t const thr = (k + 2 > (uint64_t) Lseg) ? (uint32_t) (k + 2 - Lseg) : 0u;
+			uint2 *out = ent + k * (size_t) stride;
+			int32_t const top = (int32_t) (D0 + j);
+			uint32_t cumN = 0, nent = 1, R = 0;
+			for (int32_t base = top; base >= 0; base -= 64)
+			{
+				int32_t const i = base - (int32_t) lane;
+				uint32_t const c = (i >= 0) ? __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				uint32_t const v = (i < 0) ? 0u : (((uint32_t) i < D0) ? V[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
+				bool const nz = c > 0;
+				bool const rec = nz && v >= thr;
+				uint32_t const inc = wave_incl_add(c);
+				uint64_t const rmask = __ballot(rec);
+				uint32_t const r_inc = rmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(rmask)) : 0u;
+				uint32_t const excN = cumN + (inc - r_inc) - c;
+				bool const take = nz && !rec && excN <= X;
+				uint64_t const omask = __ballot(nz && !rec);
+				uint32_t const pos = nent + (uint32_t) __popcll(omask & ((1ull << lane) - 1ull));
+				if (take) out[pos] = make_uint2(v, c);
+				uint64_t const tmask = __ballot(take);
+				nent += (uint32_t) __popcll(tmask);
+				uint32_t const t_inc = tmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(tmask)) : r_inc;
+				cumN += t_inc - r_inc;
+				R += r_inc;
+				if (tmask != omask || cumN > X) break;
+			}
+			uint32_t const cum = R + cumN;
+			if (lane == 0)
+			{
+				uint32_t const c0 = zero_present ? __hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				out[0] = make_uint2((uint32_t) (k + 1), R);
+				hdr[k] = make_uint4(nent, c0, cum == m ? 1u : 0u, cum);
+			}
+		}
+		__syncthreads();
+	}
+}
+
+} // namespace fseq
