@@ -236,9 +236,12 @@ int alloc_msa(fseq_ctx *c)
 	return FSEQ_OK;
 }
 
-uint32_t auto_block_len(uint64_t n)
+uint32_t auto_block_len(uint64_t n, bool streamed)
 {
-	uint64_t b = (n + 1023) / 1024;
+	// LDS-resident kernels: ~1024 blocks (2-4 workgroups per CU).  Streamed kernels stage a whole column
+	// in LDS (one workgroup per CU) and pay the phase-B chain per block and per row: ~256 blocks.
+	uint64_t const target = streamed ? 256 : 1024;
+	uint64_t b = (n + target - 1) / target;
 	if (b < 16) b = 16;
 	if (b > 4096) b = 4096;
 	return (uint32_t) b;
@@ -247,7 +250,7 @@ uint32_t auto_block_len(uint64_t n)
 int prepare_geometry(fseq_ctx *c)
 {
 	fseq_params const &p = c->p;
-	c->B = p.block_len ? p.block_len : auto_block_len(p.n);
+	c->B = p.block_len ? p.block_len : auto_block_len(p.n, p.m > 11264u);
 	if (c->B > p.n) c->B = (uint32_t) p.n;
 	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
 	{
