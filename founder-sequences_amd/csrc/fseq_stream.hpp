@@ -2,8 +2,9 @@
 // config C4 has m = 100,000).  Same algorithm and the same partition_step as fseq_kernels.hpp, but
 // the order (a, d) of a block lives in a per-block HBM/L2 workspace (two buffers, ping-pong) and a
 // partition pass streams it through the workgroup tile by tile (T*E = 8192 rows) with a running
-// TileCarry.  A pass = one counting sweep (bucket starts) + one partition sweep: 2 reads of a, one of
-// d, one write of each -- this is the regime where SURVEY.md's 17 B/cell is real HBM traffic.
+// TileCarry.  A column pass = the bucket sizes counted off the staged column + one partition sweep (one
+// read and one write of a and d: SURVEY.md's 17 B/cell as real HBM traffic); a rank-digit or key pass
+// has a counting sweep over the order first.
 // Only the current column (m bytes) is staged in LDS.
 #pragma once
 
@@ -59,31 +60,60 @@ __device__ __forceinline__ void block_sum4(uint32_t (&c)[4], uint32_t *red)
 		for (int x = 0; x < 4; ++x) c[x] += red[w * 4 + x];
 }
 
+// Bucket sizes of a column pass do not depend on the order: count the digit straight off the staged column.
+__device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t m, uint32_t shift, uint32_t (&cnt)[4], uint32_t *red)
+{
+#pragma unroll
+	for (int x = 0; x < 4; ++x) cnt[x] = 0;
+	for (uint32_t i = threadIdx.x * 4u; i < m; i += ST * 4u)
+	{
+		uint32_t const w = *reinterpret_cast<uint32_t const *>(sym + i);
+#pragma unroll
+		for (int b = 0; b < 4; ++b)
+		{
+			uint32_t const g = (w >> (8 * b + shift)) & 3u;
+			bool const in = i + b < m;
+#pragma unroll
+			for (int x = 0; x < 4; ++x) cnt[x] += (in && g == (uint32_t) x) ? 1u : 0u;
+		}
+	}
+	block_sum4(cnt, red);
+}
+
 // One stable 4-bucket partition pass over an order of m rows held in global memory:
-// (a_src, d_src) -> (a_dst, d_dst).  KEYS: sort keys only (no divergences).  Ends with a barrier.
+// (a_src, d_src) -> (a_dst, d_dst).  KEYS: sort keys only (no divergences).  pre_cnt: bucket sizes if the
+// caller already knows them (column passes), else a counting sweep comes first.  Ends with a barrier.
 template <bool KEYS, typename DF, typename HOOK>
 __device__ __forceinline__ void stream_pass(
 	uint32_t m, uint32_t const *a_src, uint32_t const *d_src, uint32_t *a_dst, uint32_t *d_dst,
-	uint32_t first_val, DF const digit, HOOK const hook, StreamLds &L)
+	uint32_t first_val, DF const digit, HOOK const hook, StreamLds &L, uint32_t const *pre_cnt = nullptr)
 {
 	uint32_t const tid = threadIdx.x;
-	// ---- sweep 1: bucket sizes
 	uint32_t cnt[4] = {0, 0, 0, 0};
-	for (uint32_t base = 0; base < m; base += SCAP)
+	if (pre_cnt)
 	{
 #pragma unroll
-		for (int e = 0; e < SE; ++e)
+		for (int x = 0; x < 4; ++x) cnt[x] = pre_cnt[x];
+	}
+	else
+	{
+		// ---- sweep 1: bucket sizes
+		for (uint32_t base = 0; base < m; base += SCAP)
 		{
-			uint32_t const pos = base + tid * SE + e;
-			if (pos < m)
-			{
-				uint32_t const g = digit(a_src[pos]);
 #pragma unroll
-				for (int x = 0; x < 4; ++x) cnt[x] += (g == (uint32_t) x) ? 1u : 0u;
+			for (int e = 0; e < SE; ++e)
+			{
+				uint32_t const pos = base + tid * SE + e;
+				if (pos < m)
+				{
+					uint32_t const g = digit(a_src[pos]);
+#pragma unroll
+					for (int x = 0; x < 4; ++x) cnt[x] += (g == (uint32_t) x) ? 1u : 0u;
+				}
 			}
 		}
+		block_sum4(cnt, L.red);
 	}
-	block_sum4(cnt, L.red);
 	TileCarry tc;
 	{
 		uint32_t acc = 0;
@@ -218,8 +248,10 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 		__syncthreads();
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
+			uint32_t cnt4[4];
+			column_digit_counts(sym, m, 2u * pass, cnt4, L.red);
 			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], (uint32_t) (k + 1),
-			                   DigitColumn{sym, 2u * pass}, NoHook{}, L);
+			                   DigitColumn{sym, 2u * pass}, NoHook{}, L, cnt4);
 			cur ^= 1u;
 		}
 		snapshot_if_requested(k + 1);
@@ -379,7 +411,9 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 		__syncthreads();
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
-			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, 2u * pass}, HistHook{cnt}, L);
+			uint32_t cnt4[4];
+			column_digit_counts(sym, m, 2u * pass, cnt4, L.red);
+			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, 2u * pass}, HistHook{cnt}, L, cnt4);
 			cur ^= 1u;
 		}
 		// ---- emit the top of the histogram (same list format as k_columns); counters were updated
