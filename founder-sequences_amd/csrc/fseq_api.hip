@@ -28,10 +28,12 @@ struct KernelSet {
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
 	             uint32_t *, uint32_t *, uint32_t *);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
-	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *);
+	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
+	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass);
+	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass,
+	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d);
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -53,19 +55,22 @@ struct Launch {
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd)
+	                 uint32_t nblocks, uint32_t npass, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
+	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass)
+	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass,
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass);
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass,
+		                   snap_stride, ss_a, ss_d);
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -163,6 +168,10 @@ struct fseq_ctx {
 	size_t cols_cap = 0;
 	uint2 *d_grp = nullptr;
 	size_t grp_cap = 0;
+	uint64_t *d_src = nullptr;
+	size_t src_cap = 0;
+	uint32_t snap_stride = 16;            // phase C drops the exact (a,d) every snap_stride columns for pass 2
+	uint32_t *d_ss_a = nullptr, *d_ss_d = nullptr;
 	uint2 *d_gent = nullptr;
 	uint4 *d_ghdr = nullptr;
 	size_t gather_cap = 0, gather_stride = 0;
@@ -325,6 +334,16 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if ((rc = dev_alloc(c, &c->dp.Tbv, (size_t) 32 * c->dp.tstride))) return rc;
 		}
 	}
+	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
+	{
+		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB
+		uint64_t const budget = 4ull << 30;
+		uint64_t st_ = 16;
+		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
+		c->snap_stride = (uint32_t) st_;
+		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
+	}
 	if (c->use_stream && !c->d_ws)
 	{
 		size_t const per_block = std::max<size_t>(columns_stream_ws_words(p.m, c->B), (size_t) 4 * m);
@@ -347,9 +366,9 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
-	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
+	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a); dev_free(&c->d_ss_d); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
-	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = 0;
+	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 }
 
 // Device-side input path (row N2): rows go up as they are (one copy per row), the alphabet scan
@@ -460,7 +479,8 @@ void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint3
 	if (c->use_stream)
 		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(p.m), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
 		                   c->npass, c->d_ws, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
-		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr);
+		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
+		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr);
 	else
 		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, rank, keyd, nkeys);
 }
@@ -532,9 +552,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		if (c->use_stream)
 			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->d_ws,
-			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr);
+			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		else
-			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass);
+			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass,
+			           c->snap_stride, c->d_ss_a, c->d_ss_d);
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
 		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
@@ -657,23 +678,27 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			if ((rc = dev_alloc(c, &c->d_snap_d, S2 * (size_t) m))) return rc;
 			c->snap_cap = S2;
 		}
-		// one sweep per column block that holds boundaries (boundaries ascending -> blocks ascending)
-		std::vector<uint64_t> rbs(S2);
+		// every boundary starts from the nearest exact state at or below it: a block boundary state
+		// (phase B) or one of the states phase C dropped every snap_stride columns; boundaries that share
+		// a start state share one sweep (boundaries ascending)
+		std::vector<uint64_t> rbs(S2), srcs;
 		std::vector<uint2> grp;
+		uint64_t const sstr = c->snap_stride;
+		std::vector<uint64_t> starts;
 		for (size_t i = 0; i < S2; ++i)
 		{
 			rbs[i] = c->segments[i].rb;
 			uint64_t const blk = std::min<uint64_t>(rbs[i] / c->B, c->nblocks);
-			if (grp.empty() || std::min<uint64_t>(rbs[grp.back().x] / c->B, c->nblocks) != blk)
-				grp.push_back(make_uint2((uint32_t) i, 1u));
-			else
-				++grp.back().y;
+			uint64_t const q = rbs[i] / sstr;
+			uint64_t src = blk, p0 = blk * c->B;
+			if (c->d_ss_a && q >= 1 && q * sstr > p0) { src = q | (1ull << 63); p0 = q * sstr; }
+			if (grp.empty() || srcs.back() != src) { grp.push_back(make_uint2((uint32_t) i, 1u)); srcs.push_back(src); starts.push_back(p0); }
+			else ++grp.back().y;
 		}
-		for (auto const &g : grp)
-		{
-			uint64_t const blk = std::min<uint64_t>(rbs[g.x] / c->B, c->nblocks);
-			pass2_cells += (rbs[g.x + g.y - 1] - blk * c->B) * m;
-		}
+		for (size_t g = 0; g < grp.size(); ++g)
+			pass2_cells += (rbs[grp[g].x + grp[g].y - 1] - starts[g]) * m;
+		if (c->src_cap < srcs.size()) { if ((rc = dev_alloc(c, &c->d_src, srcs.size()))) return rc; c->src_cap = srcs.size(); }
+		HIP_TRY(c, hipMemcpyAsync(c->d_src, srcs.data(), srcs.size() * 8, hipMemcpyHostToDevice, st));
 		if (c->grp_cap < grp.size()) { if ((rc = dev_alloc(c, &c->d_grp, grp.size()))) return rc; c->grp_cap = grp.size(); }
 		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
@@ -681,10 +706,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		if (c->use_stream)
 			hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) grp.size()), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B,
 			                   c->nblocks, c->npass, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
-			                   c->d_cols, c->d_grp, c->d_snap_a, c->d_snap_d);
+			                   c->d_cols, c->d_grp, c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		else
 			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
-			        c->d_snap_a, c->d_snap_d);
+			        c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));
@@ -729,6 +754,16 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
 	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
 	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
+	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
+	{
+		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB
+		uint64_t const budget = 4ull << 30;
+		uint64_t st_ = 16;
+		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
+		c->snap_stride = (uint32_t) st_;
+		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
+	}
 	if (c->use_stream && !c->d_ws)
 	{
 		c->ws_words = (size_t) 4 * m;

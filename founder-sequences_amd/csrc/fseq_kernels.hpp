@@ -181,9 +181,10 @@ __device__ __forceinline__ void read_chunk(PA const *a_l, PD const *d_l, uint32_
 }
 
 // MODE_RANK: start from the identity at column k0 = blockIdx.x * B, emit block ranks (phase A).
-// MODE_SNAP: workgroup j sweeps one column block once, from its boundary state, and emits (a,d) at
-//            every requested column task_rb[first .. first+count) inside it (task_grp[j] = {first, count},
-//            task_rb ascending) -- pass 2 costs at most one more sweep of the alignment.
+// MODE_SNAP: workgroup j starts from a stored exact state -- a block boundary state of phase B or one of the
+//            states phase C drops every snap_stride columns (task_src[j]: bit 63 = the latter) -- sweeps
+//            forward and emits (a,d) at every requested column task_rb[first .. first+count) on the way
+//            (task_grp[j] = {first, count}, task_rb ascending).
 enum { MODE_RANK = 0, MODE_SNAP = 1 };
 
 template <int T, int E, int SIGMA, int MODE, bool PK>
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(T) void k_colblock(
 	// MODE_SNAP inputs / outputs
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
-	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d)
+	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
+	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -241,12 +243,13 @@ __global__ __launch_bounds__(T) void k_colblock(
 	{
 		uint2 const grp = task_grp[blockIdx.x];
 		t_first = grp.x; t_count = grp.y;
-		uint64_t blk = task_rb[t_first] / B;
-		if (blk > nblocks) blk = nblocks;
-		k0 = blk * B;
+		uint64_t const src = task_src[blockIdx.x];
+		bool const from_stride = (src >> 63) != 0;
+		uint64_t const sidx = src & ~(1ull << 63);
+		k0 = from_stride ? sidx * snap_stride : sidx * B;
 		kend = task_rb[t_first + t_count - 1u];
-		uint32_t const *sa = bstate_a + blk * (size_t) m;
-		uint32_t const *sd = bstate_d + blk * (size_t) m;
+		uint32_t const *sa = (from_stride ? ss_a : bstate_a) + sidx * (size_t) m;
+		uint32_t const *sd = (from_stride ? ss_d : bstate_d) + sidx * (size_t) m;
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
@@ -576,7 +579,8 @@ template <int T, int E, int SIGMA, bool PK>
 __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass)
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass,
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
 {
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -717,6 +721,23 @@ __global__ __launch_bounds__(T) void k_columns(
 			if (pass + 1 == npass && more && has_chunk)
 				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
 			__syncthreads();
+		}
+
+		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
+		if (ss_a && (k0 + j + 1) % snap_stride == 0)
+		{
+			size_t const ob = (size_t) ((k0 + j + 1) / snap_stride) * m;
+#pragma unroll
+			for (int i = 0; i < E; ++i)
+			{
+				uint32_t const idx = tid + i * T;
+				if (idx < m)
+				{
+					uint32_t const vid = d_l[idx];
+					ss_a[ob + idx] = a_l[idx];
+					ss_d[ob + idx] = vid < D0 ? V_l[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
+				}
+			}
 		}
 
 		// ---- emit the top of the histogram for column k0+j (wave 0; the others run ahead into

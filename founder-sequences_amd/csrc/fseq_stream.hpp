@@ -201,7 +201,8 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
-	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d)
+	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
+	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -225,11 +226,14 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	{
 		uint2 const grp = task_grp[blockIdx.x];
 		t_first = grp.x; t_count = grp.y;
-		uint64_t blk = task_rb[t_first] / B;
-		if (blk > nblocks) blk = nblocks;
-		k0 = blk * B;
+		uint64_t const src = task_src[blockIdx.x];
+		bool const from_stride = (src >> 63) != 0;
+		uint64_t const sidx = src & ~(1ull << 63);
+		k0 = from_stride ? sidx * snap_stride : sidx * B;
 		kend = task_rb[t_first + t_count - 1u];
-		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = bstate_a[blk * (size_t) m + i]; buf[0][1][i] = bstate_d[blk * (size_t) m + i]; }
+		uint32_t const *sa = (from_stride ? ss_a : bstate_a) + sidx * (size_t) m;
+		uint32_t const *sd = (from_stride ? ss_d : bstate_d) + sidx * (size_t) m;
+		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = sa[i]; buf[0][1][i] = sd[i]; }
 	}
 	__syncthreads();
 	uint32_t cur = 0;
@@ -333,7 +337,8 @@ struct HistHook {
 __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t *ws,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr)
+	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -415,6 +420,17 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 			column_digit_counts(sym, m, 2u * pass, cnt4, L.red);
 			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, 2u * pass}, HistHook{cnt}, L, cnt4);
 			cur ^= 1u;
+		}
+		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
+		if (ss_a && (k0 + j + 1) % snap_stride == 0)
+		{
+			size_t const ob = (size_t) ((k0 + j + 1) / snap_stride) * m;
+			for (uint32_t i = tid; i < m; i += ST)
+			{
+				uint32_t const vid = buf[cur][1][i];
+				ss_a[ob + i] = buf[cur][0][i];
+				ss_d[ob + i] = vid < D0 ? V[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
+			}
 		}
 		// ---- emit the top of the histogram (same list format as k_columns); counters were updated
 		// with device-scope atomics, read them past L1
