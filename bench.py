@@ -3,7 +3,8 @@
 
 One "step" = one complete pass of the hot path (everything segmentation_lp_context does:
 pBWT pass 1 + DP, traceback, segment merge, pass-2 boundary states) over one synthetic
-founder-mosaic alignment that is already resident in HBM (column-major, 1 B/cell).
+founder-mosaic alignment that is already resident in HBM (column-major, 2 bits per cell for
+sigma <= 4, 4 bits for sigma <= 16, else 1 B).
 Workload at N=1: BASELINE.json configs[1] (C2: m=2,500 x n=100,000, sigma=4, L=50).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
@@ -36,8 +37,10 @@ WORKLOADS = {
     "C2": dict(m=2500, n=100000, L=50, K=16, B=2000, mu=1e-4, seed=0x5EED0002, kind=0),
     "C3": dict(m=2504, n=1000000, L=100, K=24, B=5000, mu=1e-4, seed=0x5EED0003, kind=0),
     "C5": dict(m=10000, n=1000000, L=100, K=32, B=5000, mu=1e-4, seed=0x5EED0005, kind=1),
-    # BASELINE C4's rows (m = 100,000: HBM-streamed block state) on a column prefix that fits one GPU at 1 B/cell
+    # BASELINE C4's rows (m = 100,000: HBM-streamed block state) on a column prefix, and C4 itself
+    # (5e11 cells = 125 GB at 2 bits per cell: one MI355X holds it; one step takes tens of seconds)
     "C4cols50k": dict(m=100000, n=50000, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0),
+    "C4": dict(m=100000, n=5000000, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0),
 }
 
 
@@ -173,8 +176,8 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": "%s: m=%d x n=%d synthetic founder-mosaic DNA (sigma=%d), segment-length-bound L=%d, "
-                        "input resident in HBM column-major 1 B/cell; per rank one alignment"
-                        % (args.workload, m, n, 16 if w["kind"] else 4, L),
+                        "input resident in HBM column-major, %d bits per cell; per rank one alignment"
+                        % (args.workload, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2),
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "segments": int(res.segment_count), "dp_segments": int(res.dp_segment_count),

@@ -25,14 +25,14 @@ namespace {
 struct KernelSet {
 	uint32_t T, E, sigma, cap;
 	size_t lds_colblock, lds_snap;
-	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
+	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t *, uint32_t *, uint32_t *);
-	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass,
+	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
 	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass,
+	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
 	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d);
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -51,25 +51,25 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int T, int E, int SIGMA, bool PK>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
+	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, rank_, keyd, nkeys,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
+	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
 	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d)
 	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass,
+		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass,
+	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
 	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass,
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
 		                   snap_stride, ss_a, ss_d);
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -146,6 +146,7 @@ struct fseq_ctx {
 
 	// geometry
 	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
+	uint32_t bsh = 0;                        // alignment packing: 8 >> bsh bits per symbol (fseq_kernels.hpp sym_bytes)
 	KernelSet ks{};
 	bool kernels_ready = false;
 	bool use_stream = false;             // m too large for an LDS-resident order: HBM-streamed kernels (fseq_stream.hpp)
@@ -238,7 +239,8 @@ void free_msa(fseq_ctx *c)
 int alloc_msa(fseq_ctx *c)
 {
 	free_msa(c);
-	c->ld = ((size_t) c->p.m + 15) & ~size_t(15);
+	c->bsh = c->sigma <= 4 ? 2u : c->sigma <= 16 ? 1u : 0u;
+	c->ld = ((size_t) sym_bytes(c->p.m, c->bsh) + 15) & ~size_t(15);
 	int rc = dev_alloc(c, &c->d_msa, c->ld * c->p.n + 16);
 	if (rc) return rc;
 	c->own_msa = true;
@@ -283,9 +285,9 @@ int prepare_geometry(fseq_ctx *c)
 	if (c->use_stream)
 	{
 		// rows beyond the LDS-resident configurations: the order streams through HBM / L2
-		if (p.m > STREAM_MAX_M)
-			return fail(c, FSEQ_E_UNSUPPORTED, "more rows than this build handles (m <= 147456: one column must fit LDS)");
-		size_t const lds = stream_lds_bytes(p.m);
+		if (sym_bytes(p.m, c->bsh) > STREAM_MAX_COLBYTES)
+			return fail(c, FSEQ_E_UNSUPPORTED, "more rows than this build handles (one packed column must fit LDS: 147456 bytes)");
+		size_t const lds = stream_lds_bytes(sym_bytes(p.m, c->bsh));
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK>, lds));
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream, lds));
@@ -336,8 +338,14 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	}
 	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
-		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB
-		uint64_t const budget = 4ull << 30;
+		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
+		// empty device: up to a sixth of the free memory, at most 32 GiB)
+		uint64_t budget = 4ull << 30;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 6, 32ull << 30));
+		}
 		uint64_t st_ = 16;
 		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
 		c->snap_stride = (uint32_t) st_;
@@ -402,8 +410,8 @@ int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 		if ((present[b >> 5] >> (b & 31)) & 1u) { tab.code_of[b] = (uint8_t) sigma; c->code_to_byte[sigma] = (uint8_t) b; ++sigma; }
 	c->sigma = sigma;
 	if ((rc = alloc_msa(c))) { cleanup(); return rc; }
-	dim3 const grid((uint32_t) ((p.n + 63) / 64), (uint32_t) ((c->ld + 63) / 64));
-	hipLaunchKernelGGL(k_encode_transpose, grid, dim3(256), 0, c->stream, d_raw, tab, p.m, p.n, c->d_msa, c->ld);
+	dim3 const grid((uint32_t) ((p.n + 63) / 64), (uint32_t) ((p.m + 63) / 64));
+	hipLaunchKernelGGL(k_encode_transpose, grid, dim3(256), 0, c->stream, d_raw, tab, p.m, p.n, c->d_msa, c->ld, c->bsh);
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	cleanup();
@@ -434,6 +442,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	// encode + transpose on the host in column tiles, then one copy per tile
 	size_t const tile = std::max<size_t>(1, (size_t) (8u << 20) / c->ld);
 	std::vector<uint8_t> buf(tile * c->ld);
+	uint32_t const bsh = c->bsh, smask = (1u << bsh) - 1u, bits = 8u >> bsh;
 	for (uint64_t c0 = 0; c0 < p.n; c0 += tile)
 	{
 		uint64_t const c1 = std::min<uint64_t>(p.n, c0 + tile);
@@ -442,7 +451,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 		{
 			uint8_t const *row = base + (size_t) r * rs;
 			for (uint64_t col = c0; col < c1; ++col)
-				buf[(col - c0) * c->ld + r] = code_of[row[col * cs]];
+				buf[(col - c0) * c->ld + (r >> bsh)] |= (uint8_t) (code_of[row[col * cs]] << ((r & smask) * bits));
 		}
 		HIP_TRY(c, hipMemcpy(c->d_msa + c0 * c->ld, buf.data(), (c1 - c0) * c->ld, hipMemcpyHostToDevice));
 	}
@@ -477,12 +486,12 @@ void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint3
 {
 	fseq_params const &p = c->p;
 	if (c->use_stream)
-		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(p.m), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
-		                   c->npass, c->d_ws, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
+		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh)), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
+		                   c->npass, c->bsh, c->d_ws, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr);
 	else
-		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, rank, keyd, nkeys);
+		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys);
 }
 
 void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t nb_total, uint32_t G,
@@ -551,10 +560,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		if (c->use_stream)
-			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->d_ws,
+			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws,
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		else
-			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass,
+			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
 			           c->snap_stride, c->d_ss_a, c->d_ss_d);
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
 		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
@@ -704,11 +713,11 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
 		if (c->use_stream)
-			hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) grp.size()), dim3(ST), stream_lds_bytes(m), st, c->d_msa, c->ld, m, n, c->B,
-			                   c->nblocks, c->npass, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
+			hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) grp.size()), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B,
+			                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
 			                   c->d_cols, c->d_grp, c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		else
-			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
+			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
 			        c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
@@ -756,8 +765,14 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
 	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
-		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB
-		uint64_t const budget = 4ull << 30;
+		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
+		// empty device: up to a sixth of the free memory, at most 32 GiB)
+		uint64_t budget = 4ull << 30;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 6, 32ull << 30));
+		}
 		uint64_t st_ = 16;
 		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
 		c->snap_stride = (uint32_t) st_;
@@ -889,6 +904,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	free_msa(c);
 	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_codes));
 	c->ld = ld;
+	c->bsh = 0;                              // borrowed columns are one code per byte
 	c->own_msa = false;
 	c->sigma = sigma;
 	for (uint32_t i = 0; i < 256; ++i) c->code_to_byte[i] = (uint8_t) i;
@@ -902,10 +918,11 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 {
 	if (!c || !spec || 0 == spec->n_founders || 0 == spec->block_len || spec->kind > 1) return FSEQ_E_ARG;
 	(void) hipSetDevice(c->p.device);
-	int rc = alloc_msa(c);
-	if (rc) return rc;
 	char const *alpha = spec->kind ? "ACGTRYSWKMBDHVN-" : "ACGT";
 	uint32_t const sigma = spec->kind ? 16u : 4u;
+	c->sigma = sigma;
+	int rc = alloc_msa(c);
+	if (rc) return rc;
 	SynthArgs A;
 	A.seed = spec->seed; A.n_founders = spec->n_founders; A.block_len = spec->block_len;
 	A.mut_threshold = spec->mut_threshold; A.kind = spec->kind; A.sigma = sigma;
@@ -917,11 +934,10 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 		A.code_of_sym[i] = (uint8_t) rank;
 		c->code_to_byte[rank] = (uint8_t) alpha[i];
 	}
-	c->sigma = sigma;
 	uint64_t const total = (c->ld / 4) * c->p.n;
 	uint64_t const grid = (total + 255) / 256;
 	if (grid > 0x7FFFFFFFull) return fail(c, FSEQ_E_UNSUPPORTED, "synthetic generator grid too large");
-	hipLaunchKernelGGL(k_synth, dim3((uint32_t) grid), dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n);
+	hipLaunchKernelGGL(k_synth, dim3((uint32_t) grid), dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n, c->bsh);
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->have_input = true;
@@ -935,10 +951,12 @@ int fseq_get_matrix(fseq_ctx *c, uint64_t c0, uint64_t c1, uint8_t *out, size_t 
 	if (!c || !out || !c->have_input || c0 > c1 || c1 > c->p.n) return FSEQ_E_ARG;
 	(void) hipSetDevice(c->p.device);
 	std::vector<uint8_t> buf((c1 - c0) * c->ld);
+	uint32_t const bsh = c->bsh, smask = (1u << bsh) - 1u, bits = 8u >> bsh, cmask = (1u << bits) - 1u;
 	HIP_TRY(c, hipMemcpy(buf.data(), c->d_msa + c0 * c->ld, buf.size(), hipMemcpyDeviceToHost));
 	for (uint64_t col = c0; col < c1; ++col)
 		for (uint32_t r = 0; r < c->p.m; ++r)
-			out[(size_t) r * row_stride + (col - c0) * col_stride] = c->code_to_byte[buf[(col - c0) * c->ld + r]];
+			out[(size_t) r * row_stride + (col - c0) * col_stride] =
+				c->code_to_byte[(buf[(col - c0) * c->ld + (r >> bsh)] >> ((r & smask) * bits)) & cmask];
 	return FSEQ_OK;
 }
 

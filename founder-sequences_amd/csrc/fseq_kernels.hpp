@@ -71,18 +71,31 @@ __device__ __forceinline__ uint32_t synth_pick(uint32_t kind, uint64_t h)
 	return 4u + (uint32_t) (hi % 12u);
 }
 
-// one thread per 4 consecutive rows of one column (coalesced 4-byte stores down the column)
-__global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t n)
+// Alignment storage in HBM: column-major, 8 >> bsh bits per dense symbol code (bsh = 2 when sigma <= 4,
+// 1 when sigma <= 16, else 0); row r of a column sits in byte r >> bsh at bit (r & (2^bsh - 1)) * (8 >> bsh).
+__host__ __device__ inline uint32_t sym_bytes(uint32_t m, uint32_t bsh) { return (m + (1u << bsh) - 1u) >> bsh; }
+
+// 2-bit digit `pass` of the code of row `a` in a (staged) packed column
+__device__ __forceinline__ uint32_t sym_digit(uint8_t const *col, uint32_t a, uint32_t bsh, uint32_t pass)
 {
-	uint64_t const quads_per_col = ld / 4;
+	uint32_t const byte = col[a >> bsh];
+	uint32_t const sh = (a & ((1u << bsh) - 1u)) * (8u >> bsh) + 2u * pass;
+	return (byte >> sh) & 3u;
+}
+
+// one thread per 32-bit word of one column = 4 << bsh consecutive rows (coalesced stores down the column)
+__global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t bsh)
+{
+	uint64_t const words_per_col = ld / 4;
 	uint64_t const gid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (gid >= quads_per_col * n) return;
-	uint64_t const c = gid / quads_per_col;
-	uint32_t const r0 = (uint32_t) (gid % quads_per_col) * 4u;
+	if (gid >= words_per_col * n) return;
+	uint64_t const c = gid / words_per_col;
+	uint32_t const w = (uint32_t) (gid % words_per_col);
+	uint32_t const spw = 4u << bsh, bits = 8u >> bsh;
+	uint32_t const r0 = w * spw;
 	uint64_t const b = c / A.block_len;
 	uint32_t packed = 0;
-#pragma unroll
-	for (int q = 0; q < 4; ++q)
+	for (uint32_t q = 0; q < spw; ++q)
 	{
 		uint32_t const r = r0 + q;
 		uint32_t code = 0;
@@ -94,9 +107,9 @@ __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__res
 				sym = (sym + 1u + (uint32_t) (synth_h(A.seed, 4, r, c) % (A.sigma - 1u))) % A.sigma;
 			code = A.code_of_sym[sym];
 		}
-		packed |= code << (8 * q);
+		packed |= code << (bits * q);
 	}
-	*reinterpret_cast<uint32_t *>(msa + c * ld + r0) = packed;
+	*reinterpret_cast<uint32_t *>(msa + c * ld + (size_t) w * 4u) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -143,10 +156,10 @@ __global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ ra
 
 struct CodeTable { uint8_t code_of[256]; };
 
-// ... and the encode + transpose: raw[r * n + c] -> msa[c * ld + r] = code_of[byte]; 64 x 64 tiles through LDS,
-// reads coalesced along a row, writes coalesced down a column.
+// ... and the encode + transpose + pack: raw[r * n + c] -> code_of[byte] at row r of packed column c; 64 x 64
+// tiles through LDS, reads coalesced along a row, writes down a column (64 >> bsh bytes per tile column).
 __global__ __launch_bounds__(256) void k_encode_transpose(
-	uint8_t const *__restrict__ raw, CodeTable const tab, uint32_t m, uint64_t n, uint8_t *__restrict__ msa, size_t ld)
+	uint8_t const *__restrict__ raw, CodeTable const tab, uint32_t m, uint64_t n, uint8_t *__restrict__ msa, size_t ld, uint32_t bsh)
 {
 	__shared__ uint8_t tile[64][65];
 	uint64_t const c0 = (uint64_t) blockIdx.x * 64;
@@ -159,11 +172,17 @@ __global__ __launch_bounds__(256) void k_encode_transpose(
 		tile[rr][tx] = (r < m && c < n) ? tab.code_of[raw[(size_t) r * n + c]] : (uint8_t) 0;
 	}
 	__syncthreads();
+	uint32_t const spb = 1u << bsh, bits = 8u >> bsh;
 	for (uint32_t cc = ty; cc < 64; cc += 4)
 	{
 		uint64_t const c = c0 + cc;
-		uint32_t const r = r0 + tx;
-		if (c < n && r < ld) msa[c * ld + r] = (r < m) ? tile[tx][cc] : (uint8_t) 0;
+		size_t const byte = (size_t) (r0 >> bsh) + tx;
+		if (c < n && tx < (64u >> bsh) && byte < ld)
+		{
+			uint32_t v = 0;
+			for (uint32_t q = 0; q < spb; ++q) v |= (uint32_t) tile[tx * spb + q][cc] << (bits * q);
+			msa[c * ld + byte] = (uint8_t) v;
+		}
 	}
 }
 
@@ -201,7 +220,7 @@ __host__ __device__ inline size_t colblock_lds_bytes()
 // range maximum of the later passes, so the result equals the single sigma-bucket partition.
 template <int T, int E, int SIGMA, int MODE, bool PK>
 __global__ __launch_bounds__(T) void k_colblock(
-	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass,
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh,
 	// MODE_RANK outputs
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	// MODE_SNAP inputs / outputs
@@ -261,7 +280,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint32_t const nb = (uint32_t) (kend - k0);
 	uint32_t const dbase = (MODE == MODE_RANK) ? (uint32_t) k0 : 0u;
 
-	bool const has_chunk = tid * 16u < m;
+	bool const has_chunk = tid * 16u < sym_bytes(m, bsh);
 	uint4 nxt = make_uint4(0, 0, 0, 0);
 	if (nb && has_chunk)
 	{
@@ -299,7 +318,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 			uint32_t a[E], d[E], s[E], dst[E], dnew[E];
 			read_chunk<T, E>(a_l, d_l, a, d);
 #pragma unroll
-			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (((uint32_t) symc[a[e]] >> (2u * pass)) & 3u) : (uint32_t) SIGMA;
+			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
 			partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 
@@ -579,7 +598,7 @@ template <int T, int E, int SIGMA, bool PK>
 __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
-	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass,
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
 {
 	constexpr uint32_t CAP = T * E;
@@ -676,7 +695,7 @@ __global__ __launch_bounds__(T) void k_columns(
 #pragma unroll
 	for (int e = 0; e < E; ++e) { a_l[p0 + e] = (AT) a[e]; d_l[p0 + e] = (AT) id[e]; }
 
-	bool const has_chunk = tid * 16u < m;
+	bool const has_chunk = tid * 16u < sym_bytes(m, bsh);
 	uint4 nxt = make_uint4(0, 0, 0, 0);
 	if (nb && has_chunk)
 	{
@@ -700,7 +719,7 @@ __global__ __launch_bounds__(T) void k_columns(
 			uint32_t s[E], dst[E], dnew[E];
 			read_chunk<T, E>(a_l, d_l, a, d);
 #pragma unroll
-			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? (((uint32_t) symc[a[e]] >> (2u * pass)) & 3u) : (uint32_t) SIGMA;
+			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
 			partition_step<T, E, SIGMA>(d, s, D0 + j, scr, dst, dnew);
 

@@ -14,21 +14,21 @@ namespace fseq {
 
 constexpr int ST = 1024, SE = 8;
 constexpr uint32_t SCAP = ST * SE;
-constexpr uint32_t STREAM_MAX_M = 147456;          // column staging: m bytes of LDS
+constexpr uint32_t STREAM_MAX_COLBYTES = 147456;   // column staging: one packed column (sym_bytes(m, bsh)) in LDS
 
 struct StreamLds {
 	StepScratch<ST, 4> scr;
 	uint32_t red[4 * (ST / WAVE) + 8];
 };
 
-__host__ __device__ inline size_t stream_lds_bytes(uint32_t m)
+__host__ __device__ inline size_t stream_lds_bytes(uint32_t colbytes)
 {
-	return carve_bytes((size_t) m + 16, 1) + carve_bytes(1, sizeof(StreamLds));
+	return carve_bytes((size_t) colbytes + 16, 1) + carve_bytes(1, sizeof(StreamLds));
 }
 
 struct DigitColumn {
-	uint8_t const *sym; uint32_t shift;
-	__device__ __forceinline__ uint32_t operator()(uint32_t a) const { return ((uint32_t) sym[a] >> shift) & 3u; }
+	uint8_t const *sym; uint32_t bsh, pass;
+	__device__ __forceinline__ uint32_t operator()(uint32_t a) const { return sym_digit(sym, a, bsh, pass); }
 };
 struct DigitRank {
 	uint32_t const *rank; uint32_t shift;
@@ -61,18 +61,20 @@ __device__ __forceinline__ void block_sum4(uint32_t (&c)[4], uint32_t *red)
 }
 
 // Bucket sizes of a column pass do not depend on the order: count the digit straight off the staged column.
-__device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t m, uint32_t shift, uint32_t (&cnt)[4], uint32_t *red)
+__device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t m, uint32_t bsh, uint32_t pass, uint32_t (&cnt)[4], uint32_t *red)
 {
 #pragma unroll
 	for (int x = 0; x < 4; ++x) cnt[x] = 0;
-	for (uint32_t i = threadIdx.x * 4u; i < m; i += ST * 4u)
+	uint32_t const spw = 4u << bsh, bits = 8u >> bsh;          // symbols per 32-bit word, bits per symbol
+	uint32_t const nwords = (sym_bytes(m, bsh) + 3u) / 4u;
+	for (uint32_t wi = threadIdx.x; wi < nwords; wi += ST)
 	{
-		uint32_t const w = *reinterpret_cast<uint32_t const *>(sym + i);
-#pragma unroll
-		for (int b = 0; b < 4; ++b)
+		uint32_t const w = *reinterpret_cast<uint32_t const *>(sym + wi * 4u);
+		uint32_t const r0 = wi * spw;
+		for (uint32_t q = 0; q < spw; ++q)
 		{
-			uint32_t const g = (w >> (8 * b + shift)) & 3u;
-			bool const in = i + b < m;
+			uint32_t const g = (w >> (bits * q + 2u * pass)) & 3u;
+			bool const in = r0 + q < m;
 #pragma unroll
 			for (int x = 0; x < 4; ++x) cnt[x] += (in && g == (uint32_t) x) ? 1u : 0u;
 		}
@@ -148,9 +150,9 @@ __device__ __forceinline__ void stream_pass(
 	}
 }
 
-__device__ __forceinline__ void stage_column(uint8_t *sym, uint8_t const *col, uint32_t m)
+__device__ __forceinline__ void stage_column(uint8_t *sym, uint8_t const *col, uint32_t colbytes)
 {
-	for (uint32_t i = threadIdx.x * 16u; i < m; i += ST * 16u)
+	for (uint32_t i = threadIdx.x * 16u; i < colbytes; i += ST * 16u)
 		*reinterpret_cast<uint4 *>(sym + i) = *reinterpret_cast<uint4 const *>(col + i);
 }
 
@@ -197,7 +199,7 @@ __device__ __forceinline__ void stream_emit_ranks(
 // ------------------------------------------------------------------------------------------------
 template <int MODE>
 __global__ __launch_bounds__(ST) void k_colblock_stream(
-	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t *ws,
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *ws,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
-	uint8_t *sym = cv.take<uint8_t>((size_t) m + 16);
+	uint8_t *sym = cv.take<uint8_t>((size_t) sym_bytes(m, bsh) + 16);
 	StreamLds &L = *cv.take<StreamLds>(1);
 	uint32_t const tid = threadIdx.x;
 	uint32_t *buf[2][2];
@@ -248,14 +250,14 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	snapshot_if_requested(k0);
 	for (uint64_t k = k0; k < kend; ++k)
 	{
-		stage_column(sym, msa + k * ld, m);
+		stage_column(sym, msa + k * ld, sym_bytes(m, bsh));
 		__syncthreads();
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
 			uint32_t cnt4[4];
-			column_digit_counts(sym, m, 2u * pass, cnt4, L.red);
+			column_digit_counts(sym, m, bsh, pass, cnt4, L.red);
 			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], (uint32_t) (k + 1),
-			                   DigitColumn{sym, 2u * pass}, NoHook{}, L, cnt4);
+			                   DigitColumn{sym, bsh, pass}, NoHook{}, L, cnt4);
 			cur ^= 1u;
 		}
 		snapshot_if_requested(k + 1);
@@ -335,14 +337,14 @@ struct HistHook {
 };
 
 __global__ __launch_bounds__(ST) void k_columns_stream(
-	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t *ws,
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
-	uint8_t *sym = cv.take<uint8_t>((size_t) m + 16);
+	uint8_t *sym = cv.take<uint8_t>((size_t) sym_bytes(m, bsh) + 16);
 	StreamLds &L = *cv.take<StreamLds>(1);
 	uint32_t const tid = threadIdx.x;
 	uint32_t *w = ws + (size_t) blockIdx.x * columns_stream_ws_words(m, B);
@@ -412,13 +414,13 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 
 	for (uint32_t j = 0; j < nb; ++j)
 	{
-		stage_column(sym, msa + (k0 + j) * ld, m);
+		stage_column(sym, msa + (k0 + j) * ld, sym_bytes(m, bsh));
 		__syncthreads();
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
 			uint32_t cnt4[4];
-			column_digit_counts(sym, m, 2u * pass, cnt4, L.red);
-			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, 2u * pass}, HistHook{cnt}, L, cnt4);
+			column_digit_counts(sym, m, bsh, pass, cnt4, L.red);
+			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, bsh, pass}, HistHook{cnt}, L, cnt4);
 			cur ^= 1u;
 		}
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)

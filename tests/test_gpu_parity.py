@@ -115,6 +115,7 @@ def test_kernel_configuration_boundaries(pkg, m):
     (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50),          # three tiles, sigma = 16 (two digit passes per column)
     (70000, 200, 12, 20, 64, 1e-4, 43, 0, 40),           # more than 65535 rows: 32-bit tile carry
     (100000, 160, 10, 64, 50, 5e-5, 0x5EED0004, 0, 0),   # BASELINE config C4 rows, shortened columns
+    (200001, 48, 8, 30, 16, 5e-5, 44, 0, 0),             # 2-bit packed columns: 50,001 bytes staged per column
 ])
 def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     """m > 11,264: the block order streams through HBM/L2 in tiles (fseq_stream.hpp)."""
@@ -123,7 +124,7 @@ def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
 
 
 def test_unsupported_shape_fails_loudly(pkg):
-    ctx = pkg.SegmentationContext(200000, 64, 8)         # more rows than one staged column allows (m <= 147,456)
+    ctx = pkg.SegmentationContext(600000, 64, 8)         # more rows than one staged column allows (147,456 bytes at 2 bits per row)
     ctx.generate_synthetic(1, 4, 16, 1e-3, 0)
     with pytest.raises(pkg.FseqError) as e:
         ctx.run()
