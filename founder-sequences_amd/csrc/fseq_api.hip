@@ -162,8 +162,10 @@ struct fseq_ctx {
 	uint2 *d_ent = nullptr;
 	uint4 *d_hdr = nullptr;
 	uint32_t X = 0, stride = 0;
+	uint32_t X_hint = 0;                     // list capacity that worked on the last run of this input
 	DpArrays dp{};
 	uint32_t *d_flags = nullptr;
+	uint32_t *d_recent = nullptr;            // k_boundary_recent counts, one per block boundary
 	uint64_t dp_size = 0;
 	uint64_t *d_cols = nullptr;           // scratch: column / rb lists
 	size_t cols_cap = 0;
@@ -217,7 +219,12 @@ int dev_alloc(fseq_ctx *c, U **p, size_t count)
 	if (e != hipSuccess)
 	{
 		*p = nullptr;
-		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, "hipMalloc", e);
+		size_t free_b = 0, total_b = 0;
+		(void) hipMemGetInfo(&free_b, &total_b);
+		char what[160];
+		snprintf(what, sizeof(what), "hipMalloc of %zu bytes (%zu of %zu bytes free on the device)",
+		         std::max<size_t>(count, 1) * sizeof(U), free_b, total_b);
+		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, what, e);
 	}
 	return FSEQ_OK;
 }
@@ -324,6 +331,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
 		if ((rc = dev_alloc(c, &c->d_flags, 256))) return rc;
+		if ((rc = dev_alloc(c, &c->d_recent, c->nblocks + 1))) return rc;
 		if (p.n >= 2 * p.segment_length)
 		{
 			c->dp_size = p.n - p.segment_length + 1;
@@ -339,12 +347,12 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
 		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
-		// empty device: up to a sixth of the free memory, at most 32 GiB)
+		// empty device: up to a fifth of the free memory, at most 32 GiB)
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 6, 32ull << 30));
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 5, 32ull << 30));
 		}
 		uint64_t st_ = 16;
 		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
@@ -358,7 +366,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		c->ws_words = per_block * std::max<size_t>(c->nblocks, 1);
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) return rc;
 	}
-	if (!c->d_ent || c->X != X)
+	if (X && (!c->d_ent || c->X != X))
 	{
 		c->X = X;
 		c->stride = (X + 3) & ~1u;                // lump + up to X+1 entries, even
@@ -372,7 +380,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
-	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags);
+	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a); dev_free(&c->d_ss_d); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
@@ -419,6 +427,7 @@ int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_input = true;
 	c->have_result = false;
 	c->kernels_ready = false;
+	c->X_hint = 0;
 	return FSEQ_OK;
 }
 
@@ -458,6 +467,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_input = true;
 	c->have_result = false;
 	c->kernels_ready = false;
+	c->X_hint = 0;
 	return FSEQ_OK;
 }
 
@@ -516,14 +526,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	KernelSet const &ks = c->ks;
 	int rc;
 
-	uint32_t X = p.list_cap ? p.list_cap : 255u;
-	if (X >= m) X = m;
+	uint32_t X = p.list_cap ? p.list_cap : std::max(255u, c->X_hint);
 	c->tm = fseq_timings{};
 	c->tm.block_len = c->B;
 	c->tm.n_blocks = c->nblocks;
 	double const t_begin = now_ms();
 
-	if ((rc = ensure_work_buffers(c, X))) return rc;
+	if ((rc = ensure_work_buffers(c, 0))) return rc;
 
 	// ---- phase A + B (independent of X)
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
@@ -548,6 +557,26 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
+	if (!p.list_cap && !c->X_hint)
+	{
+		// first run on this input: size the lists from the block boundary states (k_boundary_recent)
+		std::vector<uint32_t> recent(c->nblocks + 1);
+		hipLaunchKernelGGL(k_boundary_recent, dim3(c->nblocks + 1), dim3(256), 0, st, c->d_bstate_d, m, n, c->B, (uint32_t) L, c->d_recent);
+		HIP_TRY(c, hipMemcpyAsync(recent.data(), c->d_recent, recent.size() * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		recent.erase(std::remove(recent.begin(), recent.end(), 0xFFFFFFFFu), recent.end());
+		if (!recent.empty())
+		{
+			std::nth_element(recent.begin(), recent.begin() + recent.size() / 2, recent.end());
+			uint64_t const med = recent[recent.size() / 2];
+			uint64_t const want = med + med / 4;
+			while (X < want) X = 2 * X + 1;
+			if (getenv("FSEQ_DEBUG"))
+				fprintf(stderr, "[fseq] list capacity estimate: %zu boundaries, median recent count %llu -> X = %u\n",
+				        recent.size(), (unsigned long long) med, X);
+		}
+	}
+	if (X >= m) X = m;
 
 	double ms_c = 0, ms_dp = 0, ms_host = 0;
 	uint32_t retries = 0;
@@ -669,9 +698,11 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		ms_host += now_ms() - th0;
 		if (!overflow) break;
 		if (X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
-		X = (uint32_t) std::min<uint64_t>(m, (uint64_t) X * 4 + 3);
+		X = (uint32_t) std::min<uint64_t>(m, (uint64_t) X * 2 + 1);
 		++retries;
+		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] divergence lists too short, retry %u with X = %u\n", retries, X);
 	}
+	c->X_hint = X;                           // later runs on this context start with the capacity that worked
 	c->res.segment_count = c->segments.size();
 
 	// ---- pass 2: (a,d) at the merged boundaries (update_pbwt_task.cc:13-35)
@@ -713,9 +744,17 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
 		if (c->use_stream)
-			hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) grp.size()), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B,
-			                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
-			                   c->d_cols, c->d_grp, c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
+		{
+			// the streamed sweep needs 4m workspace words per workgroup: as many groups per launch as d_ws holds
+			size_t const cap = std::max<size_t>(1, c->ws_words / (4 * (size_t) m));
+			for (size_t g0 = 0; g0 < grp.size(); g0 += cap)
+			{
+				size_t const cnt = std::min(cap, grp.size() - g0);
+				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B,
+				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
+				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d);
+			}
+		}
 		else
 			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
 			        c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
@@ -766,12 +805,12 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
 		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
-		// empty device: up to a sixth of the free memory, at most 32 GiB)
+		// empty device: up to a fifth of the free memory, at most 32 GiB)
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 6, 32ull << 30));
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 5, 32ull << 30));
 		}
 		uint64_t st_ = 16;
 		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
@@ -911,6 +950,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_input = true;
 	c->have_result = false;
 	c->kernels_ready = false;
+	c->X_hint = 0;
 	return FSEQ_OK;
 }
 
@@ -934,15 +974,14 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 		A.code_of_sym[i] = (uint8_t) rank;
 		c->code_to_byte[rank] = (uint8_t) alpha[i];
 	}
-	uint64_t const total = (c->ld / 4) * c->p.n;
-	uint64_t const grid = (total + 255) / 256;
-	if (grid > 0x7FFFFFFFull) return fail(c, FSEQ_E_UNSUPPORTED, "synthetic generator grid too large");
-	hipLaunchKernelGGL(k_synth, dim3((uint32_t) grid), dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n, c->bsh);
+	dim3 const grid((uint32_t) ((c->ld / 4 + 255) / 256), (uint32_t) std::min<uint64_t>(c->p.n, 65535));
+	hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n, c->bsh);
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->have_input = true;
 	c->have_result = false;
 	c->kernels_ready = false;
+	c->X_hint = 0;
 	return FSEQ_OK;
 }
 

@@ -83,33 +83,35 @@ __device__ __forceinline__ uint32_t sym_digit(uint8_t const *col, uint32_t a, ui
 	return (byte >> sh) & 3u;
 }
 
-// one thread per 32-bit word of one column = 4 << bsh consecutive rows (coalesced stores down the column)
+// one thread per 32-bit word of one column = 4 << bsh consecutive rows (coalesced stores down the column);
+// blockIdx.y strides over the columns (a launch holds fewer than 2^32 threads per dimension)
 __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t bsh)
 {
-	uint64_t const words_per_col = ld / 4;
-	uint64_t const gid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	if (gid >= words_per_col * n) return;
-	uint64_t const c = gid / words_per_col;
-	uint32_t const w = (uint32_t) (gid % words_per_col);
-	uint32_t const spw = 4u << bsh, bits = 8u >> bsh;
-	uint32_t const r0 = w * spw;
-	uint64_t const b = c / A.block_len;
-	uint32_t packed = 0;
-	for (uint32_t q = 0; q < spw; ++q)
+	uint32_t const words_per_col = (uint32_t) (ld / 4);
+	uint32_t const w = blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words_per_col) return;
+	for (uint64_t c = blockIdx.y; c < n; c += gridDim.y)
 	{
-		uint32_t const r = r0 + q;
-		uint32_t code = 0;
-		if (r < m)
+		uint32_t const spw = 4u << bsh, bits = 8u >> bsh;
+		uint32_t const r0 = w * spw;
+		uint64_t const b = c / A.block_len;
+		uint32_t packed = 0;
+		for (uint32_t q = 0; q < spw; ++q)
 		{
-			uint64_t const f = synth_h(A.seed, 2, r, b) % A.n_founders;
-			uint32_t sym = synth_pick(A.kind, synth_h(A.seed, 1, f, c));
-			if (synth_h(A.seed, 3, r, c) < A.mut_threshold)
-				sym = (sym + 1u + (uint32_t) (synth_h(A.seed, 4, r, c) % (A.sigma - 1u))) % A.sigma;
-			code = A.code_of_sym[sym];
+			uint32_t const r = r0 + q;
+			uint32_t code = 0;
+			if (r < m)
+			{
+				uint64_t const f = synth_h(A.seed, 2, r, b) % A.n_founders;
+				uint32_t sym = synth_pick(A.kind, synth_h(A.seed, 1, f, c));
+				if (synth_h(A.seed, 3, r, c) < A.mut_threshold)
+					sym = (sym + 1u + (uint32_t) (synth_h(A.seed, 4, r, c) % (A.sigma - 1u))) % A.sigma;
+				code = A.code_of_sym[sym];
+			}
+			packed |= code << (bits * q);
 		}
-		packed |= code << (bits * q);
+		*reinterpret_cast<uint32_t *>(msa + c * ld + (size_t) w * 4u) = packed;
 	}
-	*reinterpret_cast<uint32_t *>(msa + c * ld + (size_t) w * 4u) = packed;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1479,6 +1481,26 @@ __global__ __launch_bounds__(1024) void k_dp(
 		uint32_t const lag = S.pipe ? 2u : 1u;
 		for (uint32_t r = (nrounds >= lag ? nrounds - lag : 0u); r < nrounds; ++r) flush_round(r);
 	}
+}
+
+// List-capacity estimate: the length-L segment ending at block boundary k has #{i : d_k[i] > k - L} distinct
+// rows; the median over the boundaries sizes the per-column lists before phase C runs (a wrong guess only
+// costs a retry, never the result).
+__global__ __launch_bounds__(256) void k_boundary_recent(
+	uint32_t const *__restrict__ bstate_d, uint32_t m, uint64_t n, uint32_t B, uint32_t L, uint32_t *__restrict__ out)
+{
+	uint64_t k = (uint64_t) blockIdx.x * B;
+	if (k > n) k = n;
+	if (k < L) { if (threadIdx.x == 0) out[blockIdx.x] = 0xFFFFFFFFu; return; }
+	uint32_t const thr = (uint32_t) (k - L);
+	uint32_t const *d = bstate_d + (size_t) blockIdx.x * m;
+	uint32_t cnt = 0;
+	for (uint32_t i = threadIdx.x; i < m; i += 256) cnt += d[i] > thr ? 1u : 0u;
+	__shared__ uint32_t red[4];
+	cnt = readlane_u32(wave_incl_add(cnt), 63);
+	if (lane_id() == 0) red[wave_id()] = cnt;
+	__syncthreads();
+	if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
 // copy the lists of selected columns into a compact buffer (for the host-side merge)

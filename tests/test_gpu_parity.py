@@ -116,6 +116,7 @@ def test_kernel_configuration_boundaries(pkg, m):
     (70000, 200, 12, 20, 64, 1e-4, 43, 0, 40),           # more than 65535 rows: 32-bit tile carry
     (100000, 160, 10, 64, 50, 5e-5, 0x5EED0004, 0, 0),   # BASELINE config C4 rows, shortened columns
     (200001, 48, 8, 30, 16, 5e-5, 44, 0, 0),             # 2-bit packed columns: 50,001 bytes staged per column
+    (11300, 2400, 4, 3, 40, 2e-3, 45, 0, 1200),          # two blocks, many segments: pass 2 in several launches
 ])
 def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     """m > 11,264: the block order streams through HBM/L2 in tiles (fseq_stream.hpp)."""
