@@ -110,8 +110,9 @@ char const *fseq_last_error(fseq_ctx const *ctx);
 int  fseq_set_rows(fseq_ctx *ctx, uint8_t const *const *rows);
 /* Same, from one host buffer: sym(r,c) = base[r*row_stride + c*col_stride]. */
 int  fseq_set_matrix(fseq_ctx *ctx, uint8_t const *base, size_t row_stride, size_t col_stride);
-/* Input already resident in HBM: column-major dense codes, column c at d_codes + c*ld, ld >= m.
- * sigma = number of codes (codes are < sigma).  The buffer is borrowed, not copied. */
+/* Input already resident in HBM: column-major dense codes, one per byte, column c at d_codes + c*ld,
+ * ld >= m.  sigma = number of codes (codes are < sigma).  The buffer is borrowed, not copied (and not
+ * repacked: inputs the library uploads itself are stored at 2 / 4 / 8 bits per cell by sigma). */
 int  fseq_set_device_columns(fseq_ctx *ctx, void const *d_codes, size_t ld, uint32_t sigma);
 /* Generate the alignment on the device (bench / large configs). */
 int  fseq_generate_synthetic(fseq_ctx *ctx, fseq_synth_spec const *spec);
