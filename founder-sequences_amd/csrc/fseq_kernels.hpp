@@ -861,7 +861,8 @@ struct DpLds {
 __host__ __device__ inline size_t dp_lds_bytes()
 {
 	return carve_bytes(DPW, 8) + carve_bytes(DPW, 4) + 2 * carve_bytes(DP_STG, 4) + 2 * carve_bytes((size_t) DP_LEVELS * DP_TRN, 4)
-	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_MBSLOTS * 64, 4);
+	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_MBSLOTS * 64, 4)
+	     + carve_bytes(4, 4);
 }
 
 // where a query may read: entries >= safe_lo and samples produced after block cb - DP_TRN live in LDS
@@ -1066,6 +1067,115 @@ __device__ __forceinline__ CellState dp_cell_sequential(
 	return st;
 }
 
+struct DpRound {
+	uint32_t e0, len, t0, t1;
+	bool final_round;
+};
+
+// The two 32-lane halves of a wave as independent scans / reductions
+__device__ __forceinline__ uint32_t half_incl_add(uint32_t v)
+{
+	v += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v)
+{
+	v = min(v, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, v));
+	uint32_t const a = readlane_u32(v, 31), b = readlane_u32(v, 63);
+	return lane_id() < 32u ? a : b;
+}
+
+// Two cells at once, one per 32-lane half (cells i0 and i0 + 1 of the round): the arithmetic of
+// dp_strip on the first 32 list entries plus the tail of dp_cell_sequential.  Nearly every cell is
+// decided there (the lumped entry plus a few dozen distinct values reach the pruning bound), so
+// a cell costs half the instructions of a full-wave strip.  A cell that is neither decided nor at the
+// end of its list after 32 entries is left unwritten and reported in the returned mask (bit 0 /
+// bit 32); the caller runs the general path for it.
+__device__ __forceinline__ uint64_t dp_cell_pair(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint32_t slot, uint32_t i0, DpRound const &R,
+	uint32_t m, uint32_t L, uint32_t *flags)
+{
+	uint32_t const lane = lane_id(), half = lane >> 5, sub = lane & 31u;
+	bool const has = i0 + half < R.len;
+	uint32_t const ci = has ? i0 + half : i0;
+	uint32_t const end = R.e0 + ci, t = end - L;
+	lds_u32 const *hp = D.H + (slot * 64u + ci) * 4u;
+	uint32_t const nent = hp[0], cnt0 = hp[1], complete = hp[2];
+	lds_u32 const *ls = D.LS + (slot * DP_RL + ci) * 128u;
+	bool const valid = sub < nent;
+	bool const have_next = sub + 1u < nent;
+	uint2 const en = valid ? make_uint2(ls[2u * sub], ls[2u * sub + 1u]) : make_uint2(0u, 0u);
+	uint32_t const vnext = have_next ? ls[2u * sub + 2u] : 0u;
+	bool const is0 = valid && en.x == 0u;
+	uint32_t const cc = (valid && !is0) ? en.y : 0u;
+	uint32_t const cum = half_incl_add(cc);
+	bool ok = valid && !is0 && have_next && vnext != 0u;
+	uint32_t lo = vnext;
+	uint32_t const c = min(en.x, end + 1u - L);              // lp.cc:444-445
+	if (lo < L)                                              // lp.cc:449-455
+	{
+		if (L < c) lo = L; else ok = false;
+	}
+	ok = ok && lo < c;                                       // lp.cc:458
+	uint32_t val = 0xFFFFFFFFu, idx = 0;
+	uint32_t const qb = lo - L, qe = c - L;
+	if (__ballot(ok && qb < V.safe_lo) == 0)
+	{
+		if (ok)
+		{
+			uint32_t mv;
+			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
+			val = max(mv, cum);                                  // lp.cc:468-471
+		}
+	}
+	else if (ok)
+	{
+		uint32_t mv;
+		idx = rmq_query(A, D, V, qb, qe, &mv);
+		val = max(mv, cum);
+	}
+	// minimum per half; among equal values the highest lane of the half (dp_strip)
+	uint32_t const vmin = half_min_u32(val);
+	uint64_t const wmask = __ballot(ok && val == vmin);
+	uint32_t const mA = (uint32_t) wmask, mB = (uint32_t) (wmask >> 32);
+	int const srcA = mA ? 31 - (int) __builtin_clz(mA) : 0, srcB = mB ? 63 - (int) __builtin_clz(mB) : 32;
+	uint32_t const lbA = readlane_u32(idx, srcA), lbB = readlane_u32(idx, srcB);
+	uint32_t const szA = readlane_u32(cum, srcA), szB = readlane_u32(cum, srcB);
+	uint32_t const cumA = readlane_u32(cum, 31), cumB = readlane_u32(cum, 63);
+	uint32_t best_v = vmin;
+	uint32_t best_lb = vmin != 0xFFFFFFFFu ? (half ? lbB : lbA) + L : 0u;
+	uint32_t best_sz = vmin != 0xFFFFFFFFu ? (half ? szB : szA) : 0u;
+	uint32_t const cum_base = half ? cumB : cumA;
+	bool const decided = best_v != 0xFFFFFFFFu && cum_base > best_v;
+	bool const more = !decided && nent > 32u;
+	if (!more)
+	{
+		if (!complete && !decided && has && sub == 0u) atomicOr(flags, 1u);   // list too short to prove the result
+		if (complete && cnt0 > 0)
+		{
+			uint32_t const w = m - cnt0;                         // lp.cc:416-421
+			if (w <= best_v) { best_v = w; best_lb = 0; best_sz = w; }
+		}
+		if (m <= best_v) { best_v = m; best_lb = 0; best_sz = m; }             // lp.cc:123
+		if (has && sub == 0u)
+		{
+			D.Mr[t & (DPW - 1u)] = best_v;
+			D.LBr[t & (DP_STG - 1u)] = best_lb;
+			D.SZr[t & (DP_STG - 1u)] = best_sz;
+		}
+	}
+	return __ballot(has && more && sub == 0u);
+}
+
 // LDS-DMA: every lane names its own 16 (or 4) global bytes; they land at LDS address lds + lane * size.
 // Inline asm on purpose: the loader wave counts these itself (s_waitcnt vmcnt(DP_Q) = "the round
 // before the one just issued has landed"); issued through the builtin, hipcc would drain them
@@ -1083,11 +1193,6 @@ __device__ __forceinline__ void dma4(void const *g, uint32_t lds_addr)
 	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
-
-struct DpRound {
-	uint32_t e0, len, t0, t1;
-	bool final_round;
-};
 
 // s_waitcnt vmcnt(N) takes an immediate: wait until at most N (4..31) of this wave's LDS-DMA loads are in flight
 __device__ __forceinline__ void dp_wait_all_but(uint32_t n)
@@ -1262,6 +1367,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 	D.H = (lds_u32 *) (lds0 + off_H);
 	D.MBi = (lds_u32 *) (lds0 + off_MBi);
 	D.MBv = (lds_u32 *) (lds0 + off_MBv);
+	lds_u32 *const fbcnt = (lds_u32 *) (lds0 + take(16));     // cells per round that needed the general path (ring of 4 rounds)
 
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(wave_id());
 	uint32_t const lane = lane_id();
@@ -1340,6 +1446,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 		if (nrounds > 1) load_round(1);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	}
+	if (threadIdx.x < 4) fbcnt[threadIdx.x] = 0;
 	dp_barrier();
 
 #ifdef FSEQ_DP_STAMPS
@@ -1348,6 +1455,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 #else
 #define DP_STAMP(x)
 #endif
+	uint32_t pair_cool = 0;                                   // rounds left before this wave tries cell pairs again
 	for (uint32_t r = 0; r < nrounds; ++r)
 	{
 		DP_STAMP(ts0);
@@ -1367,13 +1475,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 
 		if (wave < NWC)
 		{
-			// ---- compute: cells i = wave, wave + NWC, ...  (one CU's VALU issue rate bounds this
-			// phase: a stage-interleaved, branch-free variant was measured slower)
-#pragma unroll
-			for (int g = 0; g < DP_G; ++g)
-			{
-				uint32_t const i = wave + (uint32_t) g * NWC;
-				if (i >= R.len) continue;
+			// ---- compute (one CU's VALU issue rate bounds this phase: a stage-interleaved, branch-free
+			// variant was measured slower)
+			auto single_cell = [&](uint32_t i) {
 				uint32_t const end = R.e0 + i;
 				uint32_t const t = end - L;
 				lds_u32 const *hp = D.H + (slot * 64u + i) * 4u;
@@ -1396,6 +1500,38 @@ __global__ __launch_bounds__(1024) void k_dp(
 					D.Mr[t & (DPW - 1u)] = st.best_v;
 					D.LBr[t & (DP_STG - 1u)] = st.best_lb;
 					D.SZr[t & (DP_STG - 1u)] = st.best_sz;
+				}
+			};
+			// the choice between cell pairs and full-wave cells must be the same in every wave (it decides
+			// which wave owns which cell): all waves read the same counter of the previous round
+			if (r >= 1u && 2u * fbcnt[(r - 1u) & 3u] > RL) pair_cool = 16u;   // long lists here: full-wave cells for a while
+			if (wave == 0 && lane == 0) fbcnt[(r + 2u) & 3u] = 0;
+			if (!R.final_round && R.e0 > p2lim && pair_cool == 0u)
+			{
+				// two cells per step, one per half wave: pairs wave, wave + NWC
+				uint32_t ncell = 0, nfb = 0;
+#pragma unroll
+				for (int g = 0; g < DP_G / 2; ++g)
+				{
+					uint32_t const i0 = 2u * (wave + (uint32_t) g * NWC);
+					if (i0 >= R.len) continue;
+					uint64_t const fb = dp_cell_pair(A, D, V, slot, i0, R, m, L, flags);
+					ncell += 2u;
+					if (fb & 1ull) { single_cell(i0); ++nfb; }
+					if (fb >> 32) { single_cell(i0 + 1u); ++nfb; }
+				}
+				if (nfb && lane == 0) atomicAdd((uint32_t *) (fbcnt + (r & 3u)), nfb);
+				(void) ncell;
+			}
+			else
+			{
+				if (pair_cool) --pair_cool;
+#pragma unroll
+				for (int g = 0; g < DP_G; ++g)
+				{
+					uint32_t const i = wave + (uint32_t) g * NWC;
+					if (i >= R.len) continue;
+					single_cell(i);
 				}
 			}
 		}
