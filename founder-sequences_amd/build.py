@@ -5,8 +5,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fseq_api.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "fseq_kernels.hpp"), os.path.join(HERE, "csrc", "fseq_core.hpp"),
-        os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("fseq_kernels.hpp", "fseq_core.hpp", "fseq_stream.hpp", "fseq_join.hpp")] \
+    + [os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
 OUT = os.path.join(HERE, "libfseq_hip.so")
 
 
@@ -27,7 +27,9 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", OUT, SRC]
+    # FSEQ_HIPCC_FLAGS: extra flags for diagnostic builds (-DFSEQ_DP_STAMPS, -DFSEQ_DP_STATS)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("FSEQ_HIPCC_FLAGS", "").split() \
+        + ["-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

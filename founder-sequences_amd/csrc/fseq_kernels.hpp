@@ -1506,33 +1506,32 @@ __global__ __launch_bounds__(1024) void k_dp(
 			// which wave owns which cell): all waves read the same counter of the previous round
 			if (r >= 1u && 2u * fbcnt[(r - 1u) & 3u] > RL) pair_cool = 16u;   // long lists here: full-wave cells for a while
 			if (wave == 0 && lane == 0) fbcnt[(r + 2u) & 3u] = 0;
+			// one copy of each cell routine in the instruction stream (the kernel must stay well inside the
+			// instruction cache): cells for the general path are collected in a wave-uniform bit mask
+			unsigned long long todo = 0;
 			if (!R.final_round && R.e0 > p2lim && pair_cool == 0u)
 			{
 				// two cells per step, one per half wave: pairs wave, wave + NWC
-				uint32_t ncell = 0, nfb = 0;
-#pragma unroll
-				for (int g = 0; g < DP_G / 2; ++g)
+#pragma nounroll
+				for (uint32_t i0 = 2u * wave; i0 < R.len; i0 += 2u * NWC)
 				{
-					uint32_t const i0 = 2u * (wave + (uint32_t) g * NWC);
-					if (i0 >= R.len) continue;
 					uint64_t const fb = dp_cell_pair(A, D, V, slot, i0, R, m, L, flags);
-					ncell += 2u;
-					if (fb & 1ull) { single_cell(i0); ++nfb; }
-					if (fb >> 32) { single_cell(i0 + 1u); ++nfb; }
+					if (fb & 1ull) todo |= 1ull << i0;
+					if (fb >> 32) todo |= 2ull << i0;
 				}
-				if (nfb && lane == 0) atomicAdd((uint32_t *) (fbcnt + (r & 3u)), nfb);
-				(void) ncell;
+				if (todo && lane == 0) atomicAdd((uint32_t *) (fbcnt + (r & 3u)), (uint32_t) __popcll(todo));
 			}
 			else
 			{
 				if (pair_cool) --pair_cool;
-#pragma unroll
-				for (int g = 0; g < DP_G; ++g)
-				{
-					uint32_t const i = wave + (uint32_t) g * NWC;
-					if (i >= R.len) continue;
-					single_cell(i);
-				}
+				for (uint32_t i = wave; i < R.len; i += NWC) todo |= 1ull << i;
+			}
+#pragma nounroll
+			while (todo)
+			{
+				uint32_t const i = (uint32_t) __builtin_ctzll(todo);
+				todo &= todo - 1ull;
+				single_cell(i);
 			}
 		}
 		else if (wave == DP_LOADER)
