@@ -146,6 +146,7 @@ struct fseq_ctx {
 
 	// geometry
 	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
+	bool stream_staged = false;              // streamed kernels lay tiles out in LDS before writing them (needs 64 KiB more)
 	uint32_t bsh = 0;                        // alignment packing: 8 >> bsh bits per symbol (fseq_kernels.hpp sym_bytes)
 	KernelSet ks{};
 	bool kernels_ready = false;
@@ -294,11 +295,13 @@ int prepare_geometry(fseq_ctx *c)
 		// rows beyond the LDS-resident configurations: the order streams through HBM / L2
 		if (sym_bytes(p.m, c->bsh) > STREAM_MAX_COLBYTES)
 			return fail(c, FSEQ_E_UNSUPPORTED, "more rows than this build handles (one packed column must fit LDS: 147456 bytes)");
-		size_t const lds = stream_lds_bytes(sym_bytes(p.m, c->bsh));
+		// the tile staging buffer of stream_pass (64 KiB) when the staged column leaves room for it
+		c->stream_staged = stream_lds_bytes(sym_bytes(p.m, c->bsh), true) <= LDS_LIMIT;
+		size_t const lds = stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged);
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK>, lds));
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream, lds));
-		HIP_TRY(c, allow_lds(k_chain_stream, carve_bytes(1, sizeof(StreamLds))));
+		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
 	}
 	else
 	{
@@ -496,8 +499,8 @@ void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint3
 {
 	fseq_params const &p = c->p;
 	if (c->use_stream)
-		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh)), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
-		                   c->npass, c->bsh, c->d_ws, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
+		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
+		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr);
 	else
@@ -509,8 +512,8 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
                   uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
 {
 	if (c->use_stream)
-		hipLaunchKernelGGL(k_chain_stream, dim3(grid), dim3(ST), carve_bytes(1, sizeof(StreamLds)), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
-		                   cols_per_block, c->d_ws, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
+		hipLaunchKernelGGL(k_chain_stream, dim3(grid), dim3(ST), stream_lds_bytes(0, true), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
+		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
 	else
 		c->ks.chain(c->stream, grid, c->ks.lds_chain, rank, keyd, nkeys, c->p.m, nb_total, G, cols_per_block, start_a, start_d, out_a, out_d,
 		            out_rank, out_keyd, out_nkeys);
@@ -589,7 +592,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		if (c->use_stream)
-			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws,
+			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d);
 		else
 			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
@@ -750,8 +753,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			for (size_t g0 = 0; g0 < grp.size(); g0 += cap)
 			{
 				size_t const cnt = std::min(cap, grp.size() - g0);
-				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh)), st, c->d_msa, c->ld, m, n, c->B,
-				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
+				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
+				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
 				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d);
 			}
 		}
