@@ -1,7 +1,7 @@
 // fseq_stream.hpp -- the column kernels for orders that do not fit LDS (m > 11,264 rows; BASELINE
 // config C4 has m = 100,000).  Same algorithm and the same partition_step as fseq_kernels.hpp, but
 // the order (a, d) of a block lives in a per-block HBM/L2 workspace (two buffers, ping-pong) and a
-// partition pass streams it through the workgroup tile by tile (T*E = 8192 rows) with a running
+// partition pass streams it through the workgroup tile by tile (T*E = 7168 rows) with a running
 // TileCarry.  A column pass = the bucket sizes counted off the staged column + one partition sweep (one
 // read and one write of a and d: SURVEY.md's 17 B/cell as real HBM traffic); a rank-digit or key pass
 // has a counting sweep over the order first.
@@ -12,7 +12,7 @@
 
 namespace fseq {
 
-constexpr int ST = 1024, SE = 8;
+constexpr int ST = 1024, SE = 7;                   // measured on m = 100,000: SE = 7 beats 4..9 (odd: conflict-free LDS staging; SE = 8 is 25 % slower)
 constexpr uint32_t SCAP = ST * SE;
 constexpr uint32_t STREAM_MAX_COLBYTES = 147456;   // column staging: one packed column (sym_bytes(m, bsh)) in LDS
 
