@@ -259,3 +259,56 @@ def test_config_c2_full_size_properties(pkg):
     for i in (0, len(red) // 3, len(red) - 1):
         a, d = ctx.boundary_state(i)
         assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
+
+
+def test_list_capacity_estimate_and_hint(pkg):
+    """Segments larger than the default list capacity (255): the capacity comes from the block boundary
+    states (no retry), a second run on the same context starts from it, and a tiny explicit capacity
+    still reaches the same result through retries."""
+    m, n, L = 3000, 1500, 30
+    msa = fso.synth_msa(fso.synth_spec(88, 300, 100, 4e-3), m, n)      # 300 founders: segment sizes of several hundred
+    ctx, ref = compare_long(pkg, msa, L, check_dp=True)
+    assert ref["max_segment_size"] > 255
+    t = ctx.timings()
+    assert t["list_cap_used"] > 255 and t["retries"] == 0
+    red = ctx.reduced_traceback().copy()
+    ctx.run()
+    t2 = ctx.timings()
+    assert t2["retries"] == 0 and t2["list_cap_used"] == t["list_cap_used"]
+    assert np.array_equal(ctx.reduced_traceback(), red)
+    ctx3, _ = compare_long(pkg, msa, L, check_dp=False, list_cap=16)
+    assert ctx3.timings()["retries"] >= 4
+
+
+def test_concurrent_contexts_on_one_device(pkg):
+    """Several alignments in flight on one GPU (one context, stream and host thread each, as bench.py's
+    batched figure runs them): every context still gets exactly its own oracle result."""
+    import threading
+    cases = []
+    for j, (m, n, L) in enumerate([(300, 4000, 25), (1000, 3000, 30), (2500, 6000, 50), (70, 2000, 9)]):
+        msa = fso.synth_msa(fso.synth_spec(500 + j, 8 + j, 200, 2e-3), m, n)
+        ctx = pkg.SegmentationContext(m, n, L)
+        ctx.set_sequences(msa)
+        cases.append((ctx, fso.segment_long(msa, L, threads=4)))
+    errors = []
+
+    def work(ctx):
+        try:
+            for _ in range(3):
+                ctx.run()
+        except Exception as e:                           # noqa: BLE001 - reported below
+            errors.append(e)
+
+    ths = [threading.Thread(target=work, args=(c,)) for c, _ in cases]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errors, errors
+    for ctx, ref in cases:
+        red = ctx.reduced_traceback()
+        assert ctx.result.max_segment_size == ref["max_segment_size"]
+        for f in ("lb", "rb", "segment_size"):
+            assert np.array_equal(red[f], ref["reduced"][f]), f
+        a, d = ctx.boundary_state(len(red) - 1)
+        assert np.array_equal(a, ref["a"][len(red) - 1]) and np.array_equal(d, ref["d"][len(red) - 1])
