@@ -69,7 +69,10 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+    "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
+
+JOIN_GREEDY, JOIN_BIPARTITE, JOIN_RANDOM = 0, 1, 2
 
 _lib = None
 
@@ -105,6 +108,11 @@ def load_library():
     L.fseq_join_greedy.argtypes = [vp, vp]
     L.fseq_greedy_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp]
     L.fseq_write_founders.argtypes = [vp, C.POINTER(vp), vp, C.c_char_p]
+    L.fseq_join_bipartite.argtypes = [vp, vp]
+    L.fseq_join_random.argtypes = [vp, C.c_uint32, vp]
+    L.fseq_bipartite_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp, vp]
+    L.fseq_random_join_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, C.c_uint32, vp]
+    L.fseq_write_segments.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_char_p]
     L.fseq_debug_dp.argtypes = [vp, vp, vp, vp]
     L.fseq_debug_block_state.argtypes = [vp, u64, vp, vp]
     L.fseq_debug_column_list.argtypes = [vp, u64, vp, vp, vp, vp, vp]
@@ -131,6 +139,37 @@ def greedy_match_host(m, max_segment_size, lb, rb, a, d):
     d = np.ascontiguousarray(d, dtype=np.uint32)
     perm = np.zeros((len(lb), max_segment_size), dtype=np.uint32)
     rc = L.fseq_greedy_match_host(m, max_segment_size, len(lb), lb.ctypes.data, rb.ctypes.data, a.ctypes.data, d.ctypes.data, perm.ctypes.data)
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return perm
+
+
+def bipartite_match_host(m, max_segment_size, lb, rb, a, d):
+    """bipartite_matcher::match on caller-supplied boundary states (host only).  Returns (permutations,
+    total matching weight between segments s and s+1)."""
+    L = load_library()
+    lb = np.ascontiguousarray(lb, dtype=np.uint64)
+    rb = np.ascontiguousarray(rb, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    d = np.ascontiguousarray(d, dtype=np.uint32)
+    perm = np.zeros((len(lb), max_segment_size), dtype=np.uint32)
+    weights = np.zeros(max(1, len(lb) - 1), dtype=np.int64)
+    rc = L.fseq_bipartite_match_host(m, max_segment_size, len(lb), lb.ctypes.data, rb.ctypes.data, a.ctypes.data, d.ctypes.data,
+                                     perm.ctypes.data, weights.ctypes.data)
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return perm, weights[:len(lb) - 1]
+
+
+def random_join_host(m, max_segment_size, lb, rb, a, d, seed):
+    """join_context::join_random_order_and_output on caller-supplied boundary states (host only)."""
+    L = load_library()
+    lb = np.ascontiguousarray(lb, dtype=np.uint64)
+    rb = np.ascontiguousarray(rb, dtype=np.uint64)
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    d = np.ascontiguousarray(d, dtype=np.uint32)
+    perm = np.zeros((len(lb), max_segment_size), dtype=np.uint32)
+    rc = L.fseq_random_join_host(m, max_segment_size, len(lb), lb.ctypes.data, rb.ctypes.data, a.ctypes.data, d.ctypes.data, seed, perm.ctypes.data)
     if rc != FSEQ_OK:
         raise FseqError(rc, L.fseq_strerror(rc).decode())
     return perm
@@ -239,6 +278,22 @@ class SegmentationContext:
         perm = np.zeros((self.result.segment_count, self.result.max_segment_size), dtype=np.uint32)
         self._check(self.L.fseq_join_greedy(self.h, perm.ctypes.data))
         return perm
+
+    def join_bipartite(self):
+        perm = np.zeros((self.result.segment_count, self.result.max_segment_size), dtype=np.uint32)
+        self._check(self.L.fseq_join_bipartite(self.h, perm.ctypes.data))
+        return perm
+
+    def join_random(self, seed=0):
+        perm = np.zeros((self.result.segment_count, self.result.max_segment_size), dtype=np.uint32)
+        self._check(self.L.fseq_join_random(self.h, seed, perm.ctypes.data))
+        return perm
+
+    def write_segments(self, msa, joining, path):
+        """--output-segments for the joining method (JOIN_GREEDY / JOIN_BIPARTITE / JOIN_RANDOM)."""
+        assert msa.dtype == np.uint8 and msa.flags["C_CONTIGUOUS"] and msa.shape == (self.m, self.n)
+        rows = (C.c_void_p * self.m)(*[msa.ctypes.data + r * msa.strides[0] for r in range(self.m)])
+        self._check(self.L.fseq_write_segments(self.h, rows, joining, path.encode() if path else None))
 
     def write_founders(self, msa, permutations, path):
         """msa: the raw input rows as a C-contiguous uint8 array [m, n]."""

@@ -1105,6 +1105,124 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 	return FSEQ_OK;
 }
 
+// boundary states of all merged segments on the host (what join_context reads from the pbwt samples)
+static int fetch_boundary_states(fseq_ctx *c, std::vector<uint32_t> &A, std::vector<uint32_t> &D, std::vector<JoinSegment> &segs)
+{
+	if (!c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
+	(void) hipSetDevice(c->p.device);
+	size_t const m = c->p.m, S = c->segments.size();
+	A.resize(S * m); D.resize(S * m);
+	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
+	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
+	segs.resize(S);
+	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
+	return FSEQ_OK;
+}
+
+int fseq_join_bipartite(fseq_ctx *c, uint32_t *permutations)
+{
+	if (!c || !permutations) return FSEQ_E_ARG;
+	std::vector<uint32_t> A, D;
+	std::vector<JoinSegment> segs;
+	int const rc = fetch_boundary_states(c, A, D, segs);
+	if (rc) return rc;
+	bipartite_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations);
+	return FSEQ_OK;
+}
+
+int fseq_join_random(fseq_ctx *c, uint32_t seed, uint32_t *permutations)
+{
+	if (!c || !permutations) return FSEQ_E_ARG;
+	std::vector<uint32_t> A, D;
+	std::vector<JoinSegment> segs;
+	int const rc = fetch_boundary_states(c, A, D, segs);
+	if (rc) return rc;
+	random_join(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), seed, permutations);
+	return FSEQ_OK;
+}
+
+int fseq_bipartite_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                              uint32_t const *a, uint32_t const *d, uint32_t *permutations, int64_t *weights)
+{
+	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
+	std::vector<JoinSegment> segs(n_segments);
+	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
+	std::vector<int64_t> w;
+	bipartite_match(m, max_segment_size, segs, a, d, permutations, nullptr, &w);
+	if (weights) std::copy(w.begin(), w.end(), weights);
+	return FSEQ_OK;
+}
+
+int fseq_random_join_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                          uint32_t const *a, uint32_t const *d, uint32_t seed, uint32_t *permutations)
+{
+	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
+	std::vector<JoinSegment> segs(n_segments);
+	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
+	random_join(m, max_segment_size, segs, a, d, seed, permutations);
+	return FSEQ_OK;
+}
+
+int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, char const *path)
+{
+	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (joining != FSEQ_JOIN_GREEDY && !rows) return FSEQ_E_ARG;
+	std::vector<uint32_t> A, D;
+	std::vector<JoinSegment> segs;
+	if (joining != FSEQ_JOIN_GREEDY)
+	{
+		int const rc = fetch_boundary_states(c, A, D, segs);
+		if (rc) return rc;
+	}
+	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
+	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the segments output file");
+	size_t const m = c->p.m, S = segs.size();
+	uint32_t const X = c->res.max_segment_size;
+	if (FSEQ_JOIN_BIPARTITE == joining)
+	{
+		// segmentation_dp_arg.cc:59-104
+		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE\tSEQUENCES\tCOPIED_FROM\n", f);
+		for (size_t s = 0; s < S; ++s)
+		{
+			uint32_t const *a = A.data() + s * m, *d = D.data() + s * m;
+			auto const texts = create_segment_texts((uint32_t) m, X, a, prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, true));
+			for (size_t i = 0; i < texts.size(); ++i)
+			{
+				SegmentText const &tx = texts[i];
+				fprintf(f, "%zu\t%llu\t%llu\t%u\t", s, (unsigned long long) segs[s].lb, (unsigned long long) segs[s].rb, c->segments[s].segment_size);
+				uint32_t const rep = texts[tx.row_number(i)].sequence_indices.front();    // segment_text::write_text
+				fwrite(rows[rep] + segs[s].lb, 1, segs[s].rb - segs[s].lb, f);
+				fputc('\t', f);
+				for (size_t k = 0; k < tx.sequence_indices.size(); ++k) fprintf(f, k ? ",%u" : "%u", tx.sequence_indices[k]);
+				if (tx.is_copied()) fprintf(f, "\t%zu\n", tx.copied_from); else fputs("\t-\n", f);
+			}
+		}
+	}
+	else
+	{
+		// segmentation_dp_arg.cc:13-56; with greedy joining the copy-number matrix is empty
+		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n", f);
+		for (size_t s = 0; FSEQ_JOIN_RANDOM == joining && s < S; ++s)
+		{
+			uint32_t const *a = A.data() + s * m, *d = D.data() + s * m;
+			auto const cn = prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, false);
+			uint32_t prev = 0;
+			for (auto const &x : cn)
+			{
+				fprintf(f, "%zu\t%llu\t%llu\t%u\t%u\t%u\t", s, (unsigned long long) segs[s].lb, (unsigned long long) segs[s].rb, c->segments[s].segment_size,
+				        x.substring_idx, x.copy_number - prev);
+				prev = x.copy_number;
+				fwrite(rows[x.substring_idx] + segs[s].lb, 1, segs[s].rb - segs[s].lb, f);
+				fputc('\n', f);
+			}
+		}
+	}
+	fflush(f);
+	if (f != stdout) fclose(f);
+	return FSEQ_OK;
+}
+
 int fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
                            uint32_t const *a, uint32_t const *d, uint32_t *permutations)
 {

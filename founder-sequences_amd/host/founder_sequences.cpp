@@ -4,8 +4,8 @@
 // (founder-sequences/cmdline.ggo:12-29, founder-sequences/main.cc:68-150) and the controller's
 // input checks and outputs (founder-sequences/generate_context.cc:64-106,161-200,393-433).
 // Host C++17 only; all segmentation work happens behind fseq_run_segmentation on the GPU.
-// Joining: greedy (greedy_matcher.cc) is built; bipartite-matching (needs Lemon 1.3.1's
-// MaxWeightedPerfectMatching) and random are not in this build and say so.
+// Joining: greedy (greedy_matcher.cc), bipartite-matching (bipartite_matcher.cc; an own Kuhn-Munkres
+// in place of Lemon 1.3.1's MaxWeightedPerfectMatching) and random (join_context.cc:259-289).
 #include <fseq.h>
 
 #include <getopt.h>
@@ -158,12 +158,6 @@ int main(int argc, char **argv)
 	if (!(0 <= seed && (unsigned long) seed <= std::numeric_limits<std::uint_fast32_t>::max()))
 	{ std::cerr << "Random seed out of bounds." << std::endl; return EXIT_FAILURE; }
 	if (sample_rate <= 0) { std::cerr << "PBWT sample rate multiplier must be non-negative." << std::endl; return EXIT_FAILURE; }
-	if (joining::GREEDY != join)
-	{
-		std::cerr << "Segment joining method '" << (joining::RANDOM == join ? "random" : "bipartite-matching")
-		          << "' is not available in this build; use --segment-joining=greedy." << std::endl;
-		return EXIT_FAILURE;
-	}
 
 	// generate_context.cc:64-106
 	std::cerr << "Loading the input…" << std::flush;
@@ -237,16 +231,22 @@ int main(int argc, char **argv)
 	          << " segments the maximum size of which was " << res.max_segment_size << '.' << std::endl;
 	std::cerr << "Joining the remaining segments…" << std::endl;
 	std::vector<uint32_t> perm((size_t) res.segment_count * res.max_segment_size);
-	if (FSEQ_OK != (rc = fseq_join_greedy(ctx, perm.data()))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
+	switch (join)                                               // join_context.cc:130-160
+	{
+		case joining::GREEDY: rc = fseq_join_greedy(ctx, perm.data()); break;
+		case joining::BIPARTITE_MATCHING: rc = fseq_join_bipartite(ctx, perm.data()); break;
+		case joining::RANDOM: rc = fseq_join_random(ctx, (uint32_t) seed, perm.data()); break;
+	}
+	if (FSEQ_OK != rc) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	std::cerr << "Outputting the founders…" << std::endl;
 	if (FSEQ_OK != (rc = fseq_write_founders(ctx, rows.data(), perm.data(), out_founders))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	if (out_segments)
 	{
-		// With greedy joining the copy-number matrix is empty, so only the header is written
-		// (join_context.cc:57-61, greedy_matcher.cc:468-476, segmentation_dp_arg.cc:27-29)
+		// segmentation_dp_arg.cc:13-104; with greedy joining the copy-number matrix is empty, so only the
+		// header is written (join_context.cc:57-61, greedy_matcher.cc:468-476)
 		std::cerr << "Outputting the segments…" << std::endl;
-		std::ostream &ss = *open_out(out_segments, segments_file);
-		ss << "SEGMENT" "\t" "LB" "\t" "RB" "\t" "SIZE" "\t" "SUBSEQUENCE_NUMBER" "\t" "COPY_NUMBER" "\t" "SUBSEQUENCE" "\n" << std::flush;
+		int const how = joining::GREEDY == join ? FSEQ_JOIN_GREEDY : (joining::RANDOM == join ? FSEQ_JOIN_RANDOM : FSEQ_JOIN_BIPARTITE);
+		if (FSEQ_OK != (rc = fseq_write_segments(ctx, rows.data(), how, out_segments))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	}
 	std::cerr << "Done." << std::endl;
 	fseq_destroy(ctx);

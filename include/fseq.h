@@ -147,6 +147,28 @@ int  fseq_join_greedy(fseq_ctx *ctx, uint32_t *permutations);
  * lb[i], rb[i]; a, d: n_segments x m.  Used by the CPU tests of the host logic. */
 int  fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
                             uint32_t const *a, uint32_t const *d, uint32_t *permutations);
+/* ---- the non-greedy joiners, host C++ as in the reference ----
+ * replaces: join_context::join_with_bipartite_matching -> bipartite_matcher::match (join_context.cc:231-236,
+ * bipartite_matcher.cc:17-151, create_segment_texts_task.cc:15-81, merge_segments_task.cc:133-195 with
+ * INTERSECTION scoring, main.cc:126).  Lemon's MaxWeightedPerfectMatching is replaced by an own
+ * Kuhn-Munkres: every matching has the optimal total weight; which optimal matching Lemon picks is
+ * not reproduced (parity unpinned). */
+int  fseq_join_bipartite(fseq_ctx *ctx, uint32_t *permutations);
+/* replaces: join_context::join_random_order_and_output (join_context.cc:259-289): std::mt19937(seed),
+ * one std::shuffle per segment. */
+int  fseq_join_random(fseq_ctx *ctx, uint32_t seed, uint32_t *permutations);
+/* The same joiners on caller-supplied boundary states (no context, no device).  weights (optional):
+ * n_segments - 1 total matching weights. */
+int  fseq_bipartite_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                               uint32_t const *a, uint32_t const *d, uint32_t *permutations, int64_t *weights);
+int  fseq_random_join_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
+                           uint32_t const *a, uint32_t const *d, uint32_t seed, uint32_t *permutations);
+/* replaces: join_context::output_segments -> output_segments (segmentation_dp_arg.cc:13-104): the
+ * --output-segments text file for the given joining method (greedy: the header line only, SURVEY.md
+ * F5; bipartite: one line per segment text; random: one line per distinct substring with its copy
+ * number).  path NULL or "-" = stdout. */
+enum { FSEQ_JOIN_GREEDY = 0, FSEQ_JOIN_BIPARTITE = 1, FSEQ_JOIN_RANDOM = 2 };
+int  fseq_write_segments(fseq_ctx *ctx, uint8_t const *const *rows, int joining, char const *path);
 /* replaces: join_context::output_in_permutation_order (join_context.cc:333-356): max_segment_size
  * lines; line r = concatenation over segments of rows[permutations[s][r]][lb_s, rb_s).  rows = the
  * raw input sequences.  path NULL or "-" = stdout. */

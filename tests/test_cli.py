@@ -34,8 +34,8 @@ def test_validation_messages_and_exit_codes(cli, tmp_path):
     assert r.returncode == 1 and b"option required" in r.stderr
     r = run(cli, "-i", "x", "-s", "5", "-j", "nonsense")
     assert r.returncode == 1
-    r = run(cli, "-i", "x", "-s", "5")                       # default joining is bipartite-matching (cmdline.ggo:20-22)
-    assert r.returncode == 1 and b"bipartite-matching" in r.stderr
+    r = run(cli, "-i", "x", "-s", "5")                       # default joining is bipartite-matching (cmdline.ggo:20-22): accepted
+    assert r.returncode == 1 and b"Unable to open the input file" in r.stderr
     r = run(cli, "--help")
     assert r.returncode == 0 and b"--segment-length-bound" in r.stdout and b"--pbwt-sample-rate" in r.stdout
     # unequal lengths: generate_context.cc:83-106
@@ -102,3 +102,37 @@ def test_end_to_end_list_file_and_fasta(cli, tmp_path):
     first, runlen = fso.segment_short(short)
     assert r.returncode == 0 and r.stdout == b"".join(bytes(short[i]) + b"\n" for i in first)
     assert (tmp_path / "sp.txt").read_bytes() == b"SEQUENCE\n" + b"".join(b"%d\n" % x for x in runlen)
+
+
+@pytest.mark.gpu
+def test_end_to_end_default_and_random_joining(cli, tmp_path):
+    """The reference's default joiner (bipartite-matching, cmdline.ggo:20-22) and --segment-joining=random through
+    the CLI: founders are max_segment_size lines of input substrings, the segments files have the two
+    formats of segmentation_dp_arg.cc:13-104."""
+    m, n, L = 40, 600, 12
+    msa = np.ascontiguousarray(fso.synth_msa(fso.synth_spec(61, 5, 90, 6e-3), m, n))
+    res = fso.segment_long(msa, L)
+    X, red = res["max_segment_size"], res["reduced"]
+    fa = tmp_path / "in.fa"
+    with open(fa, "wb") as f:
+        for i in range(m):
+            f.write(b">s%d\n" % i + bytes(msa[i]) + b"\n")
+    for extra, header in (((), b"SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE\tSEQUENCES\tCOPIED_FROM\n"),
+                          (("-j", "random", "--random-seed", "5"), b"SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n")):
+        founders = tmp_path / "founders.txt"
+        segments = tmp_path / "segments.txt"
+        r = run(cli, "-i", str(fa), "-f", "FASTA", "-s", str(L), "-o", str(founders), "-e", str(segments), *extra)
+        assert r.returncode == 0, r.stderr
+        lines = founders.read_bytes().split(b"\n")
+        assert lines[-1] == b"" and len(lines) - 1 == X
+        for line in lines[:-1]:
+            assert len(line) == n
+            for s in range(len(red)):
+                lb, rb = int(red["lb"][s]), int(red["rb"][s])
+                assert any(bytes(msa[i, lb:rb]) == line[lb:rb] for i in range(m))
+        # every distinct substring of every segment is in some founder
+        for s in range(len(red)):
+            lb, rb = int(red["lb"][s]), int(red["rb"][s])
+            assert {bytes(msa[i, lb:rb]) for i in range(m)} == {line[lb:rb] for line in lines[:-1]}
+        seg = segments.read_bytes()
+        assert seg.startswith(header) and seg.count(b"\n") > len(red)

@@ -77,3 +77,102 @@ def test_founders_through_the_gpu_path(pkg, tmp_path):
         ctx.write_founders(msa, perm, path)
         got = open(path, "rb").read().split(b"\n")
         assert got[-1] == b"" and got[:-1] == go.founders(msa, segs, ref, res["max_segment_size"])
+
+
+# ---- non-greedy joiners: order-free checks against oracle/join_oracle.py -------------
+import join_oracle as jo
+from collections import Counter
+
+N3_CASES = CASES + [(120, 900, 10, 9, 70, 1e-2, 77)]
+
+
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed", N3_CASES)
+def test_bipartite_joiner_slots_and_optimal_matchings(pkg, m, n, L, K, Brec, mu, seed):
+    msa, res = _segment(m, n, L, K, Brec, mu, seed)
+    red, X = res["reduced"], res["max_segment_size"]
+    perm, weights = pkg.bipartite_match_host(m, X, red["lb"], red["rb"], res["a"], res["d"])
+    assert perm.shape == (len(red), X) and len(weights) == len(red) - 1
+    cls = [jo.classes(m, int(red["lb"][s]), res["a"][s], res["d"][s]) for s in range(len(red))]
+    slots = []
+    for s in range(len(red)):
+        assert len(cls[s]) == red["segment_size"][s]
+        sl = jo.slot_classes(perm[s], cls[s])                   # every slot shows a class representative
+        cnt = Counter(sl)
+        assert set(cnt) == set(range(len(cls[s])))               # every distinct substring is present
+        assert Counter((len(cls[s][i]), c) for i, c in cnt.items()) == jo.bipartite_copy_multiset(m, X, cls[s])
+        slots.append(sl)
+    for s in range(1, len(red)):
+        best, base = jo.optimal_weight(slots[s - 1], cls[s - 1], slots[s], cls[s])
+        realised = sum(int(base[l, r]) for l, r in zip(slots[s - 1], slots[s]))   # founder i keeps slot i
+        assert realised == best == int(weights[s - 1])
+
+
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed", N3_CASES[:5])
+def test_random_joiner_copy_numbers_and_seed(pkg, m, n, L, K, Brec, mu, seed):
+    msa, res = _segment(m, n, L, K, Brec, mu, seed)
+    red, X = res["reduced"], res["max_segment_size"]
+    p0 = pkg.random_join_host(m, X, red["lb"], red["rb"], res["a"], res["d"], 0)
+    p0b = pkg.random_join_host(m, X, red["lb"], red["rb"], res["a"], res["d"], 0)
+    p1 = pkg.random_join_host(m, X, red["lb"], red["rb"], res["a"], res["d"], 12345)
+    assert np.array_equal(p0, p0b)
+    for s in range(len(red)):
+        cls = jo.classes(m, int(red["lb"][s]), res["a"][s], res["d"][s])
+        first = {c[0]: len(c) for c in cls}                      # random slots hold the run's first row in pBWT order
+        for p in (p0, p1):
+            cnt = Counter(int(r) for r in p[s])
+            assert set(cnt) == set(first)
+            assert Counter((first[r], c) for r, c in cnt.items()) == jo.random_copy_multiset(X, cls)
+    if X > 2 and len(red) > 1:
+        assert not np.array_equal(p0, p1)
+
+
+def test_kuhn_munkres_small_known_answer(pkg):
+    # two segments, three classes each; the identity pairing is the unique optimum (weights 3 + 2 + 2)
+    m = 7
+    a = np.array([[0, 1, 2, 3, 4, 5, 6], [0, 1, 2, 5, 6, 3, 4]], dtype=np.uint32)
+    d = np.array([[10, 0, 0, 5, 0, 7, 0], [20, 10, 10, 15, 10, 18, 10]], dtype=np.uint32)   # classes {0,1,2} {3,4} {5,6} | {0,1,2} {5,6} {3,4}
+    perm, weights = pkg.bipartite_match_host(m, 3, [0, 10], [10, 20], a, d)
+    assert weights.tolist() == [7]
+    assert perm.tolist() == [[0, 3, 5], [0, 3, 5]]
+
+
+@pytest.mark.gpu
+def test_nongreedy_joiners_through_the_gpu_path(pkg, tmp_path):
+    m, n, L, K, Brec, mu, seed = CASES[4]
+    msa, res = _segment(m, n, L, K, Brec, mu, seed)
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.set_sequences(msa)
+    ctx.run()
+    red, X = res["reduced"], res["max_segment_size"]
+    host_perm, _ = pkg.bipartite_match_host(m, X, red["lb"], red["rb"], res["a"], res["d"])
+    assert np.array_equal(ctx.join_bipartite(), host_perm)
+    assert np.array_equal(ctx.join_random(7), pkg.random_join_host(m, X, red["lb"], red["rb"], res["a"], res["d"], 7))
+    # founders: every line is a concatenation of input substrings, one per segment
+    path = str(tmp_path / "founders_bp.txt")
+    ctx.write_founders(msa, host_perm, path)
+    lines = open(path, "rb").read().split(b"\n")[:-1]
+    assert len(lines) == X and all(len(x) == n for x in lines)
+    # segments files: bipartite = X lines per segment (texts, row lists, copied-from); random = one line per class
+    pb = str(tmp_path / "segments_bp.txt")
+    ctx.write_segments(msa, pkg.JOIN_BIPARTITE, pb)
+    rows = [x.split("\t") for x in open(pb).read().split("\n")[:-1]]
+    assert rows[0] == ["SEGMENT", "LB", "RB", "SIZE", "SUBSEQUENCE", "SEQUENCES", "COPIED_FROM"]
+    assert len(rows) - 1 == X * len(red)
+    for r in rows[1:]:
+        s = int(r[0])
+        assert (int(r[1]), int(r[2]), int(r[3])) == (int(red["lb"][s]), int(red["rb"][s]), int(red["segment_size"][s]))
+        if r[6] == "-":
+            ids = [int(x) for x in r[5].split(",")]
+            assert ids == sorted(ids) and all(bytes(msa[i, int(r[1]):int(r[2])]).decode() == r[4] for i in ids)
+        else:
+            assert r[5] == ""
+    pr = str(tmp_path / "segments_rnd.txt")
+    ctx.write_segments(msa, pkg.JOIN_RANDOM, pr)
+    rows = [x.split("\t") for x in open(pr).read().split("\n")[:-1]]
+    assert rows[0] == ["SEGMENT", "LB", "RB", "SIZE", "SUBSEQUENCE_NUMBER", "COPY_NUMBER", "SUBSEQUENCE"]
+    per_seg = Counter(int(r[0]) for r in rows[1:])
+    assert all(per_seg[s] == red["segment_size"][s] for s in range(len(red)))
+    assert all(sum(int(r[5]) for r in rows[1:] if int(r[0]) == s) == X for s in range(len(red)))
+    pg = str(tmp_path / "segments_greedy.txt")
+    ctx.write_segments(msa, pkg.JOIN_GREEDY, pg)
+    assert open(pg).read() == "SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n"
