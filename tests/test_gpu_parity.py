@@ -312,3 +312,28 @@ def test_concurrent_contexts_on_one_device(pkg):
             assert np.array_equal(red[f], ref["reduced"][f]), f
         a, d = ctx.boundary_state(len(red) - 1)
         assert np.array_equal(a, ref["a"][len(red) - 1]) and np.array_equal(d, ref["d"][len(red) - 1])
+
+
+def test_config_c3_full_size_matches_oracle(pkg):
+    """BASELINE config C3 at full size (m = 2,504 x n = 1,000,000, L = 100: the pipelined DP schedule, 10^6
+    DP cells, ~10,000 segments): merged segments and sampled boundary states against the CPU oracle
+    (about 20 s of CPU), plus the size-independent properties."""
+    c = fso.CONFIGS["C3"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    tb = ctx.traceback()
+    red = ctx.reduced_traceback()
+    assert tb["lb"][0] == 0 and tb["rb"][-1] == n
+    assert np.array_equal(tb["lb"][1:], tb["rb"][:-1]) and (tb["rb"] - tb["lb"]).min() >= L
+    assert red["lb"][0] == 0 and red["rb"][-1] == n and np.array_equal(red["lb"][1:], red["rb"][:-1])
+    assert res.max_segment_size == tb["segment_size"].max() == tb["segment_max_size"][-1] < m
+    msa = ctx.get_sequences()                                 # the device generator's alignment (checked equal to the host one elsewhere)
+    ref = fso.segment_long(msa, L, threads=8)
+    assert ref["max_segment_size"] == res.max_segment_size
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f])
+    for i in (0, len(red) // 7, len(red) // 2, len(red) - 1):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
