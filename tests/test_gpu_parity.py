@@ -337,3 +337,25 @@ def test_config_c3_full_size_matches_oracle(pkg):
     for i in (0, len(red) // 7, len(red) // 2, len(red) - 1):
         a, d = ctx.boundary_state(i)
         assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
+
+
+@pytest.mark.parametrize("name", ["one_symbol", "identical_rows", "two_rows", "two_groups", "column_of_gaps"])
+def test_degenerate_alignments(pkg, name):
+    """Alphabets of one symbol, identical rows, two rows, two constant groups, a rare symbol in one column."""
+    rng = np.random.default_rng(3)
+    if name == "one_symbol":
+        msa = np.full((20, 300), ord("A"), dtype=np.uint8)
+    elif name == "identical_rows":
+        msa = np.tile(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(1, 400)), (50, 1))
+    elif name == "two_rows":
+        msa = rng.choice(np.frombuffer(b"AC", dtype=np.uint8), size=(2, 500))
+        msa[1] = msa[0]
+        msa[1, 250] = ord("G")
+    elif name == "two_groups":
+        msa = np.empty((64, 256), dtype=np.uint8)
+        msa[:32] = ord("A")
+        msa[32:] = ord("T")
+    else:
+        msa = np.tile(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(1, 300)), (30, 1))
+        msa[7, 150] = ord("-")
+    compare_long(pkg, np.ascontiguousarray(msa), 10, block_len=37)
