@@ -122,6 +122,10 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+#ifndef FSEQ_X_FLOOR_VALUE
+#define FSEQ_X_FLOOR_VALUE 63u
+#endif
+constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column list capacity tried (the estimate and the retries raise it)
 
 double now_ms()
 {
@@ -529,7 +533,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	KernelSet const &ks = c->ks;
 	int rc;
 
-	uint32_t X = p.list_cap ? p.list_cap : std::max(255u, c->X_hint);
+	uint32_t X = p.list_cap ? p.list_cap : std::max(FSEQ_X_FLOOR, c->X_hint);
 	c->tm = fseq_timings{};
 	c->tm.block_len = c->B;
 	c->tm.n_blocks = c->nblocks;
