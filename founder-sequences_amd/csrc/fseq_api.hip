@@ -163,7 +163,9 @@ struct fseq_ctx {
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
 	uint32_t *d_srank = nullptr, *d_skeyd = nullptr, *d_snkeys = nullptr, *d_sstate_a = nullptr, *d_sstate_d = nullptr;
-	uint32_t chain_G = 0, n_super = 0;
+	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
+	uint32_t chain_G = 0, n_super = 0;       // super-blocks of chain_G blocks
+	uint32_t chain_G2 = 0, n_hyper = 0;      // third level: hyper-blocks of chain_G2 super-blocks (0 = two levels only)
 	uint2 *d_ent = nullptr;
 	uint4 *d_hdr = nullptr;
 	uint32_t X = 0, stride = 0;
@@ -277,11 +279,23 @@ int prepare_geometry(fseq_ctx *c)
 	if (c->B > p.n) c->B = (uint32_t) p.n;
 	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
 	{
-		// super-blocks of G ~ sqrt(nblocks) blocks: serial depth of phase B = G + nblocks/G + G key blocks
+		// two levels: super-blocks of G ~ sqrt(nblocks) blocks, serial depth of phase B = G + nblocks/G + G key
+		// blocks; from 216 blocks on three levels (G ~ cbrt(nblocks): 5 launches of ~G serial steps)
 		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) c->nblocks));
+		c->chain_G2 = 0; c->n_hyper = 0;
+		if (c->nblocks >= 216 && !getenv("FSEQ_TWO_LEVEL_CHAIN"))
+		{
+			g = (uint32_t) std::ceil(std::cbrt((double) c->nblocks));
+			while ((uint64_t) g * g * g < c->nblocks) ++g;
+		}
 		if (g < 1) g = 1;
 		c->chain_G = g;
 		c->n_super = (c->nblocks + g - 1) / g;
+		if (c->nblocks >= 216 && !getenv("FSEQ_TWO_LEVEL_CHAIN"))
+		{
+			c->chain_G2 = g;
+			c->n_hyper = (c->n_super + g - 1) / g;
+		}
 	}
 	uint32_t n2 = 1;
 	while (n2 < p.m) n2 <<= 1;
@@ -336,6 +350,14 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_snkeys, c->n_super))) return rc;
 		if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
+		if (c->n_hyper)
+		{
+			if ((rc = dev_alloc(c, &c->d_hrank, (size_t) c->n_hyper * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_hkeyd, (size_t) c->n_hyper * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_hnkeys, c->n_hyper))) return rc;
+			if ((rc = dev_alloc(c, &c->d_hstate_a, ((size_t) c->n_hyper + 1) * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_hstate_d, ((size_t) c->n_hyper + 1) * m))) return rc;
+		}
 		if ((rc = dev_alloc(c, &c->d_hdr, p.n))) return rc;
 		if ((rc = dev_alloc(c, &c->d_flags, 256))) return rc;
 		if ((rc = dev_alloc(c, &c->d_recent, c->nblocks + 1))) return rc;
@@ -387,6 +409,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
+	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a); dev_free(&c->d_ss_d); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
@@ -546,9 +569,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	launch_rank(c, c->nblocks, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	{
-		// phase B, two-level: compose groups of G blocks into super-blocks (parallel), chain the
-		// super-blocks (one workgroup), expand every super-block to its block boundaries (parallel)
-		uint32_t const G = c->chain_G, NSB = c->n_super;
+		// phase B: compose groups of G blocks into super-blocks (parallel), -- three levels:
+		// compose groups of G2 super-blocks into hyper-blocks (parallel) -- chain the top level (one
+		// workgroup), expand every group back to the boundaries of the level below (parallel)
+		uint32_t const G = c->chain_G, NSB = c->n_super, G2 = c->chain_G2, NH = c->n_hyper;
 		if (NSB <= 1)
 			launch_chain(c, 1, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, c->nblocks, c->B, nullptr, nullptr,
 			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
@@ -556,8 +580,18 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		{
 			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, nullptr, nullptr,
 			             nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys);
-			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
-			             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
+			if (NH > 1)
+			{
+				launch_chain(c, NH, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, nullptr, nullptr,
+				             nullptr, nullptr, c->d_hrank, c->d_hkeyd, c->d_hnkeys);
+				launch_chain(c, 1, c->d_hrank, c->d_hkeyd, c->d_hnkeys, NH, NH, (uint64_t) G2 * G * c->B, nullptr, nullptr,
+				             c->d_hstate_a, c->d_hstate_d, nullptr, nullptr, nullptr);
+				launch_chain(c, NH, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, c->d_hstate_a, c->d_hstate_d,
+				             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
+			}
+			else
+				launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
+				             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
 			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
 			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
 		}

@@ -77,6 +77,8 @@ CASES = [
     (1, 50, 5, 1, 10, 0.0, 26, 0, 8),                    # single row: cannot reduce
     (9000, 1200, 40, 16, 400, 2e-4, 27, 0, 128),         # 16-bit LDS state (m > 7168), sigma = 4
     (10000, 2500, 100, 32, 500, 1e-4, 0x5EED0005, 1, 0), # BASELINE config C5 rows (m = 10,000, sigma = 16), shortened columns
+    (300, 5000, 10, 8, 200, 2e-3, 28, 0, 16),            # 313 blocks: three-level phase B (7 x 7 x 7)
+    (64, 4000, 6, 5, 90, 5e-3, 29, 0, 4),                # 1000 blocks of 4 columns: three levels, ragged last groups
 ]
 
 
@@ -117,6 +119,7 @@ def test_kernel_configuration_boundaries(pkg, m):
     (100000, 160, 10, 64, 50, 5e-5, 0x5EED0004, 0, 0),   # BASELINE config C4 rows, shortened columns
     (200001, 48, 8, 30, 16, 5e-5, 44, 0, 0),             # 2-bit packed columns: 50,001 bytes staged per column
     (11300, 2400, 4, 3, 40, 2e-3, 45, 0, 1200),          # two blocks, many segments: pass 2 in several launches
+    (12000, 3000, 10, 12, 200, 3e-4, 46, 0, 12),         # 250 blocks: three-level phase B on the streamed kernels
 ])
 def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     """m > 11,264: the block order streams through HBM/L2 in tiles (fseq_stream.hpp)."""
