@@ -362,3 +362,35 @@ def test_degenerate_alignments(pkg, name):
         msa = np.tile(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=(1, 300)), (30, 1))
         msa[7, 150] = ord("-")
     compare_long(pkg, np.ascontiguousarray(msa), 10, block_len=37)
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("FSEQ_TEST_C4"), reason="125 GB of HBM and ~1 minute: set FSEQ_TEST_C4=1")
+def test_config_c4_full_size_properties(pkg):
+    """BASELINE config C4 at full size on one GPU (m = 100,000 x n = 5,000,000, 2 bits per cell): the
+    size-independent properties, and oracle parity of the DP on a column prefix of the same alignment."""
+    c = fso.CONFIGS["C4"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    tb = ctx.traceback()
+    red = ctx.reduced_traceback()
+    assert tb["lb"][0] == 0 and tb["rb"][-1] == n
+    assert np.array_equal(tb["lb"][1:], tb["rb"][:-1]) and (tb["rb"] - tb["lb"]).min() >= L
+    assert red["lb"][0] == 0 and red["rb"][-1] == n and np.array_equal(red["lb"][1:], red["rb"][:-1])
+    assert set(red["rb"].tolist()) <= set(tb["rb"].tolist())
+    assert res.max_segment_size == tb["segment_size"].max() == tb["segment_max_size"][-1] < m
+    assert red["segment_size"].max() <= res.max_segment_size
+    for i in (0, len(red) // 3, len(red) - 1):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(np.sort(a), np.arange(m))
+        assert int((d > red["lb"][i]).sum()) == red["segment_size"][i]
+        assert d[0] == red["rb"][i]
+    # the DP array on the first columns does not depend on the columns behind them: compare with the oracle
+    # run on a prefix (cells with end <= ncols - L have seen everything they depend on)
+    ncols = 2400
+    lb, mx, sz = ctx.debug_dp()
+    ref = fso.segment_long(ctx.get_sequences(0, ncols), L, keep_dp=True, threads=8)
+    k = ncols - 2 * L                                        # DP entries of regular cells of the prefix run
+    assert np.array_equal(mx[:k], ref["dp"]["segment_max_size"][:k])
+    assert np.array_equal(lb[:k], ref["dp"]["lb"][:k].astype(np.uint32))
