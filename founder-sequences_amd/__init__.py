@@ -69,7 +69,7 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
-    "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
+    "fseq_set_device_columns_packed", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
 
 JOIN_GREEDY, JOIN_BIPARTITE, JOIN_RANDOM = 0, 1, 2
@@ -98,6 +98,7 @@ def load_library():
     L.fseq_set_rows.argtypes = [vp, C.POINTER(vp)]
     L.fseq_set_matrix.argtypes = [vp, vp, sz, sz]
     L.fseq_set_device_columns.argtypes = [vp, vp, sz, C.c_uint32]
+    L.fseq_set_device_columns_packed.argtypes = [vp, vp, sz, C.c_uint32, C.c_uint32]
     L.fseq_generate_synthetic.argtypes = [vp, C.POINTER(SynthSpec)]
     L.fseq_get_matrix.argtypes = [vp, u64, u64, vp, sz, sz]
     L.fseq_run_segmentation.argtypes = [vp, C.POINTER(Result)]
@@ -223,6 +224,10 @@ class SegmentationContext:
     def set_device_columns(self, ptr, ld, sigma, keepalive=None):
         self._keep = keepalive
         self._check(self.L.fseq_set_device_columns(self.h, ptr, ld, sigma))
+
+    def set_device_columns_packed(self, ptr, ld_bytes, sigma, bits, keepalive=None):
+        self._keep = keepalive
+        self._check(self.L.fseq_set_device_columns_packed(self.h, ptr, ld_bytes, sigma, bits))
 
     def generate_synthetic(self, seed, n_founders, block_len, mu, kind=0):
         s = SynthSpec(seed, n_founders, block_len, synth_threshold(mu), kind)

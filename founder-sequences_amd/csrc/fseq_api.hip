@@ -995,6 +995,28 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	return FSEQ_OK;
 }
 
+int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_bytes, uint32_t sigma, uint32_t bits)
+{
+	if (!c || !d_packed) return FSEQ_E_ARG;
+	if (bits != 2 && bits != 4 && bits != 8) return fail(c, FSEQ_E_ARG, "packed device columns: bits must be 2, 4 or 8");
+	uint32_t const bsh = bits == 2 ? 2u : bits == 4 ? 1u : 0u;
+	if (sigma == 0 || sigma > (1u << bits)) return fail(c, FSEQ_E_ARG, "sigma does not fit the code width");
+	if (ld_bytes < sym_bytes(c->p.m, bsh) || (ld_bytes & 15) || (reinterpret_cast<uintptr_t>(d_packed) & 15))
+		return fail(c, FSEQ_E_ARG, "packed device columns: ld_bytes must cover a column and be a multiple of 16, base 16-byte aligned");
+	free_msa(c);
+	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_packed));
+	c->ld = ld_bytes;
+	c->bsh = bsh;
+	c->own_msa = false;
+	c->sigma = sigma;
+	for (uint32_t i = 0; i < 256; ++i) c->code_to_byte[i] = (uint8_t) i;
+	c->have_input = true;
+	c->have_result = false;
+	c->kernels_ready = false;
+	c->X_hint = 0;
+	return FSEQ_OK;
+}
+
 int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 {
 	if (!c || !spec || 0 == spec->n_founders || 0 == spec->block_len || spec->kind > 1) return FSEQ_E_ARG;

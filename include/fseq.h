@@ -114,6 +114,10 @@ int  fseq_set_matrix(fseq_ctx *ctx, uint8_t const *base, size_t row_stride, size
  * ld >= m.  sigma = number of codes (codes are < sigma).  The buffer is borrowed, not copied (and not
  * repacked: inputs the library uploads itself are stored at 2 / 4 / 8 bits per cell by sigma). */
 int  fseq_set_device_columns(fseq_ctx *ctx, void const *d_codes, size_t ld, uint32_t sigma);
+/* The same for columns that are already packed the way the library stores them: bits = 2, 4 or 8 per
+ * code (codes < sigma <= 2^bits), row r of a column in byte r / (8 / bits) at bit (r mod (8 / bits)) * bits,
+ * column c at d_packed + c * ld_bytes, ld_bytes a multiple of 16 and >= ceil(m * bits / 8). */
+int  fseq_set_device_columns_packed(fseq_ctx *ctx, void const *d_packed, size_t ld_bytes, uint32_t sigma, uint32_t bits);
 /* Generate the alignment on the device (bench / large configs). */
 int  fseq_generate_synthetic(fseq_ctx *ctx, fseq_synth_spec const *spec);
 /* Copy columns [c0,c1) back as raw bytes, out[r*row_stride + (c-c0)*col_stride] (tests, writers). */

@@ -394,3 +394,40 @@ def test_config_c4_full_size_properties(pkg):
     k = ncols - 2 * L                                        # DP entries of regular cells of the prefix run
     assert np.array_equal(mx[:k], ref["dp"]["segment_max_size"][:k])
     assert np.array_equal(lb[:k], ref["dp"]["lb"][:k].astype(np.uint32))
+
+
+@pytest.mark.parametrize("bits", [8, 4, 2])
+def test_borrowed_device_columns(pkg, bits):
+    """Input already in HBM (fseq_set_device_columns / _packed): column-major dense codes in a caller-owned
+    buffer, one per byte or packed 4 / 2 bits per code the way the library stores its own uploads."""
+    import torch
+    m, n, L = 333, 900, 12
+    sigma = {8: 7, 4: 13, 2: 4}[bits]
+    rng = np.random.default_rng(bits)
+    founders = rng.integers(0, sigma, size=(6, n))
+    pick = rng.integers(0, 6, size=(m, (n + 89) // 90))
+    codes = np.empty((m, n), dtype=np.uint8)
+    for b in range(pick.shape[1]):
+        codes[:, b * 90:(b + 1) * 90] = founders[pick[:, b], b * 90:(b + 1) * 90]
+    noise = rng.random((m, n)) < 3e-3
+    codes[noise] = rng.integers(0, sigma, size=int(noise.sum()))
+    spb = 8 // bits
+    ld = ((m + spb - 1) // spb + 15) // 16 * 16
+    cols = np.zeros((n, ld), dtype=np.uint8)
+    for r in range(m):
+        cols[:, r // spb] |= (codes[r] << ((r % spb) * bits)).astype(np.uint8)
+    dev = torch.from_numpy(cols).to("cuda")
+    ctx = pkg.SegmentationContext(m, n, L)
+    if bits == 8:
+        ctx.set_device_columns(dev.data_ptr(), ld, sigma, keepalive=dev)
+    else:
+        ctx.set_device_columns_packed(dev.data_ptr(), ld, sigma, bits, keepalive=dev)
+    assert np.array_equal(ctx.get_sequences(), codes)         # codes come back as they are (identity byte map)
+    ctx.run()
+    ref = fso.segment_long(codes, L, threads=4)
+    red = ctx.reduced_traceback()
+    assert ctx.result.max_segment_size == ref["max_segment_size"]
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f])
+    a, d = ctx.boundary_state(len(red) - 1)
+    assert np.array_equal(a, ref["a"][len(red) - 1]) and np.array_equal(d, ref["d"][len(red) - 1])
