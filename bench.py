@@ -62,7 +62,7 @@ def cpu_baseline(ctx, w, threads):
     return {
         "value": m * ncols / dt,
         "unit": "cells/s",
-        "cores": 1,
+        "cores": int(r["pass2_threads"]),       # threads used at the widest point (pass 2); pass 1 + DP are one thread, as in the reference
         "kind": "port",
         "sample": "oracle/fseq_oracle.c on the same synthetic input, first %d of %d columns, all %d rows, row-major; "
                   "pass 1 + DP on 1 thread (%.2f s), pass 2 on %d threads (%.2f s), host has %d cores"
