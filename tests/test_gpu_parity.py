@@ -431,3 +431,35 @@ def test_borrowed_device_columns(pkg, bits):
         assert np.array_equal(red[f], ref["reduced"][f])
     a, d = ctx.boundary_state(len(red) - 1)
     assert np.array_equal(a, ref["a"][len(red) - 1]) and np.array_equal(d, ref["d"][len(red) - 1])
+
+
+def _random_case(rng):
+    L = int(rng.integers(1, 41))
+    n = int(rng.integers(2 * L, 2 * L + 1200))
+    m = int(rng.choice([2, 3, 5, 17, 64, 65, 130, 300, 449, 700]))
+    sigma = int(rng.choice([2, 3, 4, 5, 16, 17, 60]))
+    k = int(rng.integers(1, 9))
+    brec = int(rng.integers(5, 200))
+    founders = rng.integers(0, sigma, size=(k, n))
+    pick = rng.integers(0, k, size=(m, (n + brec - 1) // brec))
+    msa = np.empty((m, n), dtype=np.uint8)
+    for b in range(pick.shape[1]):
+        msa[:, b * brec:(b + 1) * brec] = founders[pick[:, b], b * brec:(b + 1) * brec]
+    noise = rng.random((m, n)) < float(rng.choice([0.0, 1e-3, 1e-2]))
+    msa[noise] = rng.integers(0, sigma, size=int(noise.sum()))
+    kw = {"block_len": int(rng.choice([0, 0, 1, 7, 16, 33, 100, 5000]))}
+    if rng.random() < 0.3:
+        kw["list_cap"] = int(rng.choice([1, 2, 5, 17]))
+    return np.ascontiguousarray(msa + 33), L, kw
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_random_shapes_match_oracle(pkg, chunk):
+    """Differential test on random shapes: rows, columns, L, alphabet, recombination, noise, block length
+    and list capacity drawn at random (fixed seeds); DP array, traceback, merged segments and every
+    boundary state must equal the oracle's."""
+    import os
+    rng = np.random.default_rng(1000 + chunk)
+    for _ in range(int(os.environ.get("FSEQ_RANDOM_CASES", "10"))):
+        msa, L, kw = _random_case(rng)
+        compare_long(pkg, msa, L, check_dp=True, **kw)
