@@ -627,7 +627,11 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	{
 		if ((rc = ensure_work_buffers(c, X))) return rc;
 		// ---- phase C + D
+#if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
+		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 1024, st));
+#else
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
+#endif
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		if (c->use_stream)
 			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
@@ -665,7 +669,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 #endif
 #ifdef FSEQ_DP_STATS
-		fprintf(stderr, "[dp stats] slow strips = %u of %llu cells\n", h_flags[2], (unsigned long long) c->dp_size);
+		{
+			uint32_t hist[34];
+			HIP_TRY(c, hipMemcpy(hist, c->d_flags + 128, sizeof(hist), hipMemcpyDeviceToHost));
+			fprintf(stderr, "[dp stats] list entries a cell needed (cell-pair path; last = more than 32):");
+			for (int i = 0; i < 34; ++i) fprintf(stderr, " %u", hist[i]);
+			fprintf(stderr, "\n");
+		}
 #endif
 		double const th0 = now_ms();
 		bool overflow = (h_flags[0] & 1u) != 0;

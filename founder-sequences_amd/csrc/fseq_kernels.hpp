@@ -1157,6 +1157,15 @@ __device__ __forceinline__ uint64_t dp_cell_pair(
 	uint32_t const cum_base = half ? cumB : cumA;
 	bool const decided = best_v != 0xFFFFFFFFu && cum_base > best_v;
 	bool const more = !decided && nent > 32u;
+#ifdef FSEQ_DP_STATS
+	{
+		// diagnostic build: histogram of the list entries a cell needed before the pruning bound was
+		// reached, in flags[128 + n] (n = 33: more than the 32 of a half wave)
+		uint64_t const need = __ballot(valid && (cum <= best_v || best_v == 0xFFFFFFFFu));
+		uint32_t const nh = (uint32_t) __popc((uint32_t) (need >> (half * 32u)));
+		if (sub == 0u && has) atomicAdd(flags + 128 + (more ? 33u : nh), 1u);
+	}
+#endif
 	if (!more)
 	{
 		if (!complete && !decided && has && sub == 0u) atomicOr(flags, 1u);   // list too short to prove the result
