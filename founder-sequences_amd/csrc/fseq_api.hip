@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace fseq;
@@ -1087,6 +1088,21 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 	if (c->p.n < 2 * c->p.segment_length)
 		return run_short_path(c, res);
 	return run_long_path(c, res);
+}
+
+int fseq_run_segmentation_batch(fseq_ctx *const *ctxs, size_t count, fseq_result *results, int *return_codes)
+{
+	if ((count && (!ctxs || !results || !return_codes))) return FSEQ_E_ARG;
+	for (size_t i = 0; i < count; ++i)
+		for (size_t j = 0; j < i; ++j)
+			if (ctxs[i] == ctxs[j]) return FSEQ_E_ARG;                 // a context runs one alignment at a time
+	std::vector<std::thread> workers;
+	workers.reserve(count);
+	for (size_t i = 1; i < count; ++i)
+		workers.emplace_back([=]() { return_codes[i] = fseq_run_segmentation(ctxs[i], &results[i]); });
+	if (count) return_codes[0] = fseq_run_segmentation(ctxs[0], &results[0]);
+	for (auto &w : workers) w.join();
+	return FSEQ_OK;
 }
 
 int fseq_get_traceback(fseq_ctx *c, fseq_dp_arg *out)

@@ -463,3 +463,24 @@ def test_random_shapes_match_oracle(pkg, chunk):
     for _ in range(int(os.environ.get("FSEQ_RANDOM_CASES", "10"))):
         msa, L, kw = _random_case(rng)
         compare_long(pkg, msa, L, check_dp=True, **kw)
+
+
+def test_native_batch_runner(pkg):
+    """fseq_run_segmentation_batch: several contexts in flight from native threads; per-context results and
+    return codes (one of the inputs cannot be reduced)."""
+    cases = []
+    for j, (m, n, L) in enumerate([(300, 3000, 25), (900, 2000, 30), (64, 1500, 9)]):
+        msa = fso.synth_msa(fso.synth_spec(700 + j, 6 + j, 150, 2e-3), m, n)
+        ctx = pkg.SegmentationContext(m, n, L)
+        ctx.set_sequences(msa)
+        cases.append((ctx, fso.segment_long(msa, L, threads=4)))
+    bad = np.ascontiguousarray((np.random.default_rng(5).integers(0, 4, size=(6, 300)) + 65).astype(np.uint8))
+    cbad = pkg.SegmentationContext(6, 300, 20)
+    cbad.set_sequences(bad)
+    rcs = pkg.run_batch([c for c, _ in cases] + [cbad])
+    assert rcs[:3] == [pkg.FSEQ_OK] * 3 and rcs[3] == pkg.FSEQ_E_NO_REDUCTION
+    for ctx, ref in cases:
+        red = ctx.reduced_traceback()
+        assert ctx.result.max_segment_size == ref["max_segment_size"]
+        for f in ("lb", "rb", "segment_size"):
+            assert np.array_equal(red[f], ref["reduced"][f])
