@@ -7,6 +7,7 @@
 // unavailable the call fails with an error code.
 #include "../../include/fseq.h"
 #include "fseq_kernels.hpp"
+#include "fseq_dp.hpp"
 #include "fseq_stream.hpp"
 #include "fseq_join.hpp"
 

@@ -1,0 +1,862 @@
+// fseq_dp.hpp -- phase D of the segmentation path: the minimum-segmentation DP over the columns
+// (calculate_segmentation_lp_dp_arg, segmentation_lp_context.cc:393-481, driven as generate_traceback
+// parts 2-4 do, :26-188) with the exact semantics of rmq.hh, as ONE workgroup of sixteen specialised
+// waves on one CU.  Consumes the per-column lists k_columns / k_columns_stream emit.
+#pragma once
+
+#include "fseq_kernels.hpp"
+
+namespace fseq {
+
+// ------------------------------------------------------------------------------------------------
+// Phase D: the DP.  One workgroup; waves take columns; rounds of <= L columns are mutually
+// independent (the step at column end reads DP entries <= end-2L and writes end-L:
+// segmentation_lp_context.cc:444-445,463-465,135-137).
+// rmq.hh semantics (block 64) via P (first-min of the block prefix), S (first-min of the block
+// suffix) and the sparse table Tb with the smp1 == smp2 quirk (rmq.hh:76-79).
+// ------------------------------------------------------------------------------------------------
+// K[t]: 64-bit mask over the 64-block of t; bit p (p <= t mod 64) is set iff M[p] <= min(M[p+1..t])
+// (the monotonic stack after scanning the block up to t, popping only strictly greater keys).
+// The first minimum of [b, t] inside one block (std::min_element, rmq.hh:116) is the lowest set
+// bit of K[t] at or above b -- every partial-block scan of rmq.hh in O(1).
+// Tb[p][j] / Tbv[p][j]: sparse-table sample (index / key) of rmq.hh's m_precalc[p][j].
+struct DpArrays {
+	uint32_t *M, *LB, *SZ, *Tb, *Tbv;
+	unsigned long long *K;
+	uint32_t tstride;
+};
+
+// One workgroup of 16 waves, specialised: 14 compute waves that touch LDS only, one loader wave
+// that streams the per-column lists (and the old sparse-table samples the update needs) into LDS
+// two rounds ahead with LDS-DMA, one writer wave that flushes finished rounds to HBM.  A global
+// memory round trip costs ~1.5 us here, a round must cost about that in total, so no wave that
+// the round barriers wait for may ever wait on HBM.
+constexpr uint32_t DPW = 4096;            // DP entries mirrored in LDS (ring, slot = index mod DPW)
+constexpr uint32_t DP_RL = 56;            // cells per round (<= L)
+constexpr uint32_t DP_NWC = 14;           // compute waves
+constexpr int      DP_G = 4;              // cells per compute wave per round (14 * 4 = 56)
+constexpr uint32_t DP_STG = 512;          // staging ring for LB / SZ
+constexpr uint32_t DP_TRN = 64;           // sparse-table ring: last 64 samples of every level
+constexpr uint32_t DP_LEVELS = 32;
+constexpr uint32_t DP_HPMIN = 7;          // levels >= 7: input sample is older than the ring -> mailbox
+constexpr uint32_t DP_SLOTS = 3;          // list slots: rounds r, r+1, r+2
+constexpr uint32_t DP_MBSLOTS = 4;        // mailbox slots (read one round later in pipelined mode)
+constexpr uint32_t DP_Q = DP_RL / 2 + 1 + 2;   // LDS-DMA instructions the loader issues per round
+constexpr uint32_t DP_LOADER = 14, DP_WRITER = 15;
+
+// LDS pointers carry their address space so that a choice between an LDS and an HBM source stays
+// two different loads (ds_read vs global_load) instead of one flat load through a selected pointer
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+
+struct DpLds {
+	lds_u64 *Kr;
+	lds_u32 *Mr, *LBr, *SZr, *Tr, *Trv;
+	lds_u32 *LS;                          // [DP_SLOTS][DP_RL][64] x {value, count}
+	lds_u32 *H;                           // [DP_SLOTS][64] x {n_entries, cnt0, complete, cum}
+	lds_u32 *MBi, *MBv;                   // [DP_SLOTS][64]
+};
+
+__host__ __device__ inline size_t dp_lds_bytes()
+{
+	return carve_bytes(DPW, 8) + carve_bytes(DPW, 4) + 2 * carve_bytes(DP_STG, 4) + 2 * carve_bytes((size_t) DP_LEVELS * DP_TRN, 4)
+	     + carve_bytes((size_t) DP_SLOTS * DP_RL * 64, 8) + carve_bytes((size_t) DP_SLOTS * 64, 16) + 2 * carve_bytes((size_t) DP_MBSLOTS * 64, 4)
+	     + carve_bytes(4, 4);
+}
+
+// where a query may read: entries >= safe_lo and samples produced after block cb - DP_TRN live in LDS
+struct DpView {
+	uint32_t safe_lo;     // first DP entry guaranteed to be in the LDS ring during this round
+	uint32_t cb;          // complete (indexed) blocks at the start of this round
+};
+
+__device__ __forceinline__ uint32_t dp_key(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t i)
+{
+	return i >= V.safe_lo ? D.Mr[i & (DPW - 1u)] : A.M[i];
+}
+
+__device__ __forceinline__ unsigned long long dp_mask(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t i)
+{
+	return i >= V.safe_lo ? D.Kr[i & (DPW - 1u)] : A.K[i];
+}
+
+// sample (p, j) was produced when block j + 2^p - 1 completed
+__device__ __forceinline__ void dp_sample(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t p, uint32_t j, uint32_t *idx, uint32_t *val)
+{
+	if (j + (1u << p) + DP_TRN > V.cb + 2u)
+	{
+		*idx = D.Tr[p * DP_TRN + (j & (DP_TRN - 1u))];
+		*val = D.Trv[p * DP_TRN + (j & (DP_TRN - 1u))];
+	}
+	else
+	{
+		*idx = A.Tb[(size_t) p * A.tstride + j];
+		*val = A.Tbv[(size_t) p * A.tstride + j];
+	}
+}
+
+// rmq.hh:85-105 (operator()), every query of the DP has end <= number of indexed entries.
+// Returns the index; *val = its key.
+__device__ __forceinline__ uint32_t rmq_query(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t beg, uint32_t end, uint32_t *val)
+{
+	uint32_t const bb = beg >> 6, eb = (end - 1u) >> 6;
+	uint32_t const beg_block = bb + 1u, end_block = end >> 6;
+	uint32_t const ie = end - 1u;
+	unsigned long long const ke = dp_mask(A, D, V, ie);
+	if (bb == eb)
+	{
+		// beg_block >= end_block, one block: naive_min (rmq.hh:90-91)
+		uint32_t const idx = beg + (uint32_t) __builtin_ctzll(ke >> (beg & 63u));
+		*val = dp_key(A, D, V, idx);
+		return idx;
+	}
+	unsigned long long const kb = dp_mask(A, D, V, (bb << 6) + 63u);
+	uint32_t const il = beg + (uint32_t) __builtin_ctzll(kb >> (beg & 63u));   // naive_min(beg, beg_block*64)
+	uint32_t const ir = (ie & ~63u) + (uint32_t) __builtin_ctzll(ke);           // naive_min(end_block*64, end)
+	uint32_t const m_il = dp_key(A, D, V, il), m_ir = dp_key(A, D, V, ir);
+	uint32_t idx, v;
+	if (beg_block < end_block)
+	{
+		uint32_t const pow2 = 31u - (uint32_t) __builtin_clz(end_block - beg_block);
+		uint32_t t1, t2, m_t1, m_t2;
+		dp_sample(A, D, V, pow2, beg_block, &t1, &m_t1);
+		dp_sample(A, D, V, pow2, end_block - (1u << pow2), &t2, &m_t2);
+		idx = t1; v = m_t1;
+		if (m_t2 < v) { idx = t2; v = m_t2; }                   // rmq.hh:96
+		if (m_il < v) { idx = il; v = m_il; }                   // rmq.hh:97-98
+		if ((end & 63u) != 0 && m_ir < v) { idx = ir; v = m_ir; }   // rmq.hh:100-104
+	}
+	else
+	{
+		// two adjacent blocks: naive_min over [beg, block end) ++ [block start, end), first minimum
+		idx = il; v = m_il;
+		if (m_ir < v) { idx = ir; v = m_ir; }
+	}
+	*val = v;
+	return idx;
+}
+
+// The same query when the whole range (and therefore every sample it needs) is inside the LDS
+// ring: beg >= safe_lo implies beg_block >= cb - DP_TRN + 3, so dp_sample would pick LDS anyway.
+// 32-bit address math only; this is the path practically every candidate takes.
+__device__ __forceinline__ uint32_t rmq_query_lds(DpLds const &D, uint32_t beg, uint32_t end, uint32_t *val)
+{
+	uint32_t const bb = beg >> 6, eb = (end - 1u) >> 6;
+	uint32_t const ie = end - 1u;
+	unsigned long long const ke = D.Kr[ie & (DPW - 1u)];
+	unsigned long long const kb = D.Kr[((bb << 6) + 63u) & (DPW - 1u)];
+	uint32_t const sh = beg & 63u;
+	// one block: first min of [beg, end) from the mask of the right end; else the two partial blocks
+	uint32_t const il = beg + (uint32_t) __builtin_ctzll((bb == eb ? ke : kb) >> sh);
+	uint32_t const ir = (ie & ~63u) + (uint32_t) __builtin_ctzll(ke);
+	uint32_t idx = il, v = D.Mr[il & (DPW - 1u)];
+	if (bb != eb)
+	{
+		uint32_t const m_ir = D.Mr[ir & (DPW - 1u)];
+		uint32_t const beg_block = bb + 1u, end_block = end >> 6;
+		if (beg_block < end_block)
+		{
+			uint32_t const pow2 = 31u - (uint32_t) __builtin_clz(end_block - beg_block);
+			uint32_t const s1 = pow2 * DP_TRN + (beg_block & (DP_TRN - 1u));
+			uint32_t const s2 = pow2 * DP_TRN + ((end_block - (1u << pow2)) & (DP_TRN - 1u));
+			uint32_t const t1 = D.Tr[s1], m_t1 = D.Trv[s1], t2 = D.Tr[s2], m_t2 = D.Trv[s2];
+			uint32_t const m_il = v;
+			idx = t1; v = m_t1;
+			if (m_t2 < v) { idx = t2; v = m_t2; }                   // rmq.hh:96
+			if (m_il < v) { idx = il; v = m_il; }                   // rmq.hh:97-98
+			if ((end & 63u) != 0 && m_ir < v) { idx = ir; v = m_ir; }   // rmq.hh:100-104
+		}
+		else if (m_ir < v) { idx = ir; v = m_ir; }                  // two adjacent blocks, first minimum
+	}
+	*val = v;
+	return idx;
+}
+
+// State of one DP cell while a wave evaluates it (calculate_segmentation_lp_dp_arg, lp.cc:393-481,
+// candidate ranges visited in descending divergence order and pruned exactly).
+struct CellState {
+	uint32_t best_v, best_lb, best_sz, cum_base;
+};
+
+// One strip of 64 list entries starting at entry s0; lanes < ncand are candidates (the lane's
+// range needs the next entry's value).  Returns true when the cell is decided (pruned).
+__device__ __forceinline__ bool dp_strip(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint2 en_in, uint32_t vnext_in, uint32_t nent, uint32_t s0,
+	uint32_t ncand, uint32_t L, uint32_t end, CellState &st)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const i = s0 + lane;
+	bool const valid = i < nent;
+	bool const have_next = i + 1 < nent && lane < ncand;
+	uint2 const en = valid ? en_in : make_uint2(0u, 0u);
+	uint32_t const vnext = have_next ? vnext_in : 0u;
+	bool const is0 = valid && en.x == 0u;
+	uint32_t const cc = (valid && !is0) ? en.y : 0u;
+	uint32_t const cum = st.cum_base + wave_incl_add(cc);
+	bool ok = valid && !is0 && have_next && vnext != 0u;
+	uint32_t lo = vnext;
+	uint32_t const c = min(en.x, end + 1u - L);              // lp.cc:444-445 (text_pos + 2 - L)
+	if (lo < L)                                              // lp.cc:449-455 (lb == 0)
+	{
+		if (L < c) lo = L; else ok = false;
+	}
+	ok = ok && lo < c;                                       // lp.cc:458
+	uint32_t val = 0xFFFFFFFFu, idx = 0;
+	uint32_t const qb = lo - L, qe = c - L;
+	if (__ballot(ok && qb < V.safe_lo) == 0)
+	{
+		// every candidate of the strip lies inside the LDS ring
+		if (ok)
+		{
+			uint32_t mv;
+			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
+			val = max(mv, cum);                                  // lp.cc:468-471
+		}
+	}
+	else if (ok)
+	{
+		uint32_t mv;
+		idx = rmq_query(A, D, V, qb, qe, &mv);
+		val = max(mv, cum);
+	}
+	// minimum value; among equal values the candidate the reference visits first = the largest i
+	// (lowest divergence value) = the highest lane of the strip
+	uint32_t const vmin = wave_min_u32(val);
+	if (vmin != 0xFFFFFFFFu && vmin <= st.best_v)
+	{
+		uint64_t const wmask = __ballot(ok && val == vmin);
+		int const src = 63 - (int) __builtin_clzll(wmask);       // wave-uniform: v_readlane, no LDS round trip
+		st.best_v = vmin;
+		st.best_lb = readlane_u32(idx, src) + L;
+		st.best_sz = readlane_u32(cum, src);
+	}
+	bool const last = s0 + 64u >= nent;                       // strip reaches the end of the list
+	st.cum_base = readlane_u32(cum, 63);
+	if (!last && ncand < 64u) st.cum_base = readlane_u32(cum, 62);
+	return st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
+}
+
+// A whole cell, strip after strip (the general path: lists longer than one strip, or ranges that
+// reach behind the LDS ring).  Returns the finished state; sets the overflow flag when the list is
+// too short to prove the result.
+__device__ __forceinline__ CellState dp_cell_sequential(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint2 const *__restrict__ list, uint2 en0, uint32_t vnext0,
+	uint4 const h, uint32_t m, uint32_t L, uint32_t end, uint32_t *flags)
+{
+	uint32_t const lane = lane_id();
+	CellState st;
+	st.best_v = 0xFFFFFFFFu; st.best_lb = 0; st.best_sz = 0; st.cum_base = 0;
+	uint32_t const nent = h.x;
+	bool done = dp_strip(A, D, V, en0, vnext0, nent, 0, 63, L, end, st);
+	for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)     // continue from HBM (rare; only this wave waits)
+	{
+		uint2 const e2 = list[s0 + lane];
+		uint32_t const v2 = list[s0 + lane + 1u].x;
+		done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
+	}
+	uint32_t const cnt0 = h.y, complete = h.z;
+	bool const stopped = st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
+	if (!complete && !stopped && lane == 0) atomicOr(flags, 1u);   // list too short to prove the result
+	if (complete && cnt0 > 0)
+	{
+		uint32_t const w = m - cnt0;                         // lp.cc:416-421, visited first by the reference
+		if (w <= st.best_v) { st.best_v = w; st.best_lb = 0; st.best_sz = w; }
+	}
+	if (m <= st.best_v) { st.best_v = m; st.best_lb = 0; st.best_sz = m; }   // initial min_arg, lp.cc:123
+	return st;
+}
+
+struct DpRound {
+	uint32_t e0, len, t0, t1;
+	bool final_round;
+};
+
+// The two 32-lane halves of a wave as independent scans / reductions
+__device__ __forceinline__ uint32_t half_incl_add(uint32_t v)
+{
+	v += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, v);
+	v += dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t half_min_u32(uint32_t v)
+{
+	v = min(v, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, v));
+	v = min(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, v));
+	uint32_t const a = readlane_u32(v, 31), b = readlane_u32(v, 63);
+	return lane_id() < 32u ? a : b;
+}
+
+// Two cells at once, one per 32-lane half (cells i0 and i0 + 1 of the round): the arithmetic of
+// dp_strip on the first 32 list entries plus the tail of dp_cell_sequential.  Nearly every cell is
+// decided there (the lumped entry plus a few dozen distinct values reach the pruning bound), so
+// a cell costs half the instructions of a full-wave strip.  A cell that is neither decided nor at the
+// end of its list after 32 entries is left unwritten and reported in the returned mask (bit 0 /
+// bit 32); the caller runs the general path for it.
+__device__ __forceinline__ uint64_t dp_cell_pair(
+	DpArrays const &A, DpLds const &D, DpView const &V, uint32_t slot, uint32_t i0, DpRound const &R,
+	uint32_t m, uint32_t L, uint32_t *flags)
+{
+	uint32_t const lane = lane_id(), half = lane >> 5, sub = lane & 31u;
+	bool const has = i0 + half < R.len;
+	uint32_t const ci = has ? i0 + half : i0;
+	uint32_t const end = R.e0 + ci, t = end - L;
+	lds_u32 const *hp = D.H + (slot * 64u + ci) * 4u;
+	uint32_t const nent = hp[0], cnt0 = hp[1], complete = hp[2];
+	lds_u32 const *ls = D.LS + (slot * DP_RL + ci) * 128u;
+	bool const valid = sub < nent;
+	bool const have_next = sub + 1u < nent;
+	uint2 const en = valid ? make_uint2(ls[2u * sub], ls[2u * sub + 1u]) : make_uint2(0u, 0u);
+	uint32_t const vnext = have_next ? ls[2u * sub + 2u] : 0u;
+	bool const is0 = valid && en.x == 0u;
+	uint32_t const cc = (valid && !is0) ? en.y : 0u;
+	uint32_t const cum = half_incl_add(cc);
+	bool ok = valid && !is0 && have_next && vnext != 0u;
+	uint32_t lo = vnext;
+	uint32_t const c = min(en.x, end + 1u - L);              // lp.cc:444-445
+	if (lo < L)                                              // lp.cc:449-455
+	{
+		if (L < c) lo = L; else ok = false;
+	}
+	ok = ok && lo < c;                                       // lp.cc:458
+	uint32_t val = 0xFFFFFFFFu, idx = 0;
+	uint32_t const qb = lo - L, qe = c - L;
+	if (__ballot(ok && qb < V.safe_lo) == 0)
+	{
+		if (ok)
+		{
+			uint32_t mv;
+			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
+			val = max(mv, cum);                                  // lp.cc:468-471
+		}
+	}
+	else if (ok)
+	{
+		uint32_t mv;
+		idx = rmq_query(A, D, V, qb, qe, &mv);
+		val = max(mv, cum);
+	}
+	// minimum per half; among equal values the highest lane of the half (dp_strip)
+	uint32_t const vmin = half_min_u32(val);
+	uint64_t const wmask = __ballot(ok && val == vmin);
+	uint32_t const mA = (uint32_t) wmask, mB = (uint32_t) (wmask >> 32);
+	int const srcA = mA ? 31 - (int) __builtin_clz(mA) : 0, srcB = mB ? 63 - (int) __builtin_clz(mB) : 32;
+	uint32_t const lbA = readlane_u32(idx, srcA), lbB = readlane_u32(idx, srcB);
+	uint32_t const szA = readlane_u32(cum, srcA), szB = readlane_u32(cum, srcB);
+	uint32_t const cumA = readlane_u32(cum, 31), cumB = readlane_u32(cum, 63);
+	uint32_t best_v = vmin;
+	uint32_t best_lb = vmin != 0xFFFFFFFFu ? (half ? lbB : lbA) + L : 0u;
+	uint32_t best_sz = vmin != 0xFFFFFFFFu ? (half ? szB : szA) : 0u;
+	uint32_t const cum_base = half ? cumB : cumA;
+	bool const decided = best_v != 0xFFFFFFFFu && cum_base > best_v;
+	bool const more = !decided && nent > 32u;
+#ifdef FSEQ_DP_STATS
+	{
+		// diagnostic build: histogram of the list entries a cell needed before the pruning bound was
+		// reached, in flags[128 + n] (n = 33: more than the 32 of a half wave)
+		uint64_t const need = __ballot(valid && (cum <= best_v || best_v == 0xFFFFFFFFu));
+		uint32_t const nh = (uint32_t) __popc((uint32_t) (need >> (half * 32u)));
+		if (sub == 0u && has) atomicAdd(flags + 128 + (more ? 33u : nh), 1u);
+	}
+#endif
+	if (!more)
+	{
+		if (!complete && !decided && has && sub == 0u) atomicOr(flags, 1u);   // list too short to prove the result
+		if (complete && cnt0 > 0)
+		{
+			uint32_t const w = m - cnt0;                         // lp.cc:416-421
+			if (w <= best_v) { best_v = w; best_lb = 0; best_sz = w; }
+		}
+		if (m <= best_v) { best_v = m; best_lb = 0; best_sz = m; }             // lp.cc:123
+		if (has && sub == 0u)
+		{
+			D.Mr[t & (DPW - 1u)] = best_v;
+			D.LBr[t & (DP_STG - 1u)] = best_lb;
+			D.SZr[t & (DP_STG - 1u)] = best_sz;
+		}
+	}
+	return __ballot(has && more && sub == 0u);
+}
+
+// LDS-DMA: every lane names its own 16 (or 4) global bytes; they land at LDS address lds + lane * size.
+// Inline asm on purpose: the loader wave counts these itself (s_waitcnt vmcnt(DP_Q) = "the round
+// before the one just issued has landed"); issued through the builtin, hipcc would drain them
+// with vmcnt(0) in front of every barrier and LDS read that follows.  M0 carries the LDS base
+// and is restored (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+// the same without the save / restore, for a run of loads bracketed by m0_save() / m0_restore() with
+// nothing else in between (the loader's list loop: two scalar instructions fewer per load)
+__device__ __forceinline__ uint32_t m0_save()
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0" : "=s"(keep) : : "memory");
+	return keep;
+}
+__device__ __forceinline__ void m0_restore(uint32_t keep)
+{
+	asm volatile("s_mov_b32 m0, %0" : : "s"(keep) : "memory");
+}
+__device__ __forceinline__ void dma16_m0(void const *g, uint32_t lds_addr)
+{
+	asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(g), "s"(lds_addr) : "memory");
+}
+__device__ __forceinline__ void dma4(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
+// s_waitcnt vmcnt(N) takes an immediate: wait until at most N (4..31) of this wave's LDS-DMA loads are in flight
+__device__ __forceinline__ void dp_wait_all_but(uint32_t n)
+{
+#define FSEQ_W(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+	switch (n)
+	{
+		FSEQ_W(4) FSEQ_W(5) FSEQ_W(6) FSEQ_W(7) FSEQ_W(8) FSEQ_W(9) FSEQ_W(10) FSEQ_W(11) FSEQ_W(12) FSEQ_W(13) FSEQ_W(14)
+		FSEQ_W(15) FSEQ_W(16) FSEQ_W(17) FSEQ_W(18) FSEQ_W(19) FSEQ_W(20) FSEQ_W(21) FSEQ_W(22) FSEQ_W(23) FSEQ_W(24)
+		FSEQ_W(25) FSEQ_W(26) FSEQ_W(27) FSEQ_W(28) FSEQ_W(29) FSEQ_W(30) FSEQ_W(31)
+		default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+	}
+#undef FSEQ_W
+}
+
+// Round schedule.  nreg regular rounds of <= RL cells (end = L + r*RL + i), then -- pipelined mode
+// only -- one empty drain round (the update of the last regular round), then the final cell at
+// rb = n (lp.cc:165-183).
+struct DpSchedule {
+	uint32_t L, n, RL, nreg, nrounds;
+	bool pipe;
+};
+
+__device__ __forceinline__ DpRound dp_round(DpSchedule const &S, uint32_t r)
+{
+	DpRound R;
+	uint32_t const last_end = S.n - S.L;
+	R.final_round = (r + 1u == S.nrounds);
+	bool const regular = r < S.nreg;
+	R.e0 = R.final_round ? S.n : (regular ? S.L + r * S.RL : last_end + 1u);
+	R.len = R.final_round ? 1u : (regular ? min(S.RL, last_end - R.e0 + 1u) : 0u);
+	R.t0 = R.e0 - S.L;
+	R.t1 = R.t0 + R.len;
+	return R;
+}
+
+__device__ __forceinline__ void dp_barrier()
+{
+	// LDS traffic only; outstanding HBM loads / stores of the loader and writer waves stay in flight
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+	__builtin_amdgcn_s_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// rmq.update, part 1 (rmq.hh:61-68 made O(1) to query): one 16-bit slice (positions [16c, 16c+16)
+// of the block) of the stack masks of the fresh entries of block blk.
+__device__ __forceinline__ void dp_mask_slice(DpLds const &D, DpRound const &R, uint32_t blk, uint32_t chunk)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u, idx = base + lane;
+	bool const fresh = idx >= R.t0 && idx < R.t1;
+	uint32_t const mine = D.Mr[idx & (DPW - 1u)];
+	uint32_t const plo = 16u * chunk, phi = plo + 16u;
+	// running minimum of the keys to the right of the slice, up to this lane: inclusive prefix-min
+	// over the lanes >= phi (the lane's own key included)
+	uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
+	pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+	pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+	uint32_t runmin = lane >= phi ? pm : mine;
+	uint32_t bits = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
+#pragma unroll
+	for (int pp = 15; pp >= 0; --pp)
+	{
+		uint32_t const p = plo + (uint32_t) pp;
+		uint32_t const x = readlane_u32(mine, (int) p);
+		bool const in = lane > p;
+		bits |= (in && x <= runmin) ? (1u << pp) : 0u;
+		runmin = in ? min(runmin, x) : runmin;
+	}
+	if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
+}
+
+// All four slices of one block by one wave: four independent dependency chains that interleave
+// (pipelined schedule, where only two waves do the update).
+__device__ __forceinline__ void dp_mask_block(DpLds const &D, DpRound const &R, uint32_t blk)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u, idx = base + lane;
+	bool const fresh = idx >= R.t0 && idx < R.t1;
+	uint32_t const mine = D.Mr[idx & (DPW - 1u)];
+	uint32_t runmin[4], bits[4];
+#pragma unroll
+	for (int c = 0; c < 4; ++c)
+	{
+		uint32_t const plo = 16u * c, phi = plo + 16u;
+		uint32_t pm = lane >= phi ? mine : 0xFFFFFFFFu;
+		pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+		runmin[c] = lane >= phi ? pm : mine;
+		bits[c] = (lane >= plo && lane < phi) ? (1u << (lane - plo)) : 0u;
+	}
+#pragma unroll
+	for (int pp = 15; pp >= 0; --pp)
+	{
+#pragma unroll
+		for (int c = 0; c < 4; ++c)
+		{
+			uint32_t const p = 16u * c + (uint32_t) pp;
+			uint32_t const x = readlane_u32(mine, (int) p);
+			bool const in = lane > p;
+			bits[c] |= (in && x <= runmin[c]) ? (1u << pp) : 0u;
+			runmin[c] = in ? min(runmin[c], x) : runmin[c];
+		}
+	}
+	if (fresh)
+		D.Kr[idx & (DPW - 1u)] = (unsigned long long) (bits[0] | (bits[1] << 16)) | ((unsigned long long) (bits[2] | (bits[3] << 16)) << 32);
+}
+
+// rmq.update, part 2 (rmq.hh:66-80): block blk is complete, push its samples on every level.
+// mb: mailbox slot holding the old level-(p-1) samples for the levels whose input is older than the ring.
+__device__ __forceinline__ void dp_push_samples(DpLds const &D, uint32_t blk, uint32_t mb)
+{
+	uint32_t const lane = lane_id();
+	uint32_t const base = blk * 64u;
+	uint32_t const mine = D.Mr[(base + lane) & (DPW - 1u)];
+	uint32_t const new_val = wave_min_u32(mine);
+	uint32_t const new_smp = base + (uint32_t) __builtin_ctzll(__ballot(mine == new_val));   // first minimum of the block
+	uint32_t const bnum = blk + 1u;
+	if (lane < DP_LEVELS && (1u << lane) <= bnum)
+	{
+		uint32_t const j = bnum - (1u << lane);
+		uint32_t res = new_smp, resv = new_val;
+		if (lane >= 1)
+		{
+			uint32_t smp, sval;
+			if (lane < DP_HPMIN)
+			{
+				smp = D.Tr[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+				sval = D.Trv[(lane - 1u) * DP_TRN + (j & (DP_TRN - 1u))];
+			}
+			else
+			{
+				smp = D.MBi[mb * 64u + lane];
+				sval = D.MBv[mb * 64u + lane];
+			}
+			if (!(new_val < sval)) { res = smp; resv = sval; }    // rmq.hh:76-79 (smp1 == smp2)
+		}
+		D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))] = res;
+		D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))] = resv;
+	}
+}
+
+__global__ __launch_bounds__(1024) void k_dp(
+	DpArrays const A, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t stride,
+	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	lds_char *const lds0 = (lds_char *) smem;
+	uint32_t const lds0_addr = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) lds0);   // LDS byte address of the carve base
+	uint32_t off = 0;
+	auto take = [&](size_t bytes) { uint32_t const o = off; off += (uint32_t) ((bytes + 15) & ~size_t(15)); return o; };
+	DpLds D;
+	D.Kr = (lds_u64 *) (lds0 + take((size_t) DPW * 8));
+	D.Mr = (lds_u32 *) (lds0 + take((size_t) DPW * 4));
+	D.LBr = (lds_u32 *) (lds0 + take((size_t) DP_STG * 4));
+	D.SZr = (lds_u32 *) (lds0 + take((size_t) DP_STG * 4));
+	D.Tr = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	D.Trv = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	uint32_t const off_LS = take((size_t) DP_SLOTS * DP_RL * 64 * 8);
+	uint32_t const off_H = take((size_t) DP_SLOTS * 64 * 16);
+	uint32_t const off_MBi = take((size_t) DP_MBSLOTS * 64 * 4);
+	uint32_t const off_MBv = take((size_t) DP_MBSLOTS * 64 * 4);
+	D.LS = (lds_u32 *) (lds0 + off_LS);
+	D.H = (lds_u32 *) (lds0 + off_H);
+	D.MBi = (lds_u32 *) (lds0 + off_MBi);
+	D.MBv = (lds_u32 *) (lds0 + off_MBv);
+	lds_u32 *const fbcnt = (lds_u32 *) (lds0 + take(16));     // cells per round that needed the general path (ring of 4 rounds)
+
+	uint32_t const wave = __builtin_amdgcn_readfirstlane(wave_id());
+	uint32_t const lane = lane_id();
+	uint32_t const p2lim = min(2u * L, n - L) - 1u;          // lp.cc:72
+	uint32_t const last_end = n - L;                          // lp.cc:113
+
+	// Two schedules.  Classic: rounds of <= min(L, 56) cells, the rmq.update of a round between two
+	// barriers.  Pipelined (L >= 96): rounds of 48 cells -- a round then never reads
+	// what the previous round wrote (a cell reads entries <= end - 2L), so two dedicated waves do
+	// the update of round r-1 while the compute waves are already in round r: one barrier a round.
+	DpSchedule S;
+	S.L = L; S.n = n;
+	S.pipe = L >= 96u;                                        // measured: pays only with 4 cells per compute wave
+	S.RL = S.pipe ? (min(L / 2u, 48u) / 12u) * 12u : min(L, DP_RL);   // pipelined: whole cells per compute wave
+	S.nreg = (last_end - L) / S.RL + 1u;
+	S.nrounds = S.nreg + (S.pipe ? 2u : 1u);
+	uint32_t const NWC = S.pipe ? 12u : DP_NWC;               // compute waves
+	uint32_t const nrounds = S.nrounds, RL = S.RL;
+	uint32_t const npairs = (RL + 1u) / 2u;                    // list DMA instructions per round (+3: headers, mailbox)
+
+	// loader: all LDS-DMA of round R (exactly DP_Q instructions, so that vmcnt counts rounds)
+	auto load_round = [&](uint32_t r) {
+		DpRound const R = dp_round(S, r);
+		uint32_t const slot = r % DP_SLOTS;
+		// (RL + 1) / 2 list loads (two cells each) whatever the round's own length, so that every
+		// round issues the same number of instructions and vmcnt counts rounds
+		// The loader's ~30 issues a round compete with three compute waves of its SIMD (measured: the round
+		// waits for it), so the loop is kept to five instructions a load: M0 saved once, no address select
+		// while both cells of a load exist.
+		uint2 const *src = ent + (size_t) (R.e0 - 1u + (lane >> 5)) * stride + (lane & 31u) * 2u;
+		uint32_t dst = __builtin_amdgcn_readfirstlane(lds0_addr + off_LS + slot * DP_RL * 512u);
+		uint32_t const nfull = R.len / 2u;
+		uint32_t q = 0;
+		uint32_t const m0_keep = m0_save();
+#pragma nounroll
+		for (; q < nfull; ++q)
+		{
+			dma16_m0(src, dst);
+			src += 2u * (size_t) stride;
+			dst += 1024u;
+		}
+#pragma nounroll
+		for (; q < npairs; ++q)
+		{
+			uint32_t const i = 2u * q + (lane >> 5);
+			dma16_m0(i < R.len ? (void const *) src : (void const *) ent, dst);
+			src += 2u * (size_t) stride;
+			dst += 1024u;
+		}
+		m0_restore(m0_keep);
+		{
+			uint32_t const k = (lane < R.len) ? R.e0 + lane - 1u : 0u;
+			dma16(hdr + k, __builtin_amdgcn_readfirstlane(lds0_addr + off_H + slot * 1024u));
+		}
+		{
+			// old sparse-table samples for the block that completes in round R (at most one: RL < 64)
+			uint32_t const blk = R.t0 >> 6;
+			uint32_t const bnum = blk + 1u;
+			bool const completes = R.len > 0 && !R.final_round && bnum * 64u <= R.t1;
+			size_t o = 0;
+			if (completes && lane >= DP_HPMIN && lane < DP_LEVELS && (1u << lane) <= bnum)
+				o = (size_t) (lane - 1u) * A.tstride + (bnum - (1u << lane));
+			uint32_t const mb = r % DP_MBSLOTS;
+			dma4(A.Tb + o, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBi + mb * 256u));
+			dma4(A.Tbv + o, __builtin_amdgcn_readfirstlane(lds0_addr + off_MBv + mb * 256u));
+		}
+	};
+	// writer: round P to HBM (stores only, never waited for)
+	auto flush_round = [&](uint32_t r) {
+		DpRound const P = dp_round(S, r);
+		if (lane < P.len)
+		{
+			uint32_t const t = P.t0 + lane;
+			A.M[t] = D.Mr[t & (DPW - 1u)];
+			A.LB[t] = D.LBr[t & (DP_STG - 1u)];
+			A.SZ[t] = D.SZr[t & (DP_STG - 1u)];
+			if (!P.final_round) A.K[t] = D.Kr[t & (DPW - 1u)];
+		}
+		uint32_t const bnum = (P.t0 >> 6) + 1u;
+		if (P.len > 0 && !P.final_round && bnum * 64u <= P.t1 && lane < DP_LEVELS && (1u << lane) <= bnum)
+		{
+			uint32_t const j = bnum - (1u << lane);
+			A.Tb[(size_t) lane * A.tstride + j] = D.Tr[lane * DP_TRN + (j & (DP_TRN - 1u))];
+			A.Tbv[(size_t) lane * A.tstride + j] = D.Trv[lane * DP_TRN + (j & (DP_TRN - 1u))];
+		}
+	};
+
+	if (wave == DP_LOADER)
+	{
+		load_round(0);
+		if (nrounds > 1) load_round(1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	}
+	if (threadIdx.x < 4) fbcnt[threadIdx.x] = 0;
+	dp_barrier();
+
+#ifdef FSEQ_DP_STAMPS
+	unsigned long long acc[6] = {0, 0, 0, 0, 0, 0};
+#define DP_STAMP(x) unsigned long long x = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F)
+#else
+#define DP_STAMP(x)
+#endif
+	uint32_t pair_cool = 0;                                   // rounds left before this wave tries cell pairs again
+	for (uint32_t r = 0; r < nrounds; ++r)
+	{
+		DP_STAMP(ts0);
+		DpRound const R = dp_round(S, r);
+		uint32_t const slot = r % DP_SLOTS;
+		// Entries < filled are indexed (masks + samples).  The ring keeps the last DPW entries and
+		// this round's (pipelined: this and the previous round's) results land above `filled`, so
+		// anything >= filled + (writes in flight) - DPW (+ margin) is safe to read from LDS.
+		uint32_t filled;
+		if (R.final_round) filled = n - 2u * L + 1u;
+		else if (!S.pipe) filled = R.t0;
+		else filled = (r == 0) ? 0u : dp_round(S, r - 1u).t0;
+		uint32_t const inflight = S.pipe ? 2u * RL : RL;
+		DpView V;
+		V.safe_lo = (filled + inflight + 128u > DPW) ? (filled + inflight + 128u - DPW) : 0u;
+		V.cb = filled >> 6;
+
+		if (wave < NWC)
+		{
+			// ---- compute (one CU's VALU issue rate bounds this phase: a stage-interleaved, branch-free
+			// variant was measured slower)
+			auto single_cell = [&](uint32_t i) {
+				uint32_t const end = R.e0 + i;
+				uint32_t const t = end - L;
+				lds_u32 const *hp = D.H + (slot * 64u + i) * 4u;
+				uint4 const h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+				CellState st;
+				if (!R.final_round && end <= p2lim)
+				{
+					// part 2, lp.cc:85-93
+					st.best_v = m - h.y; st.best_lb = 0; st.best_sz = st.best_v; st.cum_base = 0;
+				}
+				else
+				{
+					lds_u32 const *ls = D.LS + (slot * DP_RL + i) * 128u;
+					uint2 const en = make_uint2(ls[2u * lane], ls[2u * lane + 1u]);
+					uint32_t const vnext = ls[2u * ((lane + 1u) & 63u)];
+					st = dp_cell_sequential(A, D, V, ent + (size_t) (end - 1u) * stride, en, vnext, h, m, L, end, flags);
+				}
+				if (lane == 0)
+				{
+					D.Mr[t & (DPW - 1u)] = st.best_v;
+					D.LBr[t & (DP_STG - 1u)] = st.best_lb;
+					D.SZr[t & (DP_STG - 1u)] = st.best_sz;
+				}
+			};
+			// the choice between cell pairs and full-wave cells must be the same in every wave (it decides
+			// which wave owns which cell): all waves read the same counter of the previous round
+			if (r >= 1u && 2u * fbcnt[(r - 1u) & 3u] > RL) pair_cool = 16u;   // long lists here: full-wave cells for a while
+			if (wave == 0 && lane == 0) fbcnt[(r + 2u) & 3u] = 0;
+			// one copy of each cell routine in the instruction stream (the kernel must stay well inside the
+			// instruction cache): cells for the general path are collected in a wave-uniform bit mask
+			unsigned long long todo = 0;
+			if (!R.final_round && R.e0 > p2lim && pair_cool == 0u)
+			{
+				// two cells per step, one per half wave: pairs wave, wave + NWC
+#pragma nounroll
+				for (uint32_t i0 = 2u * wave; i0 < R.len; i0 += 2u * NWC)
+				{
+					uint64_t const fb = dp_cell_pair(A, D, V, slot, i0, R, m, L, flags);
+					if (fb & 1ull) todo |= 1ull << i0;
+					if (fb >> 32) todo |= 2ull << i0;
+				}
+				if (todo && lane == 0) atomicAdd((uint32_t *) (fbcnt + (r & 3u)), (uint32_t) __popcll(todo));
+			}
+			else
+			{
+				if (pair_cool) --pair_cool;
+				for (uint32_t i = wave; i < R.len; i += NWC) todo |= 1ull << i;
+			}
+#pragma nounroll
+			while (todo)
+			{
+				uint32_t const i = (uint32_t) __builtin_ctzll(todo);
+				todo &= todo - 1ull;
+				single_cell(i);
+			}
+		}
+		else if (wave == DP_LOADER)
+		{
+			// ---- loader: lists of round r+2; then make sure round r+1 has landed
+			if (r + 2u < nrounds)
+			{
+				load_round(r + 2u);
+				dp_wait_all_but(npairs + 3u);                  // = everything but the round just issued
+			}
+			else
+				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
+		else if (wave == DP_WRITER)
+		{
+			// ---- writer: a finished *and indexed* round to HBM
+			uint32_t const lag = S.pipe ? 2u : 1u;
+			if (r >= lag) flush_round(r - lag);
+		}
+		else
+		{
+			// ---- pipelined mode, waves 12 and 13: rmq.update of round r-1 (rmq.hh:61-81)
+			if (r >= 1u)
+			{
+				DpRound const P = dp_round(S, r - 1u);
+				if (P.len > 0 && !P.final_round)
+				{
+					uint32_t const blkA = P.t0 >> 6, blkB = (P.t1 - 1u) >> 6;
+					if (wave == 12u)
+					{
+						dp_mask_block(D, P, blkA);
+						if ((blkA + 1u) * 64u <= P.t1) dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
+					}
+					else if (blkB != blkA)
+						dp_mask_block(D, P, blkB);
+				}
+			}
+		}
+		DP_STAMP(ts1);
+		dp_barrier();
+		DP_STAMP(ts2);
+		if (R.final_round) break;                             // no rmq.update after the last cell
+		if (S.pipe)
+		{
+#ifdef FSEQ_DP_STAMPS
+			acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[4] += 1;
+#endif
+			continue;
+		}
+
+		// ---- classic mode: rmq.update for the new entries [t0, t1) (rmq.hh:61-81).  At most two
+		// 64-blocks are touched and at most one completes (RL < 64).  Eight waves build the stack
+		// masks, each a 16-bit slice of one block; a ninth pushes the sparse-table samples.
+		{
+			uint32_t const blkA = R.t0 >> 6, blkB = (R.t1 - 1u) >> 6;
+			uint32_t const nslices = 4u * (blkB - blkA + 1u);
+			if (wave < nslices)
+				dp_mask_slice(D, R, blkA + (wave >> 2), wave & 3u);
+			else if (wave == 8 && (blkA + 1u) * 64u <= R.t1)
+				dp_push_samples(D, blkA, r % DP_MBSLOTS);
+		}
+		DP_STAMP(ts3);
+		dp_barrier();
+#ifdef FSEQ_DP_STAMPS
+		{
+			DP_STAMP(ts4);
+			acc[0] += ts1 - ts0; acc[1] += ts2 - ts1; acc[2] += ts3 - ts2; acc[3] += ts4 - ts3; acc[4] += 1;
+		}
+#endif
+	}
+#ifdef FSEQ_DP_STAMPS
+	if (lane == 0)
+	{
+		unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 8) + wave * 3u;
+		o[0] = acc[0]; o[1] = acc[1] + acc[2] + acc[3]; o[2] = acc[4];
+	}
+#endif
+
+	// the writer flushes what is still only in LDS
+	if (wave == DP_WRITER)
+	{
+		uint32_t const lag = S.pipe ? 2u : 1u;
+		for (uint32_t r = (nrounds >= lag ? nrounds - lag : 0u); r < nrounds; ++r) flush_round(r);
+	}
+}
+
+} // namespace fseq
