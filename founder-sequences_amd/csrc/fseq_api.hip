@@ -35,7 +35,8 @@ struct KernelSet {
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
-	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d);
+	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0);
+	uint32_t (*columns_resident)(size_t lds);                 // workgroups of k_columns one CU holds
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -69,10 +70,16 @@ struct Launch {
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d)
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0)
 	{
 		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-		                   snap_stride, ss_a, ss_d);
+		                   snap_stride, ss_a, ss_d, block0);
+	}
+	static uint32_t columns_resident(size_t lds)
+	{
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns<T, E, SIGMA, PK>, T, lds) != hipSuccess || nb < 1) nb = 1;
+		return (uint32_t) nb;
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
@@ -96,7 +103,7 @@ struct Launch {
 		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
 		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
 		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
-		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns;
+		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
 		k.lds_chain = chain_lds_bytes<T, E, PK>();
 		k.chain = &chain; k.prepare = &prepare;
 		return k;
@@ -199,6 +206,9 @@ struct fseq_ctx {
 	std::vector<uint32_t> sp_first, sp_len;
 	fseq_timings tm{};
 	hipEvent_t ev[8]{};
+	hipStream_t stream2 = nullptr;           // the DP, while phase C is still producing lists for later columns
+	hipEvent_t ev_part[16]{};                // part c of phase C done
+	hipEvent_t ev_dp[2]{};                   // DP begin / end on stream2
 };
 
 namespace {
@@ -330,7 +340,8 @@ int prepare_geometry(fseq_ctx *c)
 			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
 	}
-	HIP_TRY(c, allow_lds(k_dp, dp_lds_bytes()));
+	HIP_TRY(c, allow_lds(k_dp<false>, dp_lds_bytes()));
+	HIP_TRY(c, allow_lds(k_dp<true>, dp_lds_bytes()));
 	c->kernels_ready = true;
 	return FSEQ_OK;
 }
@@ -634,15 +645,87 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 #else
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 #endif
+		// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
+		// rounds whose lists are complete, on a second stream: the DP of a column prefix runs while later
+		// columns are still being produced.  Only where one workgroup of the column kernel fills a CU (16-bit
+		// and streamed state) and a launch has several waves of them anyway: a part is then ncu - 1
+		// workgroups per wave, which leaves the DP (a whole CU's LDS) a CU of its own.  FSEQ_C_PARTS forces a count.
+		DpSchedule const S = dp_schedule((uint32_t) L, (uint32_t) n);
+		uint32_t parts = 1, part_blocks = c->nblocks;
+		{
+			int ncu = 0;
+			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+			uint32_t const per_cu = c->use_stream ? 1u : ks.columns_resident(c->lds_columns);
+			if (per_cu == 1u && ncu > 1 && c->nblocks >= 2u * (uint32_t) ncu)
+			{
+				uint32_t const wave_blocks = (uint32_t) ncu - 1u;
+				uint32_t const waves = (c->nblocks + wave_blocks - 1) / wave_blocks;
+				part_blocks = wave_blocks * ((waves + 7u) / 8u);
+				parts = (c->nblocks + part_blocks - 1) / part_blocks;
+			}
+			if (char const *e = getenv("FSEQ_C_PARTS"))
+			{
+				parts = (uint32_t) std::min<long>(16, std::max<long>(1, atol(e)));
+				parts = std::min(parts, c->nblocks);
+				part_blocks = (c->nblocks + parts - 1) / parts;
+				parts = (c->nblocks + part_blocks - 1) / part_blocks;
+			}
+		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		if (c->use_stream)
-			hipLaunchKernelGGL(k_columns_stream, dim3(c->nblocks), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d);
+		auto launch_columns = [&](uint32_t b0, uint32_t nb) {
+			if (c->use_stream)
+				hipLaunchKernelGGL(k_columns_stream, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0);
+			else
+				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
+				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0);
+		};
+		if (parts <= 1)
+		{
+			launch_columns(0, c->nblocks);
+			HIP_TRY(c, hipEventRecord(c->ev[4], st));
+			// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
+			// each resuming from the arrays the one before it flushed
+			uint32_t chunks = 1;
+			if (char const *e = getenv("FSEQ_DP_CHUNKS")) chunks = (uint32_t) std::max(1, atoi(e));
+			chunks = std::min(chunks, S.nrounds);
+			HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
+			if (chunks <= 1)
+				hipLaunchKernelGGL(k_dp<false>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, 0u, S.nrounds);
+			for (uint32_t k = 0; chunks > 1 && k < chunks; ++k)
+			{
+				uint32_t const r0 = (uint32_t) ((uint64_t) S.nrounds * k / chunks), r1 = (uint32_t) ((uint64_t) S.nrounds * (k + 1) / chunks);
+				hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, r0, r1);
+			}
+			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
+		}
 		else
-			ks.columns(st, c->nblocks, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
-			           c->snap_stride, c->d_ss_a, c->d_ss_d);
-		HIP_TRY(c, hipEventRecord(c->ev[4], st));
-		hipLaunchKernelGGL(k_dp, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L, c->d_flags);
+		{
+			hipStream_t const st2 = c->stream2;
+			uint32_t r_done = 0;
+			bool dp_started = false;
+			for (uint32_t k = 0; k < parts; ++k)
+			{
+				uint32_t const b0 = k * part_blocks, nb = std::min(part_blocks, c->nblocks - b0);
+				launch_columns(b0, nb);
+				HIP_TRY(c, hipEventRecord(c->ev_part[k], st));
+				uint64_t const col_hi = std::min<uint64_t>(n, (uint64_t) (b0 + nb) * c->B);
+				uint32_t const r1 = (k + 1 == parts) ? S.nrounds : dp_rounds_within(S, col_hi);
+				if (r1 > r_done)
+				{
+					HIP_TRY(c, hipStreamWaitEvent(st2, c->ev_part[k], 0));
+					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
+					hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+					                   c->d_flags, r_done, r1);
+					r_done = r1;
+				}
+			}
+			HIP_TRY(c, hipEventRecord(c->ev[4], st));
+			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
+			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
+		}
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
 		HIP_TRY(c, hipGetLastError());
 
@@ -656,7 +739,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		{
 			float f = 0;
 			HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
-			HIP_TRY(c, hipEventElapsedTime(&f, c->ev[4], c->ev[5])); ms_dp += f;
+			HIP_TRY(c, hipEventElapsedTime(&f, c->ev_dp[0], c->ev_dp[1])); ms_dp += f;     // overlaps phase C when that runs in parts
 		}
 #ifdef FSEQ_DP_STAMPS
 		{
@@ -944,6 +1027,11 @@ int fseq_create(fseq_params const *params, fseq_ctx **out)
 	fseq_ctx *c = new fseq_ctx();
 	c->p = *params;
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	for (auto &e : c->ev_part)
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	for (auto &e : c->ev_dp)
+		if (hipEventCreate(&e) != hipSuccess) { delete c; return FSEQ_E_HIP; }
 	for (auto &e : c->ev)
 		if (hipEventCreate(&e) != hipSuccess) { delete c; return FSEQ_E_HIP; }
 	*out = c;
@@ -958,6 +1046,9 @@ void fseq_destroy(fseq_ctx *c)
 	free_msa(c);
 	free_work(c);
 	for (auto &e : c->ev) if (e) (void) hipEventDestroy(e);
+	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
+	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
+	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;
 }

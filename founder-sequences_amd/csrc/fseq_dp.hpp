@@ -442,17 +442,50 @@ struct DpSchedule {
 	bool pipe;
 };
 
-__device__ __forceinline__ DpRound dp_round(DpSchedule const &S, uint32_t r)
+__host__ __device__ inline DpRound dp_round(DpSchedule const &S, uint32_t r)
 {
 	DpRound R;
 	uint32_t const last_end = S.n - S.L;
 	R.final_round = (r + 1u == S.nrounds);
 	bool const regular = r < S.nreg;
 	R.e0 = R.final_round ? S.n : (regular ? S.L + r * S.RL : last_end + 1u);
-	R.len = R.final_round ? 1u : (regular ? min(S.RL, last_end - R.e0 + 1u) : 0u);
+	uint32_t const rest = last_end - R.e0 + 1u;
+	R.len = R.final_round ? 1u : (regular ? (S.RL < rest ? S.RL : rest) : 0u);
 	R.t0 = R.e0 - S.L;
 	R.t1 = R.t0 + R.len;
 	return R;
+}
+
+// Two schedules.  Classic: rounds of <= min(L, DP_RL) cells, the rmq.update of a round between two
+// barriers.  Pipelined (L >= 96): rounds of 48 cells -- a round then never reads what the previous
+// round wrote (a cell reads entries <= end - 2L), so two dedicated waves do the update of round r-1
+// while the compute waves are already in round r: one barrier a round.
+__host__ __device__ inline DpSchedule dp_schedule(uint32_t L, uint32_t n)
+{
+	DpSchedule S;
+	S.L = L; S.n = n;
+	S.pipe = L >= 96u;                                        // measured: pays only with 4 cells per compute wave
+	uint32_t const half = L / 2u < 48u ? L / 2u : 48u;
+	S.RL = S.pipe ? (half / 12u) * 12u : (L < DP_RL ? L : DP_RL);   // pipelined: whole cells per compute wave
+	S.nreg = ((n - L) - L) / S.RL + 1u;
+	S.nrounds = S.nreg + (S.pipe ? 2u : 1u);
+	return S;
+}
+
+// Rounds of the schedule whose cells only need the lists of columns < col_hi (a cell `end` reads the list
+// of column end - 1): the DP of a column prefix can run while later columns are still being produced.
+__host__ __device__ inline uint32_t dp_rounds_within(DpSchedule const &S, uint64_t col_hi)
+{
+	if (col_hi >= S.n) return S.nrounds;
+	uint32_t lo = 0, hi = S.nrounds;                          // first round that needs a column >= col_hi
+	while (lo < hi)
+	{
+		uint32_t const mid = (lo + hi) / 2u;
+		DpRound const R = dp_round(S, mid);
+		bool const needs = R.len > 0 && (uint64_t) R.e0 + R.len - 2u >= col_hi;
+		if (needs) hi = mid; else lo = mid + 1u;
+	}
+	return lo;
 }
 
 __device__ __forceinline__ void dp_barrier()
@@ -569,10 +602,16 @@ __device__ __forceinline__ void dp_push_samples(DpLds const &D, uint32_t blk, ui
 	}
 }
 
+// PARTIAL = false: the whole schedule in one launch (r_begin_arg / r_end_arg ignored: the common case keeps
+// its registers).
+template <bool PARTIAL>
 __global__ __launch_bounds__(1024) void k_dp(
 	DpArrays const A, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t stride,
-	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags)
+	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags, uint32_t r_begin_arg, uint32_t r_end_arg)
 {
+	// Rounds [r_begin, r_end) of the schedule.  A launch that does not start at round 0 restores the LDS
+	// rings from the arrays the launch before it flushed; one that stops early completes the rmq.update
+	// of its last round before it flushes (pipelined schedule: one more iteration without cells).
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	lds_char *const lds0 = (lds_char *) smem;
 	uint32_t const lds0_addr = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) lds0);   // LDS byte address of the carve base
@@ -600,18 +639,12 @@ __global__ __launch_bounds__(1024) void k_dp(
 	uint32_t const p2lim = min(2u * L, n - L) - 1u;          // lp.cc:72
 	uint32_t const last_end = n - L;                          // lp.cc:113
 
-	// Two schedules.  Classic: rounds of <= min(L, 56) cells, the rmq.update of a round between two
-	// barriers.  Pipelined (L >= 96): rounds of 48 cells -- a round then never reads
-	// what the previous round wrote (a cell reads entries <= end - 2L), so two dedicated waves do
-	// the update of round r-1 while the compute waves are already in round r: one barrier a round.
-	DpSchedule S;
-	S.L = L; S.n = n;
-	S.pipe = L >= 96u;                                        // measured: pays only with 4 cells per compute wave
-	S.RL = S.pipe ? (min(L / 2u, 48u) / 12u) * 12u : min(L, DP_RL);   // pipelined: whole cells per compute wave
-	S.nreg = (last_end - L) / S.RL + 1u;
-	S.nrounds = S.nreg + (S.pipe ? 2u : 1u);
+	DpSchedule const S = dp_schedule(L, n);
 	uint32_t const NWC = S.pipe ? 12u : DP_NWC;               // compute waves
 	uint32_t const nrounds = S.nrounds, RL = S.RL;
+	uint32_t const r_begin = PARTIAL ? r_begin_arg : 0u, r_end = PARTIAL ? r_end_arg : nrounds;
+	bool const stops_early = PARTIAL && r_end < nrounds;
+	uint32_t const r_stop = (S.pipe && stops_early) ? r_end + 1u : r_end;   // pipelined: + the drain iteration
 	uint32_t const npairs = (RL + 1u) / 2u;                    // list DMA instructions per round (+3: headers, mailbox)
 
 	// loader: all LDS-DMA of round R (exactly DP_Q instructions, so that vmcnt counts rounds)
@@ -681,13 +714,40 @@ __global__ __launch_bounds__(1024) void k_dp(
 		}
 	};
 
+	if (PARTIAL && r_begin > 0u)
+	{
+		// resume: entries < T0 are computed, indexed and in HBM
+		uint32_t const tid = threadIdx.x;
+		uint32_t const T0 = dp_round(S, r_begin).t0;
+		for (uint32_t t = (T0 > DPW ? T0 - DPW : 0u) + tid; t < T0; t += 1024u)
+		{
+			D.Mr[t & (DPW - 1u)] = A.M[t];
+			D.Kr[t & (DPW - 1u)] = A.K[t];
+		}
+		uint32_t const cb = T0 >> 6;
+		for (uint32_t idx = tid; idx < DP_LEVELS * DP_TRN; idx += 1024u)
+		{
+			uint32_t const p = idx / DP_TRN, q = idx % DP_TRN;
+			if (p < 31u && (1u << p) <= cb)
+			{
+				uint32_t const jmax = cb - (1u << p);             // newest sample of level p
+				uint32_t const back = (jmax - q) & (DP_TRN - 1u);  // the one sample j = q (mod DP_TRN) among the last DP_TRN
+				if (back <= jmax)
+				{
+					uint32_t const j = jmax - back;
+					D.Tr[idx] = A.Tb[(size_t) p * A.tstride + j];
+					D.Trv[idx] = A.Tbv[(size_t) p * A.tstride + j];
+				}
+			}
+		}
+	}
 	if (wave == DP_LOADER)
 	{
-		load_round(0);
-		if (nrounds > 1) load_round(1);
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		load_round(r_begin);
+		if (r_begin + 1u < r_end) load_round(r_begin + 1u);
 	}
 	if (threadIdx.x < 4) fbcnt[threadIdx.x] = 0;
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	dp_barrier();
 
 #ifdef FSEQ_DP_STAMPS
@@ -697,9 +757,10 @@ __global__ __launch_bounds__(1024) void k_dp(
 #define DP_STAMP(x)
 #endif
 	uint32_t pair_cool = 0;                                   // rounds left before this wave tries cell pairs again
-	for (uint32_t r = 0; r < nrounds; ++r)
+	for (uint32_t r = r_begin; r < r_stop; ++r)
 	{
 		DP_STAMP(ts0);
+		bool const drain = PARTIAL && (r == r_end);               // no cells: only the update of round r - 1
 		DpRound const R = dp_round(S, r);
 		uint32_t const slot = r % DP_SLOTS;
 		// Entries < filled are indexed (masks + samples).  The ring keeps the last DPW entries and
@@ -714,7 +775,10 @@ __global__ __launch_bounds__(1024) void k_dp(
 		V.safe_lo = (filled + inflight + 128u > DPW) ? (filled + inflight + 128u - DPW) : 0u;
 		V.cb = filled >> 6;
 
-		if (wave < NWC)
+		if (wave < NWC && drain)
+		{
+		}
+		else if (wave < NWC)
 		{
 			// ---- compute (one CU's VALU issue rate bounds this phase: a stage-interleaved, branch-free
 			// variant was measured slower)
@@ -778,7 +842,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 		else if (wave == DP_LOADER)
 		{
 			// ---- loader: lists of round r+2; then make sure round r+1 has landed
-			if (r + 2u < nrounds)
+			if (r + 2u < r_end)
 			{
 				load_round(r + 2u);
 				dp_wait_all_but(npairs + 3u);                  // = everything but the round just issued
@@ -790,12 +854,13 @@ __global__ __launch_bounds__(1024) void k_dp(
 		{
 			// ---- writer: a finished *and indexed* round to HBM
 			uint32_t const lag = S.pipe ? 2u : 1u;
-			if (r >= lag) flush_round(r - lag);
+			if (r >= r_begin + lag) flush_round(r - lag);
 		}
 		else
 		{
-			// ---- pipelined mode, waves 12 and 13: rmq.update of round r-1 (rmq.hh:61-81)
-			if (r >= 1u)
+			// ---- pipelined mode, waves 12 and 13: rmq.update of round r-1 (rmq.hh:61-81); the launch before
+			// this one has done it for the round in front of r_begin
+			if (r > r_begin)
 			{
 				DpRound const P = dp_round(S, r - 1u);
 				if (P.len > 0 && !P.final_round)
@@ -814,7 +879,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 		DP_STAMP(ts1);
 		dp_barrier();
 		DP_STAMP(ts2);
-		if (R.final_round) break;                             // no rmq.update after the last cell
+		if (R.final_round && !drain) break;                   // no rmq.update after the last cell
 		if (S.pipe)
 		{
 #ifdef FSEQ_DP_STAMPS
@@ -855,7 +920,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 	if (wave == DP_WRITER)
 	{
 		uint32_t const lag = S.pipe ? 2u : 1u;
-		for (uint32_t r = (nrounds >= lag ? nrounds - lag : 0u); r < nrounds; ++r) flush_round(r);
+		for (uint32_t r = (r_stop >= r_begin + lag ? r_stop - lag : r_begin); r < r_end; ++r) flush_round(r);
 	}
 }
 

@@ -602,8 +602,9 @@ __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
-	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0)
 {
+	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// [a_l][d_l][sym0][sym1][cnt_l] are contiguous: the prologue's sort buffer (N2 < 2m words) overlays them
@@ -620,7 +621,7 @@ __global__ __launch_bounds__(T) void k_columns(
 
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = tid * E;
-	uint64_t const k0 = (uint64_t) blockIdx.x * B;
+	uint64_t const k0 = (uint64_t) (blockIdx.x + block0) * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	uint32_t const nb = (uint32_t) (kend - k0);
 
@@ -628,7 +629,7 @@ __global__ __launch_bounds__(T) void k_columns(
 	// boundary state straight into registers (chunk ownership: positions tid*E .. tid*E+E-1)
 	uint32_t a[E], d[E];
 	{
-		size_t const ob = (size_t) blockIdx.x * m;
+		size_t const ob = (size_t) (blockIdx.x + block0) * m;
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{

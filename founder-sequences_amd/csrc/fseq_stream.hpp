@@ -391,7 +391,7 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
-	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d)
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -399,15 +399,16 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 	StreamLds &L = *cv.take<StreamLds>(1);
 	uint32_t *const stage = staged ? cv.take<uint32_t>(2 * (size_t) SCAP) : nullptr;
 	uint32_t const tid = threadIdx.x;
-	uint32_t *w = ws + (size_t) blockIdx.x * columns_stream_ws_words(m, B);
+	uint32_t const blk = blockIdx.x + block0;                  // phase C may be launched in several parts
+	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
 	uint32_t *buf[2][2] = {{w, w + m}, {w + 2u * (size_t) m, w + 3u * (size_t) m}};
 	uint32_t *keys[2] = {w + 4u * (size_t) m, w + 5u * (size_t) m};
 	uint32_t *V = w + 6u * (size_t) m, *Vpos = w + 7u * (size_t) m, *cnt = w + 8u * (size_t) m;
 
-	uint64_t const k0 = (uint64_t) blockIdx.x * B;
+	uint64_t const k0 = (uint64_t) blk * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	uint32_t const nb = (uint32_t) (kend - k0);
-	uint32_t const *sa = bstate_a + (size_t) blockIdx.x * m, *sd = bstate_d + (size_t) blockIdx.x * m;
+	uint32_t const *sa = bstate_a + (size_t) blk * m, *sd = bstate_d + (size_t) blk * m;
 
 	// ---- prologue: sort the boundary divergences (2-bit LSD passes), distinct values -> V, counts, ids
 	for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = sa[i]; keys[0][i] = sd[i]; }

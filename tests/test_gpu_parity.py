@@ -484,3 +484,19 @@ def test_native_batch_runner(pkg):
         assert ctx.result.max_segment_size == ref["max_segment_size"]
         for f in ("lb", "rb", "segment_size"):
             assert np.array_equal(red[f], ref["reduced"][f])
+
+
+@pytest.mark.parametrize("parts,chunks", [(3, 0), (16, 0), (0, 5)])
+def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, chunks):
+    """Phase C launched in parts with the DP of the finished column prefix running beside it on a second
+    stream (what large 16-bit / streamed inputs do by themselves), and the DP alone in several resumed
+    launches: the LDS rings restored from HBM must give bit-identical results, also on the pipelined
+    schedule (L >= 96) and on the streamed kernels."""
+    if parts:
+        monkeypatch.setenv("FSEQ_C_PARTS", str(parts))
+    if chunks:
+        monkeypatch.setenv("FSEQ_DP_CHUNKS", str(chunks))
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 50), (900, 5000, 100, 10, 300, 1e-3, 52, 1, 64),
+                                                  (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, block_len=B)
