@@ -35,7 +35,7 @@ struct KernelSet {
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
-	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0);
+	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch);
 	uint32_t (*columns_resident)(size_t lds);                 // workgroups of k_columns one CU holds
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -70,10 +70,10 @@ struct Launch {
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0)
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch)
 	{
 		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-		                   snap_stride, ss_a, ss_d, block0);
+		                   snap_stride, ss_a, ss_d, block0, done_host, epoch);
 	}
 	static uint32_t columns_resident(size_t lds)
 	{
@@ -209,6 +209,8 @@ struct fseq_ctx {
 	hipStream_t stream2 = nullptr;           // the DP, while phase C is still producing lists for later columns
 	hipEvent_t ev_part[16]{};                // part c of phase C done
 	hipEvent_t ev_dp[2]{};                   // DP begin / end on stream2
+	uint32_t *h_done = nullptr, *d_done = nullptr;   // per-block "lists are in memory" flags in host-coherent memory (host / device view)
+	uint32_t done_cap = 0, epoch = 0;
 };
 
 namespace {
@@ -672,15 +674,66 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			}
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		auto launch_columns = [&](uint32_t b0, uint32_t nb) {
+		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
 			if (c->use_stream)
 				hipLaunchKernelGGL(k_columns_stream, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0);
+				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 			else
 				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
-				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0);
+				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 		};
-		if (parts <= 1)
+		// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
+		// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
+		// launches on the second stream).  Phase C keeps its efficiency (no drain between parts).
+		bool const host_flags = (parts > 1 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_NO_HOST_FLAGS")) || getenv("FSEQ_HOST_FLAGS");
+		if (host_flags)
+		{
+			if (c->done_cap < c->nblocks)
+			{
+				if (c->h_done) (void) hipHostFree(c->h_done);
+				c->h_done = nullptr;
+				HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_done), (size_t) c->nblocks * 4, hipHostMallocMapped | hipHostMallocCoherent));
+				HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0));
+				memset(c->h_done, 0, (size_t) c->nblocks * 4);
+				c->done_cap = c->nblocks;
+				c->epoch = 0;
+			}
+			uint32_t const epoch = ++c->epoch;
+			hipStream_t const st2 = c->stream2;
+			launch_columns(0, c->nblocks, c->d_done, epoch);
+			HIP_TRY(c, hipEventRecord(c->ev[4], st));
+			HIP_TRY(c, hipGetLastError());
+			// the host follows the completed block prefix and hands the DP the rounds whose lists are complete
+			uint32_t prefix = 0, r_done = 0;
+			uint32_t const min_rounds = getenv("FSEQ_HOST_FLAGS") ? 1u : std::max(64u, S.nrounds / 12u);   // forced (tests): as many resumed launches as possible
+			bool dp_started = false;
+			double const t_wait0 = now_ms();
+			while (r_done < S.nrounds)
+			{
+				while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
+				uint32_t const r1 = (prefix == c->nblocks) ? S.nrounds : dp_rounds_within(S, std::min<uint64_t>(n, (uint64_t) prefix * c->B));
+				if (r1 > r_done && (r1 - r_done >= min_rounds || prefix == c->nblocks))
+				{
+					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
+					hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+					                   c->d_flags, r_done, r1);
+					r_done = r1;
+					continue;
+				}
+				if (hipStreamQuery(st) == hipSuccess && prefix < c->nblocks)
+				{
+					// phase C has finished but a flag is missing: should not happen; do not spin for ever
+					while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
+					if (prefix < c->nblocks) prefix = c->nblocks;
+					continue;
+				}
+				if (now_ms() - t_wait0 > 600e3) return fail(c, FSEQ_E_HIP, "timed out waiting for phase C");
+				std::this_thread::yield();
+			}
+			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
+			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
+		}
+		else if (parts <= 1)
 		{
 			launch_columns(0, c->nblocks);
 			HIP_TRY(c, hipEventRecord(c->ev[4], st));
@@ -1048,6 +1101,7 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
+	if (c->h_done) (void) hipHostFree(c->h_done);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;

@@ -375,4 +375,21 @@ __device__ __forceinline__ void partition_step(
 	}
 }
 
+// A workgroup publishes "all my global stores are done" to the HOST: every storing wave drains its stores,
+// the workgroup meets, one lane releases at system scope (the XCD L2's dirty lines are written back) and
+// stores the flag into host-coherent memory.  The consumer is never a running kernel: the host polls the
+// flag and only then launches the kernel that reads the data, whose dispatch carries the acquire
+// (MI355X_MICROARCH.md, inter-workgroup visibility: producer form; HSA memory model for the rest).
+__device__ __forceinline__ void publish_block_done(uint32_t *done_host, uint32_t index, uint32_t epoch)
+{
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__syncthreads();
+	if (done_host && threadIdx.x == 0)
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__hip_atomic_store(done_host + index, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
 } // namespace fseq

@@ -602,7 +602,8 @@ __global__ __launch_bounds__(T) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
-	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0)
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
+	uint32_t *done_host, uint32_t epoch)
 {
 	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
 	constexpr uint32_t CAP = T * E;
@@ -807,6 +808,8 @@ __global__ __launch_bounds__(T) void k_columns(
 			}
 		}
 	}
+	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
+	publish_block_done(done_host, blockIdx.x + block0, epoch);
 }
 
 // List-capacity estimate: the length-L segment ending at block boundary k has #{i : d_k[i] > k - L} distinct

@@ -391,7 +391,8 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
-	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0)
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
+	uint32_t *done_host, uint32_t epoch)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -529,6 +530,7 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 		}
 		__syncthreads();
 	}
+	publish_block_done(done_host, blk, epoch);
 }
 
 } // namespace fseq

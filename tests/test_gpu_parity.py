@@ -486,13 +486,16 @@ def test_native_batch_runner(pkg):
             assert np.array_equal(red[f], ref["reduced"][f])
 
 
-@pytest.mark.parametrize("parts,chunks", [(3, 0), (16, 0), (0, 5)])
+@pytest.mark.parametrize("parts,chunks", [(-1, 0), (3, 0), (16, 0), (0, 5)])
 def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, chunks):
-    """Phase C launched in parts with the DP of the finished column prefix running beside it on a second
-    stream (what large 16-bit / streamed inputs do by themselves), and the DP alone in several resumed
-    launches: the LDS rings restored from HBM must give bit-identical results, also on the pipelined
-    schedule (L >= 96) and on the streamed kernels."""
-    if parts:
+    """The DP of the finished column prefix running beside phase C on a second stream -- what large 16-bit /
+    streamed inputs do by themselves: ONE phase C launch whose workgroups flag the host, which launches
+    resumed DP kernels (parts = -1: forced, as many launches as possible), or phase C launched in parts --
+    and the DP alone in several resumed launches: the LDS rings restored from HBM must give bit-identical
+    results, also on the pipelined schedule (L >= 96) and on the streamed kernels."""
+    if parts < 0:
+        monkeypatch.setenv("FSEQ_HOST_FLAGS", "1")
+    elif parts:
         monkeypatch.setenv("FSEQ_C_PARTS", str(parts))
     if chunks:
         monkeypatch.setenv("FSEQ_DP_CHUNKS", str(chunks))
