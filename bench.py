@@ -147,14 +147,14 @@ def main():
     # run inside this process); only quoted when it was taken on this workload
     traffic, traffic_src = None, None
     try:
-        prof = os.path.join(ROOT, "profiles", "r01_f_pmc_traffic.json")
+        prof = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
         if args.workload == "C2" and os.path.exists(prof):
             with open(prof) as f:
                 pk = json.load(f)["kernels"]
             for name, d in pk.items():
                 if "k_columns" in name and "hbm_bytes_per_launch_corrected" in d:
                     traffic = d["hbm_bytes_per_launch_corrected"]
-                    traffic_src = "profiles/r01_f_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"
+                    traffic_src = "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"
     except Exception:
         traffic = None
     steps = max(1, args.steps)
