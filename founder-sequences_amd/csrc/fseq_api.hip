@@ -1079,14 +1079,14 @@ int fseq_create(fseq_params const *params, fseq_ctx **out)
 	if (hipSetDevice(params->device) != hipSuccess) return FSEQ_E_HIP;
 	fseq_ctx *c = new fseq_ctx();
 	c->p = *params;
-	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return FSEQ_E_HIP; }
-	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
+	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	for (auto &e : c->ev_part)
-		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+		if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	for (auto &e : c->ev_dp)
-		if (hipEventCreate(&e) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+		if (hipEventCreate(&e) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	for (auto &e : c->ev)
-		if (hipEventCreate(&e) != hipSuccess) { delete c; return FSEQ_E_HIP; }
+		if (hipEventCreate(&e) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	*out = c;
 	return FSEQ_OK;
 }
