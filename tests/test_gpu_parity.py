@@ -503,3 +503,40 @@ def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, ch
                                                   (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0)]:
         msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
         compare_long(pkg, msa, L, block_len=B)
+
+
+def test_host_flag_overlap_under_load(pkg, monkeypatch):
+    """The path large 16-bit inputs take by themselves (one phase C launch flagging the host, resumed DP launches
+    beside it), repeated while another context keeps the chip unevenly busy: every run must equal the run
+    with the overlap switched off."""
+    import threading
+    m, n, L = 10000, 600000, 100                      # 600 blocks of 1000 columns, one workgroup per CU
+    monkeypatch.setenv("FSEQ_NO_HOST_FLAGS", "1")
+    ref = pkg.SegmentationContext(m, n, L)
+    ref.generate_synthetic(0x5EED0005, 32, 5000, 1e-4, 1)
+    ref.run()
+    want, want_tb = ref.reduced_traceback().copy(), ref.traceback().copy()
+    a0, d0 = ref.boundary_state(len(want) // 2)
+    ref.close()
+    monkeypatch.delenv("FSEQ_NO_HOST_FLAGS")
+    stop = []
+
+    def noise():
+        c = pkg.SegmentationContext(2500, 100000, 50)
+        c.generate_synthetic(1, 16, 2000, 1e-4, 0)
+        while not stop:
+            c.run()
+
+    th = threading.Thread(target=noise)
+    th.start()
+    try:
+        ctx = pkg.SegmentationContext(m, n, L)
+        ctx.generate_synthetic(0x5EED0005, 32, 5000, 1e-4, 1)
+        for _ in range(4):
+            ctx.run()
+            assert np.array_equal(ctx.reduced_traceback(), want) and np.array_equal(ctx.traceback(), want_tb)
+            a, d = ctx.boundary_state(len(want) // 2)
+            assert np.array_equal(a, a0) and np.array_equal(d, d0)
+    finally:
+        stop.append(1)
+        th.join()
