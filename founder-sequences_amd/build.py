@@ -52,6 +52,24 @@ def build_cli(force=False):
     return CLI_OUT
 
 
+AUX_TOOLS = ("remove_identity_columns", "insert_identity_columns", "match_founder_sequences")
+
+
+def build_aux(force=False):
+    """The reference's three auxiliary tools (host only, no GPU): same option surface, built with g++."""
+    os.makedirs(os.path.dirname(CLI_OUT), exist_ok=True)
+    outs = []
+    for name in AUX_TOOLS:
+        src = os.path.join(HERE, "host", name + ".cpp")
+        out = os.path.join(HERE, "bin", name)
+        deps = [src, os.path.join(HERE, "host", "aux_common.hpp")]
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+            subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", src, "-o", out], check=True)
+        outs.append(out)
+    return outs
+
+
 if __name__ == "__main__":
+    build_aux(force="--force" in sys.argv)
     build_cli(force="--force" in sys.argv)
     print(build(force="--force" in sys.argv, verbose=True))
