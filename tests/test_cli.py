@@ -136,3 +136,30 @@ def test_end_to_end_default_and_random_joining(cli, tmp_path):
             assert {bytes(msa[i, lb:rb]) for i in range(m)} == {line[lb:rb] for line in lines[:-1]}
         seg = segments.read_bytes()
         assert seg.startswith(header) and seg.count(b"\n") > len(red)
+
+
+@pytest.mark.gpu
+def test_founders_cover_every_input_sequence(cli, tmp_path):
+    """End to end with the reference's own validator: founders written by founder_sequences, then
+    match_founder_sequences threads every input sequence through them -- no character may be missing and the
+    pieces must tile each sequence."""
+    build = importlib.import_module("founder-sequences_amd.build")
+    matcher = [p for p in build.build_aux() if p.endswith("match_founder_sequences")][0]
+    m, n, L = 60, 1500, 20
+    msa = np.ascontiguousarray(fso.synth_msa(fso.synth_spec(71, 6, 130, 4e-3), m, n))
+    paths = []
+    for r in range(m):
+        (tmp_path / ("seq%d.txt" % r)).write_bytes(bytes(msa[r]))
+        paths.append(str(tmp_path / ("seq%d.txt" % r)))
+    (tmp_path / "list.txt").write_text("\n".join(paths) + "\n")
+    for joining in ("greedy", "bipartite-matching"):
+        founders = tmp_path / ("founders_%s.txt" % joining)
+        r = run(cli, "-i", str(tmp_path / "list.txt"), "-s", str(L), "-j", joining, "-o", str(founders))
+        assert r.returncode == 0, r.stderr
+        r = subprocess.run([matcher, "-s", str(tmp_path / "list.txt"), "-f", str(founders), "--founders-format", "text", "--single-threaded"],
+                           capture_output=True, timeout=300)
+        assert r.returncode == 0 and b"not found in the founders" not in r.stderr
+        rows = [x.split("\t") for x in r.stdout.decode().split("\n")[1:-1]]
+        for s in range(m):
+            mine = [(int(x[1]), int(x[2])) for x in rows if int(x[0]) == s]
+            assert mine[0][0] == 0 and mine[-1][1] == n and all(a[1] == b[0] for a, b in zip(mine, mine[1:]))
