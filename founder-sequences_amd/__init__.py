@@ -69,7 +69,7 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
-    "fseq_set_device_columns_packed", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
+    "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
 
 JOIN_GREEDY, JOIN_BIPARTITE, JOIN_RANDOM = 0, 1, 2
@@ -110,6 +110,7 @@ def load_library():
     L.fseq_greedy_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp]
     L.fseq_write_founders.argtypes = [vp, C.POINTER(vp), vp, C.c_char_p]
     L.fseq_run_segmentation_batch.argtypes = [vp, sz, vp, vp]
+    L.fseq_debug_dp_schedule.argtypes = [u64, u64, u64, vp, vp, vp, vp]
     L.fseq_join_bipartite.argtypes = [vp, vp]
     L.fseq_join_random.argtypes = [vp, C.c_uint32, vp]
     L.fseq_bipartite_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp, vp]
@@ -144,6 +145,16 @@ def greedy_match_host(m, max_segment_size, lb, rb, a, d):
     if rc != FSEQ_OK:
         raise FseqError(rc, L.fseq_strerror(rc).decode())
     return perm
+
+
+def dp_schedule(segment_length, n, col_hi):
+    """(rounds, cells per round, leading rounds that only need columns < col_hi, pipelined) of the DP schedule."""
+    L = load_library()
+    a, b, c_, d = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_int()
+    rc = L.fseq_debug_dp_schedule(segment_length, n, col_hi, C.byref(a), C.byref(b), C.byref(c_), C.byref(d))
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return a.value, b.value, c_.value, bool(d.value)
 
 
 def run_batch(contexts):

@@ -647,6 +647,12 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 #else
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
 #endif
+		if (getenv("FSEQ_POISON_LISTS"))
+		{
+			// tests of the DP-beside-phase-C forms: a list read before it is written must not look right by accident
+			HIP_TRY(c, hipMemsetAsync(c->d_ent, 0xFF, ((size_t) n * c->stride + 256) * sizeof(uint2), st));
+			HIP_TRY(c, hipMemsetAsync(c->d_hdr, 0xFF, (size_t) n * sizeof(uint4), st));
+		}
 		// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
 		// rounds whose lists are complete, on a second stream: the DP of a column prefix runs while later
 		// columns are still being produced.  Only where one workgroup of the column kernel fills a CU (16-bit
@@ -1483,6 +1489,18 @@ int fseq_write_founders(fseq_ctx *c, uint8_t const *const *rows, uint32_t const 
 	}
 	fflush(f);
 	if (f != stdout) fclose(f);
+	return FSEQ_OK;
+}
+
+int fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi, uint32_t *n_rounds, uint32_t *cells_per_round,
+                           uint32_t *rounds_within, int *pipelined)
+{
+	if (0 == segment_length || n < 2 * segment_length || n >= 0xFFFFFFF0ull) return FSEQ_E_ARG;
+	DpSchedule const S = dp_schedule((uint32_t) segment_length, (uint32_t) n);
+	if (n_rounds) *n_rounds = S.nrounds;
+	if (cells_per_round) *cells_per_round = S.RL;
+	if (rounds_within) *rounds_within = dp_rounds_within(S, col_hi);
+	if (pipelined) *pipelined = S.pipe ? 1 : 0;
 	return FSEQ_OK;
 }
 

@@ -477,15 +477,17 @@ __host__ __device__ inline DpSchedule dp_schedule(uint32_t L, uint32_t n)
 __host__ __device__ inline uint32_t dp_rounds_within(DpSchedule const &S, uint64_t col_hi)
 {
 	if (col_hi >= S.n) return S.nrounds;
-	uint32_t lo = 0, hi = S.nrounds;                          // first round that needs a column >= col_hi
+	// the regular rounds need ascending columns (the drain round needs none, the final cell needs column n - 1):
+	// first regular round that needs a column >= col_hi
+	uint32_t lo = 0, hi = S.nreg;
 	while (lo < hi)
 	{
 		uint32_t const mid = (lo + hi) / 2u;
 		DpRound const R = dp_round(S, mid);
-		bool const needs = R.len > 0 && (uint64_t) R.e0 + R.len - 2u >= col_hi;
+		bool const needs = (uint64_t) R.e0 + R.len - 2u >= col_hi;
 		if (needs) hi = mid; else lo = mid + 1u;
 	}
-	return lo;
+	return lo < S.nreg ? lo : S.nrounds - 1u;                  // all regular rounds (and the drain): everything but the final cell
 }
 
 __device__ __forceinline__ void dp_barrier()

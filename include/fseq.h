@@ -184,6 +184,11 @@ int  fseq_write_segments(fseq_ctx *ctx, uint8_t const *const *rows, int joining,
  * raw input sequences.  path NULL or "-" = stdout. */
 int  fseq_write_founders(fseq_ctx *ctx, uint8_t const *const *rows, uint32_t const *permutations, char const *path);
 
+/* The DP's round schedule (debug / tests of the host logic; no device needed): number of rounds for (L, n),
+ * cells per round, and how many leading rounds only need the lists of columns < col_hi (what the host hands
+ * to a resumed DP launch while later columns are still being produced). */
+int  fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi, uint32_t *n_rounds, uint32_t *cells_per_round,
+                            uint32_t *rounds_within, int *pipelined);
 /* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
 int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
 /* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */

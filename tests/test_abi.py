@@ -61,3 +61,31 @@ def test_bad_arguments_fail_without_touching_a_device(pkg):
     p = pkg.Params(0, 10, 2, 0, 0, 0, 0)
     assert lib.fseq_create(C.byref(p), C.byref(h)) == pkg.FSEQ_E_ARG
     assert lib.fseq_last_error(None).decode() == "null context"
+
+
+def test_dp_schedule_and_prefix_rounds(pkg):
+    """Host logic behind the resumed DP launches (fseq_dp.hpp dp_schedule / dp_rounds_within): cells L .. n-L in
+    rounds of RL, a drain round when pipelined, the final cell; a round belongs to the column prefix [0, col_hi)
+    iff the lists of all its cells (column end - 1) are inside it."""
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for _ in range(300):
+        L = int(rng.integers(1, 300))
+        n = int(rng.integers(2 * L, 2 * L + 5000))
+        nr, RL, _, pipe = pkg.dp_schedule(L, n, n)
+        assert pipe == (L >= 96)
+        assert RL == ((min(L // 2, 48) // 12) * 12 if pipe else min(L, 56))
+        nreg = (n - 2 * L) // RL + 1
+        assert nr == nreg + (2 if pipe else 1)
+        # rounds: r < nreg -> cells end = L + r*RL + i, i < min(RL, n - L - e0 + 1); drain: none; final: end = n
+        def needs(r):
+            if r == nr - 1:
+                return n - 1
+            if r >= nreg:
+                return -1
+            e0 = L + r * RL
+            return e0 + min(RL, n - L - e0 + 1) - 2
+        for col_hi in [0, 1, L, L + 1, n // 3, n // 2, n - L, n - 1, n, n + 5] + [int(x) for x in rng.integers(0, n + 1, size=5)]:
+            got = pkg.dp_schedule(L, n, col_hi)[2]
+            want = nr if col_hi >= n else next((r for r in range(nr) if needs(r) >= col_hi), nr)
+            assert got == want, (L, n, col_hi, got, want)

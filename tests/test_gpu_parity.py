@@ -493,6 +493,7 @@ def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, ch
     resumed DP kernels (parts = -1: forced, as many launches as possible), or phase C launched in parts --
     and the DP alone in several resumed launches: the LDS rings restored from HBM must give bit-identical
     results, also on the pipelined schedule (L >= 96) and on the streamed kernels."""
+    monkeypatch.setenv("FSEQ_POISON_LISTS", "1")            # a list read before phase C wrote it must not look right by accident
     if parts < 0:
         monkeypatch.setenv("FSEQ_HOST_FLAGS", "1")
     elif parts:
@@ -519,6 +520,7 @@ def test_host_flag_overlap_under_load(pkg, monkeypatch):
     a0, d0 = ref.boundary_state(len(want) // 2)
     ref.close()
     monkeypatch.delenv("FSEQ_NO_HOST_FLAGS")
+    monkeypatch.setenv("FSEQ_POISON_LISTS", "1")
     stop = []
 
     def noise():
