@@ -720,7 +720,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 	{
 		// resume: entries < T0 are computed, indexed and in HBM
 		uint32_t const tid = threadIdx.x;
-		uint32_t const T0 = dp_round(S, r_begin).t0;
+		// (the final cell sits L - 1 entries behind the last regular one: nothing is computed in between)
+		DpRound const R0 = dp_round(S, r_begin);
+		uint32_t const T0 = R0.final_round ? n - 2u * L + 1u : R0.t0;
 		for (uint32_t t = (T0 > DPW ? T0 - DPW : 0u) + tid; t < T0; t += 1024u)
 		{
 			D.Mr[t & (DPW - 1u)] = A.M[t];

@@ -486,7 +486,7 @@ def test_native_batch_runner(pkg):
             assert np.array_equal(red[f], ref["reduced"][f])
 
 
-@pytest.mark.parametrize("parts,chunks", [(-1, 0), (3, 0), (16, 0), (0, 5)])
+@pytest.mark.parametrize("parts,chunks", [(-1, 0), (3, 0), (16, 0), (0, 5), (0, 1000000)])
 def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, chunks):
     """The DP of the finished column prefix running beside phase C on a second stream -- what large 16-bit /
     streamed inputs do by themselves: ONE phase C launch whose workgroups flag the host, which launches
@@ -500,8 +500,10 @@ def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, ch
         monkeypatch.setenv("FSEQ_C_PARTS", str(parts))
     if chunks:
         monkeypatch.setenv("FSEQ_DP_CHUNKS", str(chunks))
+    # chunks = 1000000: every round its own launch, the drain round and the final cell included
     for (m, n, L, K, Brec, mu, seed, kind, B) in [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 50), (900, 5000, 100, 10, 300, 1e-3, 52, 1, 64),
-                                                  (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0)]:
+                                                  (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0),
+                                                  (200, 4000, 250, 6, 400, 2e-3, 55, 0, 100), (120, 3000, 140, 5, 300, 3e-3, 56, 0, 64)]:
         msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
         compare_long(pkg, msa, L, block_len=B)
 
