@@ -184,6 +184,8 @@ def main():
             "max_segment_size": int(res.max_segment_size),
             "phases_ms": {k: round(v / steps, 4) for k, v in phase.items()},
             "pass2_cells": int(t["pass2_cells"]),
+            # pass 1 alone (pBWT phases A-C + DP; the DP may run beside phase C on large inputs)
+            "pass1_only_cells_per_s": m * n / (max(1e-9, (phase["ms_phase_a"] + phase["ms_phase_b"] + phase["ms_phase_c"] + phase["ms_dp"]) / steps) * 1e-3),
         },
         "roofline": {
             "bound": "hbm",
