@@ -388,22 +388,6 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if ((rc = dev_alloc(c, &c->dp.Tbv, (size_t) 32 * c->dp.tstride))) return rc;
 		}
 	}
-	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
-	{
-		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
-		// empty device: up to a fifth of the free memory, at most 32 GiB)
-		uint64_t budget = 4ull << 30;
-		{
-			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 5, 32ull << 30));
-		}
-		uint64_t st_ = 16;
-		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
-		c->snap_stride = (uint32_t) st_;
-		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
-	}
 	if (c->use_stream && !c->d_ws)
 	{
 		size_t const per_block = std::max<size_t>(columns_stream_ws_words(p.m, c->B), (size_t) 4 * m);
@@ -414,7 +398,35 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	{
 		c->X = X;
 		c->stride = (X + 3) & ~1u;                // lump + up to X+1 entries, even
-		if ((rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256))) return rc;   // padded: the DP loads strips unconditionally
+		rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256);   // padded: the DP loads strips unconditionally
+		if (rc == FSEQ_E_OOM && c->d_ss_a)
+		{
+			// the stride states were sized before the lists grew: give their memory back and size them again below
+			dev_free(&c->d_ss_a); dev_free(&c->d_ss_d);
+			rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256);
+		}
+		if (rc) return rc;
+	}
+	if (X && !c->d_ss_a && p.n >= 2 * p.segment_length)
+	{
+		// stride states for pass 2: (n / stride + 1) x m words each for a and d.  Sized after the lists: what is
+		// free now, minus the boundary snapshots pass 2 will need at most (n / L of them) and a margin, within
+		// [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.
+		uint64_t budget = 4ull << 30;
+		{
+			size_t free_b = 0, total_b = 0;
+			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			{
+				uint64_t const reserve = (p.n / p.segment_length + 1) * (uint64_t) m * 8ull + (4ull << 30);
+				uint64_t const avail = free_b > reserve ? free_b - reserve : 0;
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 64ull << 30));
+			}
+		}
+		uint64_t st_ = 16;
+		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
+		c->snap_stride = (uint32_t) st_;
+		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
 	}
 	return FSEQ_OK;
 }
@@ -997,22 +1009,6 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
 	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
 	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
-	if (!c->d_ss_a && p.n >= 2 * p.segment_length)
-	{
-		// stride states: (n / stride + 1) x m words each for a and d, kept under ~4 GiB (more on a mostly
-		// empty device: up to a fifth of the free memory, at most 32 GiB)
-		uint64_t budget = 4ull << 30;
-		{
-			size_t free_b = 0, total_b = 0;
-			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-				budget = std::max<uint64_t>(budget, std::min<uint64_t>(free_b / 5, 32ull << 30));
-		}
-		uint64_t st_ = 16;
-		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
-		c->snap_stride = (uint32_t) st_;
-		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
-	}
 	if (c->use_stream && !c->d_ws)
 	{
 		c->ws_words = (size_t) 4 * m;
