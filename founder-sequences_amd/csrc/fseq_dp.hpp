@@ -464,7 +464,10 @@ __host__ __device__ inline DpSchedule dp_schedule(uint32_t L, uint32_t n)
 {
 	DpSchedule S;
 	S.L = L; S.n = n;
-	S.pipe = L >= 96u;                                        // measured: pays only with 4 cells per compute wave
+#ifndef FSEQ_DP_PIPE_MIN_L
+#define FSEQ_DP_PIPE_MIN_L 96u
+#endif
+	S.pipe = L >= FSEQ_DP_PIPE_MIN_L;                         // measured: pays only with 4 cells per compute wave
 	uint32_t const half = L / 2u < 48u ? L / 2u : 48u;
 	S.RL = S.pipe ? (half / 12u) * 12u : (L < DP_RL ? L : DP_RL);   // pipelined: whole cells per compute wave
 	S.nreg = ((n - L) - L) / S.RL + 1u;
