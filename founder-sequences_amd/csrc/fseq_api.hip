@@ -814,8 +814,14 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 #ifdef FSEQ_DP_STAMPS
 		{
-			unsigned long long stamps[48];
+			unsigned long long stamps[96];
 			HIP_TRY(c, hipMemcpy(stamps, c->d_flags + 8, sizeof(stamps), hipMemcpyDeviceToHost));
+			for (int w = 0; w < 16; ++w)
+			{
+				unsigned long long const *q = stamps + 48 + 3 * w;
+				double const nr = (double) (stamps[3 * w + 2] ? stamps[3 * w + 2] : 1);
+				fprintf(stderr, "[dp stamps] wave %2d cycles/round: barrier 1 = %.0f, update = %.0f, barrier 2 = %.0f\n", w, q[0] / nr, q[1] / nr, q[2] / nr);
+			}
 			for (int w = 0; w < 16; ++w)
 			{
 				unsigned long long const *q = stamps + 3 * w;

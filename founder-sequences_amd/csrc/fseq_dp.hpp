@@ -920,6 +920,8 @@ __global__ __launch_bounds__(1024) void k_dp(
 	{
 		unsigned long long *o = reinterpret_cast<unsigned long long *>(flags + 8) + wave * 3u;
 		o[0] = acc[0]; o[1] = acc[1] + acc[2] + acc[3]; o[2] = acc[4];
+		unsigned long long *q = reinterpret_cast<unsigned long long *>(flags + 8) + 48 + wave * 3u;   // classic schedule: barrier 1, update, barrier 2
+		q[0] = acc[1]; q[1] = acc[2]; q[2] = acc[3];
 	}
 #endif
 
