@@ -96,10 +96,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the segmentation path has no CPU fallback")
+    # rehearsal on a box with fewer GPUs than ranks (FSEQ_BENCH_REHEARSAL=1): ranks share the cards and the
+    # timing collectives run over gloo on CPU tensors; everything else is the path the driver launches
+    rehearsal = bool(os.environ.get("FSEQ_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     pkg = importlib.import_module("founder-sequences_amd")
     fdist = importlib.import_module("founder-sequences_amd.dist")
@@ -139,7 +147,7 @@ def main():
     counted["on"] = True
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, max over ranks
     dt = fdist.timed_steps(step, args.steps, 0, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
-                           tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cuda"))
+                           tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cpu" if rehearsal else "cuda"))
 
     t = ctx.timings()
     res = ctx.result
