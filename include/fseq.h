@@ -131,8 +131,9 @@ int  fseq_get_matrix(fseq_ctx *ctx, uint64_t c0, uint64_t c1, uint8_t *out, size
 int  fseq_run_segmentation(fseq_ctx *ctx, fseq_result *res);
 /* Several independent alignments (chromosomes, windows) at once: one host thread and one stream per
  * context, all in flight together -- the DP of one alignment keeps a single CU busy, so the chip is
- * shared (measured: 4 alignments of BASELINE C2 shape in flight give 2.6x the throughput of one after
- * the other).  results[i] / return_codes[i] are what fseq_run_segmentation(ctxs[i], ...) gives; the
+ * shared (measured: 8 alignments of BASELINE C2 shape in flight give 3.5x the throughput of one after
+ * the other; beyond 4 in flight set GPU_MAX_HW_QUEUES -- the HIP runtime's default of 4 hardware queues
+ * makes contexts that share a queue take turns).  results[i] / return_codes[i] are what fseq_run_segmentation(ctxs[i], ...) gives; the
  * return value is FSEQ_OK when every call was made (look at return_codes for their outcomes). */
 int  fseq_run_segmentation_batch(fseq_ctx *const *ctxs, size_t count, fseq_result *results, int *return_codes);
 
