@@ -8,6 +8,7 @@
 #include "../../include/fseq.h"
 #include "fseq_kernels.hpp"
 #include "fseq_dp.hpp"
+#include "fseq_dpspec.hpp"
 #include "fseq_stream.hpp"
 #include "fseq_join.hpp"
 
@@ -180,6 +181,9 @@ struct fseq_ctx {
 	uint32_t X = 0, stride = 0;
 	uint32_t X_hint = 0;                     // list capacity that worked on the last run of this input
 	DpArrays dp{};
+	uint32_t *d_Mprev = nullptr;             // chunk-speculative DP: the iterate the last sweep started from
+	uint32_t *d_spec = nullptr;              // its per-chunk words (active, changed, tailmin, floor, lift, ovf) + SpecCtl
+	uint32_t spec_cap = 0;
 	uint32_t *d_flags = nullptr;
 	uint32_t *d_recent = nullptr;            // k_boundary_recent counts, one per block boundary
 	uint64_t dp_size = 0;
@@ -342,8 +346,9 @@ int prepare_geometry(fseq_ctx *c)
 			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
 	}
-	HIP_TRY(c, allow_lds(k_dp<false>, dp_lds_bytes()));
-	HIP_TRY(c, allow_lds(k_dp<true>, dp_lds_bytes()));
+	HIP_TRY(c, allow_lds(k_dp<DP_WHOLE>, dp_lds_bytes()));
+	HIP_TRY(c, allow_lds(k_dp<DP_PARTIAL>, dp_lds_bytes()));
+	HIP_TRY(c, allow_lds(k_dp<DP_SPEC>, dp_lds_bytes()));
 	c->kernels_ready = true;
 	return FSEQ_OK;
 }
@@ -386,6 +391,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if ((rc = dev_alloc(c, &c->dp.K, c->dp_size + 64))) return rc;
 			if ((rc = dev_alloc(c, &c->dp.Tb, (size_t) 32 * c->dp.tstride))) return rc;
 			if ((rc = dev_alloc(c, &c->dp.Tbv, (size_t) 32 * c->dp.tstride))) return rc;
+			if ((rc = dev_alloc(c, &c->d_Mprev, c->dp_size))) return rc;
 		}
 	}
 	if (c->use_stream && !c->d_ws)
@@ -439,6 +445,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
 	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
+	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a); dev_free(&c->d_ss_d); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
@@ -573,6 +580,136 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 		            out_rank, out_keyd, out_nkeys);
 }
 
+// The chunk plan of the speculative DP (fseq_dpspec.hpp): 0 chunks = use the serial kernel.
+struct SpecPlan { uint32_t rounds_per_chunk = 0, nchunks = 0; };
+
+SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
+{
+	SpecPlan P;
+#if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
+	return P;                                // the diagnostic builds instrument the serial kernel
+#endif
+	if (getenv("FSEQ_DP_SERIAL")) return P;
+	int ncu = 0;
+	(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+	if (ncu < 1) ncu = 1;
+	// one chunk per CU, but chunks of at least max(1024, 8L) entries (several tail windows; the sweeps of shorter
+	// chunks are cheaper but more of them are needed)
+	uint32_t const min_entries = std::max<uint32_t>(1024u, 8u * S.L);
+	uint32_t rpc = std::max<uint32_t>((S.nreg + (uint32_t) ncu - 1u) / (uint32_t) ncu, (min_entries + S.RL - 1u) / S.RL);
+	if (char const *e = getenv("FSEQ_DP_SPEC_ROUNDS")) rpc = (uint32_t) std::max(1, atoi(e));   // tests: any chunk length
+	uint32_t const nch = (S.nreg + rpc - 1u) / rpc;
+	if (nch < 3u && !getenv("FSEQ_DP_SPEC_ROUNDS")) return P;
+	if (nch < 2u || nch > 65535u) return P;
+	P.rounds_per_chunk = rpc; P.nchunks = nch;
+	return P;
+}
+
+// Phase D as chunk-speculative sweeps on the whole chip (fseq_dpspec.hpp).  Leaves M / LB / SZ exactly as
+// k_dp<DP_WHOLE> would; *overflow = some cell's list was too short.
+int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t st, uint32_t *overflow, uint32_t *sweeps_out)
+{
+	fseq_params const &p = c->p;
+	uint32_t const m = p.m, n = (uint32_t) p.n, L = (uint32_t) p.segment_length;
+	uint32_t const nch = P.nchunks;
+	int rc;
+	if (c->spec_cap < nch)
+	{
+		if ((rc = dev_alloc(c, &c->d_spec, (size_t) 6 * nch + 16))) return rc;
+		c->spec_cap = nch;
+	}
+	uint32_t *d_active = c->d_spec, *d_changed = d_active + nch, *d_tailmin = d_changed + nch, *d_floor = d_tailmin + nch,
+	         *d_lift = d_floor + nch, *d_ovf = d_lift + nch;
+	SpecCtl *d_ctl = reinterpret_cast<SpecCtl *>(d_ovf + nch);
+	SpecGeom G;
+	G.entries_per_chunk = P.rounds_per_chunk * S.RL;
+	G.nchunks = nch;
+	G.NR = n - 2u * L + 1u;
+	G.t_final = n - L;
+	G.win = std::max<uint32_t>(256u, 4u * L);
+	if (char const *e = getenv("FSEQ_DP_SPEC_WIN")) G.win = (uint32_t) std::max(1, atoi(e));
+	uint32_t const nblk = (G.NR + 63u) / 64u, ncomplete = G.NR / 64u;
+	uint32_t const grid_c = (uint32_t) ((c->dp_size + 255) / 256);          // 4 blocks of 64 entries per workgroup, incl. the final cell's
+	(void) nblk;
+	HIP_TRY(c, hipMemsetAsync(c->dp.M, 0, c->dp_size * 4, st));
+	HIP_TRY(c, hipMemsetAsync(c->d_Mprev, 0, c->dp_size * 4, st));
+	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 6 * nch + 16) * 4, st));
+	HIP_TRY(c, hipMemsetAsync(d_active, 0x01, (size_t) nch * 4, st));        // != 0: every chunk runs in sweep 1
+
+	DpSpecArgs SP;
+	SP.rounds_per_chunk = P.rounds_per_chunk; SP.nchunks = nch; SP.active = d_active; SP.ovf = d_ovf;
+	SP.ctl = reinterpret_cast<uint32_t const *>(d_ctl);
+	auto sweep = [&](bool fresh) {
+		SP.fresh = fresh ? 1u : 0u;
+		hipLaunchKernelGGL(k_dp<DP_SPEC>, dim3(nch), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
+		                   c->d_flags, 0u, 0u, SP);
+	};
+	auto compare = [&](bool first) {
+		hipLaunchKernelGGL(k_spec_scan, dim3(nch), dim3(256), 0, st, c->dp.M, c->d_Mprev, G, d_active, d_changed, d_tailmin, d_ctl);
+		hipLaunchKernelGGL(k_spec_decide, dim3(1), dim3(64), 0, st, nch, first ? 1u : 0u, d_changed, d_tailmin, d_floor, d_lift, d_active, d_ovf, d_ctl);
+	};
+	auto rebuild = [&]() {
+		hipLaunchKernelGGL(k_spec_rebuild, dim3(grid_c), dim3(256), 0, st, c->dp, c->d_Mprev, G, d_lift, d_ctl);
+		hipLaunchKernelGGL(k_spec_table, dim3((ncomplete + 255u) / 256u), dim3(256), 0, st, c->dp, ncomplete, d_ctl);
+	};
+	uint32_t max_sweeps = 12;
+	if (char const *e = getenv("FSEQ_DP_SPEC_MAX_SWEEPS")) max_sweeps = (uint32_t) std::max(1, atoi(e));
+	SpecCtl h{};
+	sweep(true);
+	uint32_t done_sweeps = 1;
+	// every kernel returns at once when the iteration has converged, so sweeps are queued ahead of the
+	// host's look at the control word: three further sweeps first (the measured common case needs three in all),
+	// then two at a time
+	uint32_t batch = 3;
+	while (true)
+	{
+		for (uint32_t i = 0; i < batch && done_sweeps < max_sweeps; ++i)
+		{
+			compare(done_sweeps == 1);
+			rebuild();
+			sweep(false);
+			++done_sweeps;
+		}
+		compare(done_sweeps == 1);
+		HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		HIP_TRY(c, hipGetLastError());
+		if (h.done || done_sweeps >= max_sweeps) break;
+		// the compare just queued has already chosen the next sweep's active set and lifts
+		rebuild();
+		sweep(false);
+		++done_sweeps;
+		batch = 1;
+	}
+	if (!h.done)
+	{
+		// bounded: finish serially behind the last chunk known to be exact (its masks and samples are rebuilt first)
+		rebuild();
+		uint32_t const r0 = (h.first_changed + 1u) * P.rounds_per_chunk;
+		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
+		if (r0 < S.nrounds)
+			hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
+			                   c->d_flags, std::min(r0, S.nreg), S.nrounds, DpSpecArgs{});
+		// overflow: the serial part reports through d_flags, the frozen chunks through their own words
+		std::vector<uint32_t> ovf(nch);
+		uint32_t fl[4] = {0, 0, 0, 0};
+		HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(fl, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		HIP_TRY(c, hipGetLastError());
+		uint32_t o = fl[0] & 1u;
+		for (uint32_t k = 0; k <= h.first_changed && k < nch; ++k) o |= ovf[k] ? 1u : 0u;
+		*overflow = o;
+		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] speculative DP: not converged after %u sweeps, serial from round %u\n", done_sweeps, r0);
+	}
+	else
+		*overflow = h.overflow;
+	if (sweeps_out) *sweeps_out = h.done ? h.sweeps : done_sweeps + 1000u;
+	if (getenv("FSEQ_DEBUG"))
+		fprintf(stderr, "[fseq] speculative DP: %u chunks of %u rounds, %u sweeps compared, done=%u\n", nch, P.rounds_per_chunk, h.sweeps, h.done);
+	return FSEQ_OK;
+}
+
 int run_long_path(fseq_ctx *c, fseq_result *res)
 {
 	fseq_params const &p = c->p;
@@ -671,7 +808,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		// and streamed state) and a launch has several waves of them anyway: a part is then ncu - 1
 		// workgroups per wave, which leaves the DP (a whole CU's LDS) a CU of its own.  FSEQ_C_PARTS forces a count.
 		DpSchedule const S = dp_schedule((uint32_t) L, (uint32_t) n);
+		// default: the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp);
+		// the forms that run the serial DP beside phase C remain for FSEQ_DP_SERIAL and the forced test schedules
+		SpecPlan const spec = spec_plan(c, S);
+		bool const use_spec = spec.nchunks > 0 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_HOST_FLAGS") && !getenv("FSEQ_DP_CHUNKS");
+		uint32_t spec_overflow = 0, spec_sweeps = 0;
 		uint32_t parts = 1, part_blocks = c->nblocks;
+		if (!use_spec)
 		{
 			int ncu = 0;
 			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
@@ -733,8 +876,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				if (r1 > r_done && (r1 - r_done >= min_rounds || prefix == c->nblocks))
 				{
 					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-					hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-					                   c->d_flags, r_done, r1);
+					hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+					                   c->d_flags, r_done, r1, DpSpecArgs{});
 					r_done = r1;
 					continue;
 				}
@@ -761,14 +904,18 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			if (char const *e = getenv("FSEQ_DP_CHUNKS")) chunks = (uint32_t) std::max(1, atoi(e));
 			chunks = std::min(chunks, S.nrounds);
 			HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
-			if (chunks <= 1)
-				hipLaunchKernelGGL(k_dp<false>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, 0u, S.nrounds);
-			for (uint32_t k = 0; chunks > 1 && k < chunks; ++k)
+			if (use_spec)
+			{
+				if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps))) return rc;
+			}
+			else if (chunks <= 1)
+				hipLaunchKernelGGL(k_dp<DP_WHOLE>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, 0u, S.nrounds, DpSpecArgs{});
+			for (uint32_t k = 0; !use_spec && chunks > 1 && k < chunks; ++k)
 			{
 				uint32_t const r0 = (uint32_t) ((uint64_t) S.nrounds * k / chunks), r1 = (uint32_t) ((uint64_t) S.nrounds * (k + 1) / chunks);
-				hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, r0, r1);
+				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, r0, r1, DpSpecArgs{});
 			}
 			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
 		}
@@ -788,8 +935,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				{
 					HIP_TRY(c, hipStreamWaitEvent(st2, c->ev_part[k], 0));
 					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-					hipLaunchKernelGGL(k_dp<true>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-					                   c->d_flags, r_done, r1);
+					hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+					                   c->d_flags, r_done, r1, DpSpecArgs{});
 					r_done = r1;
 				}
 			}
@@ -840,7 +987,9 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 #endif
 		double const th0 = now_ms();
-		bool overflow = (h_flags[0] & 1u) != 0;
+		bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
+		c->tm.dp_sweeps = spec_sweeps;
+		c->tm.dp_chunks = use_spec ? spec.nchunks : 0u;
 
 		if (!overflow)
 		{

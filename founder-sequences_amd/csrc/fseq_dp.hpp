@@ -70,6 +70,7 @@ __host__ __device__ inline size_t dp_lds_bytes()
 struct DpView {
 	uint32_t safe_lo;     // first DP entry guaranteed to be in the LDS ring during this round
 	uint32_t cb;          // complete (indexed) blocks at the start of this round
+	uint32_t fresh_lo;    // speculative first sweep of a chunk: entries below this index count as 0 (else 0)
 };
 
 __device__ __forceinline__ uint32_t dp_key(DpArrays const &A, DpLds const &D, DpView const &V, uint32_t i)
@@ -205,22 +206,25 @@ __device__ __forceinline__ bool dp_strip(
 	ok = ok && lo < c;                                       // lp.cc:458
 	uint32_t val = 0xFFFFFFFFu, idx = 0;
 	uint32_t const qb = lo - L, qe = c - L;
-	if (__ballot(ok && qb < V.safe_lo) == 0)
+	bool const open_lhs = ok && qb < V.fresh_lo;             // range reaches in front of a speculative chunk: a key 0 is in it
+	bool const okq = ok && !open_lhs;
+	if (__ballot(okq && qb < V.safe_lo) == 0)
 	{
 		// every candidate of the strip lies inside the LDS ring
-		if (ok)
+		if (okq)
 		{
 			uint32_t mv;
 			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
 			val = max(mv, cum);                                  // lp.cc:468-471
 		}
 	}
-	else if (ok)
+	else if (okq)
 	{
 		uint32_t mv;
 		idx = rmq_query(A, D, V, qb, qe, &mv);
 		val = max(mv, cum);
 	}
+	if (open_lhs) { idx = qb; val = cum; }
 	// minimum value; among equal values the candidate the reference visits first = the largest i
 	// (lowest divergence value) = the highest lane of the strip
 	uint32_t const vmin = wave_min_u32(val);
@@ -329,21 +333,24 @@ __device__ __forceinline__ uint64_t dp_cell_pair(
 	ok = ok && lo < c;                                       // lp.cc:458
 	uint32_t val = 0xFFFFFFFFu, idx = 0;
 	uint32_t const qb = lo - L, qe = c - L;
-	if (__ballot(ok && qb < V.safe_lo) == 0)
+	bool const open_lhs = ok && qb < V.fresh_lo;             // see dp_strip
+	bool const okq = ok && !open_lhs;
+	if (__ballot(okq && qb < V.safe_lo) == 0)
 	{
-		if (ok)
+		if (okq)
 		{
 			uint32_t mv;
 			idx = rmq_query_lds(D, qb, qe, &mv);                 // lp.cc:465
 			val = max(mv, cum);                                  // lp.cc:468-471
 		}
 	}
-	else if (ok)
+	else if (okq)
 	{
 		uint32_t mv;
 		idx = rmq_query(A, D, V, qb, qe, &mv);
 		val = max(mv, cum);
 	}
+	if (open_lhs) { idx = qb; val = cum; }
 	// minimum per half; among equal values the highest lane of the half (dp_strip)
 	uint32_t const vmin = half_min_u32(val);
 	uint64_t const wmask = __ballot(ok && val == vmin);
@@ -533,14 +540,11 @@ __device__ __forceinline__ void dp_mask_slice(DpLds const &D, DpRound const &R, 
 	if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
 }
 
-// All four slices of one block by one wave: four independent dependency chains that interleave
-// (pipelined schedule, where only two waves do the update).
-__device__ __forceinline__ void dp_mask_block(DpLds const &D, DpRound const &R, uint32_t blk)
+// Stack masks of a whole 64-block held one key per lane: lane t gets the mask of entry t (bit p <= t set iff
+// key[p] <= min key(p..t]).  Four independent dependency chains (one per 16-bit slice) that interleave.
+__device__ __forceinline__ unsigned long long stack_mask64(uint32_t mine)
 {
 	uint32_t const lane = lane_id();
-	uint32_t const base = blk * 64u, idx = base + lane;
-	bool const fresh = idx >= R.t0 && idx < R.t1;
-	uint32_t const mine = D.Mr[idx & (DPW - 1u)];
 	uint32_t runmin[4], bits[4];
 #pragma unroll
 	for (int c = 0; c < 4; ++c)
@@ -569,8 +573,16 @@ __device__ __forceinline__ void dp_mask_block(DpLds const &D, DpRound const &R, 
 			runmin[c] = in ? min(runmin[c], x) : runmin[c];
 		}
 	}
-	if (fresh)
-		D.Kr[idx & (DPW - 1u)] = (unsigned long long) (bits[0] | (bits[1] << 16)) | ((unsigned long long) (bits[2] | (bits[3] << 16)) << 32);
+	return (unsigned long long) (bits[0] | (bits[1] << 16)) | ((unsigned long long) (bits[2] | (bits[3] << 16)) << 32);
+}
+
+// All four slices of one block by one wave (pipelined schedule, where only two waves do the update).
+__device__ __forceinline__ void dp_mask_block(DpLds const &D, DpRound const &R, uint32_t blk)
+{
+	uint32_t const idx = blk * 64u + lane_id();
+	bool const fresh = idx >= R.t0 && idx < R.t1;
+	unsigned long long const k = stack_mask64(D.Mr[idx & (DPW - 1u)]);
+	if (fresh) D.Kr[idx & (DPW - 1u)] = k;
 }
 
 // rmq.update, part 2 (rmq.hh:66-80): block blk is complete, push its samples on every level.
@@ -607,16 +619,33 @@ __device__ __forceinline__ void dp_push_samples(DpLds const &D, uint32_t blk, ui
 	}
 }
 
-// PARTIAL = false: the whole schedule in one launch (r_begin_arg / r_end_arg ignored: the common case keeps
-// its registers).
-template <bool PARTIAL>
+// Chunk-speculative sweeps (fseq_dpspec.hpp): the regular rounds are cut into chunks of rounds_per_chunk rounds,
+// workgroup c of the launch runs chunk c from whatever the arrays hold in front of it.
+struct DpSpecArgs {
+	uint32_t rounds_per_chunk, nchunks;
+	uint32_t fresh;                       // first sweep: nothing is known in front of a chunk (keys there count as 0)
+	uint32_t const *active;               // [nchunks] chunks to run in this sweep
+	uint32_t *ovf;                        // [nchunks] "list too short" flag of the sweep that last ran the chunk
+	uint32_t const *ctl;                  // ctl[0] != 0: the iteration has converged, nothing to do
+};
+
+// MODE 0: the whole schedule in one launch (r_begin_arg / r_end_arg ignored: the common case keeps its registers).
+// MODE 1: rounds [r_begin_arg, r_end_arg).  MODE 2: workgroup = chunk of the speculative iteration.
+enum { DP_WHOLE = 0, DP_PARTIAL = 1, DP_SPEC = 2 };
+template <int MODE>
 __global__ __launch_bounds__(1024) void k_dp(
 	DpArrays const A, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t stride,
-	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags, uint32_t r_begin_arg, uint32_t r_end_arg)
+	uint32_t m, uint32_t n, uint32_t L, uint32_t *flags, uint32_t r_begin_arg, uint32_t r_end_arg, DpSpecArgs const SP)
 {
+	constexpr bool PARTIAL = MODE != DP_WHOLE;
 	// Rounds [r_begin, r_end) of the schedule.  A launch that does not start at round 0 restores the LDS
 	// rings from the arrays the launch before it flushed; one that stops early completes the rmq.update
 	// of its last round before it flushes (pipelined schedule: one more iteration without cells).
+	if (MODE == DP_SPEC)
+	{
+		if (SP.ctl[0] != 0u || SP.active[blockIdx.x] == 0u) return;
+		flags = SP.ovf + blockIdx.x;
+	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	lds_char *const lds0 = (lds_char *) smem;
 	uint32_t const lds0_addr = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) lds0);   // LDS byte address of the carve base
@@ -647,7 +676,15 @@ __global__ __launch_bounds__(1024) void k_dp(
 	DpSchedule const S = dp_schedule(L, n);
 	uint32_t const NWC = S.pipe ? 12u : DP_NWC;               // compute waves
 	uint32_t const nrounds = S.nrounds, RL = S.RL;
-	uint32_t const r_begin = PARTIAL ? r_begin_arg : 0u, r_end = PARTIAL ? r_end_arg : nrounds;
+	uint32_t r_begin = PARTIAL ? r_begin_arg : 0u, r_end = PARTIAL ? r_end_arg : nrounds;
+	if (MODE == DP_SPEC)
+	{
+		// chunks tile the regular rounds; the last one also takes the drain round and the final cell
+		r_begin = blockIdx.x * SP.rounds_per_chunk;
+		r_end = (blockIdx.x + 1u == SP.nchunks) ? nrounds : r_begin + SP.rounds_per_chunk;
+	}
+	bool const fresh = MODE == DP_SPEC && SP.fresh != 0u && r_begin > 0u;
+	uint32_t const fresh_lo = fresh ? dp_round(S, r_begin).t0 : 0u;
 	bool const stops_early = PARTIAL && r_end < nrounds;
 	uint32_t const r_stop = (S.pipe && stops_early) ? r_end + 1u : r_end;   // pipelined: + the drain iteration
 	uint32_t const npairs = (RL + 1u) / 2u;                    // list DMA instructions per round (+3: headers, mailbox)
@@ -719,7 +756,8 @@ __global__ __launch_bounds__(1024) void k_dp(
 		}
 	};
 
-	if (PARTIAL && r_begin > 0u)
+	if (MODE == DP_SPEC && threadIdx.x == 0) *flags = 0u;
+	if (PARTIAL && r_begin > 0u && !fresh)
 	{
 		// resume: entries < T0 are computed, indexed and in HBM
 		uint32_t const tid = threadIdx.x;
@@ -781,6 +819,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 		DpView V;
 		V.safe_lo = (filled + inflight + 128u > DPW) ? (filled + inflight + 128u - DPW) : 0u;
 		V.cb = filled >> 6;
+		V.fresh_lo = fresh_lo;
 
 		if (wave < NWC && drain)
 		{

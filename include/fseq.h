@@ -93,6 +93,8 @@ typedef struct fseq_timings {
 	uint32_t retries;               /* list_cap retries                                    */
 	uint32_t block_len;             /* B in use                                            */
 	uint32_t n_blocks;
+	uint32_t dp_chunks;             /* chunks of the speculative DP (0: the serial kernel ran)               */
+	uint32_t dp_sweeps;             /* sweeps it compared until no key changed (>= 1000: serial fallback took over) */
 } fseq_timings;
 
 uint32_t    fseq_abi_version(void);

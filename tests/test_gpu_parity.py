@@ -508,6 +508,44 @@ def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, ch
         compare_long(pkg, msa, L, block_len=B)
 
 
+SPEC_SHAPES = [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 50), (900, 5000, 100, 10, 300, 1e-3, 52, 1, 64),
+               (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0),
+               (200, 4000, 250, 6, 400, 2e-3, 55, 0, 100), (120, 3000, 140, 5, 300, 3e-3, 56, 0, 64),
+               (2500, 20000, 50, 16, 2000, 1e-4, 0x5EED0002, 0, 0)]
+
+
+@pytest.mark.parametrize("rounds,max_sweeps,win", [(0, 0, 0), (1, 0, 0), (3, 0, 0), (7, 0, 0), (40, 0, 0), (5, 2, 0), (2, 1, 0), (4, 0, 1), (4, 3, 5000)])
+def test_speculative_dp_matches_serial_walk(pkg, monkeypatch, rounds, max_sweeps, win):
+    """Phase D as chunk-speculative sweeps (fseq_dpspec.hpp): whatever the chunk length (rounds = 1: every round
+    its own chunk), the tail window (1: the lifts pick up every spike; 5000: whole chunks) and the sweep budget
+    (1, 2, 3: the serial kernel takes over behind the first dirty chunk), the whole DP array, the traceback, the
+    merged segments and the boundary states equal the oracle's serial walk.  rounds = 0: the plan the library picks."""
+    monkeypatch.setenv("FSEQ_POISON_LISTS", "1")
+    if rounds:
+        monkeypatch.setenv("FSEQ_DP_SPEC_ROUNDS", str(rounds))
+    if max_sweeps:
+        monkeypatch.setenv("FSEQ_DP_SPEC_MAX_SWEEPS", str(max_sweeps))
+    if win:
+        monkeypatch.setenv("FSEQ_DP_SPEC_WIN", str(win))
+    for (m, n, L, K, Brec, mu, seed, kind, B) in SPEC_SHAPES:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctx, _ = compare_long(pkg, msa, L, block_len=B)
+        t = ctx.timings()
+        if rounds:
+            assert t["dp_chunks"] >= 2, t
+        if max_sweeps and rounds:
+            assert t["dp_sweeps"] <= max_sweeps + 1 or t["dp_sweeps"] >= 1000, t
+
+
+def test_speculative_dp_with_short_lists_retries(pkg, monkeypatch):
+    """A list too short to prove a cell is reported per chunk by the sweep that last ran the chunk; the run
+    retries with longer lists and stays exact."""
+    monkeypatch.setenv("FSEQ_DP_SPEC_ROUNDS", "3")
+    msa = fso.synth_msa(fso.synth_spec(61, 8, 200, 2e-3, 0), 300, 6000)
+    ctx, _ = compare_long(pkg, msa, 25, block_len=50, list_cap=2)
+    assert ctx.timings()["retries"] >= 1 and ctx.timings()["dp_chunks"] >= 2
+
+
 def test_host_flag_overlap_under_load(pkg, monkeypatch):
     """The path large 16-bit inputs take by themselves (one phase C launch flagging the host, resumed DP launches
     beside it), repeated while another context keeps the chip unevenly busy: every run must equal the run
