@@ -5,7 +5,8 @@ One "step" = one complete pass of the hot path (everything segmentation_lp_conte
 pBWT pass 1 + DP, traceback, segment merge, pass-2 boundary states) over one synthetic
 founder-mosaic alignment that is already resident in HBM (column-major, 2 bits per cell for
 sigma <= 4, 4 bits for sigma <= 16, else 1 B).
-Workload at N=1: BASELINE.json configs[1] (C2: m=2,500 x n=100,000, sigma=4, L=50).
+Workload at N=1: BASELINE.json configs[2] (C3: m=2,504 x n=1,000,000, sigma=4, L=100), the largest configuration
+BASELINE.json labels 1xMI355X (C2 is too small for a roofline fraction to mean anything).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -49,6 +50,36 @@ WORKLOADS = {
 }
 
 
+def csrc_sha():
+    """Hash of the kernel sources: a PMC summary is only quoted for the code it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "founder-sequences_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hpp", ".hip")) and "join" not in f:
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload):
+    """HBM bytes per step and kernel from the newest profiles/r*_pmc_traffic_<workload>.json taken on the current
+    kernel sources (rocprofv3 cannot run inside this process); (None, reason) otherwise."""
+    import glob
+    hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
+    sha = csrc_sha()
+    for path in reversed(hits):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d.get("csrc_sha") != sha:
+                continue
+            return d["phases_hbm_bytes_per_step"], os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)"
+        except Exception:
+            continue
+    return None, "no PMC summary under profiles/ for workload %s on kernel sources %s" % (workload, sha)
+
+
 def cpu_baseline(ctx, w, threads):
     """The oracle (CPU restatement, -O2) timed on this host: pass 1 on one core as the reference
     runs it, pass 2 on `threads` threads.  Sample = the whole workload when it is
@@ -81,7 +112,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
     ap.add_argument("--block-len", type=int, default=0)
     ap.add_argument("--list-cap", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -116,6 +147,8 @@ def main():
 
     pkg = importlib.import_module("founder-sequences_amd")
     fdist = importlib.import_module("founder-sequences_amd.dist")
+    if args.workload is None:
+        args.workload = "C3"
     w = dict(WORKLOADS[args.workload])
     m, n, L = w["m"], w["n"], w["L"]
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
@@ -156,24 +189,38 @@ def main():
 
     t = ctx.timings()
     res = ctx.result
-    # HBM bytes per k_columns launch from the PMC passes committed under profiles/ (rocprofv3 cannot
-    # run inside this process); only quoted when it was taken on this workload
-    traffic, traffic_src = None, None
-    try:
-        prof = os.path.join(ROOT, "profiles", "r01_g_pmc_traffic.json")
-        if args.workload == "C2" and os.path.exists(prof):
-            with open(prof) as f:
-                pk = json.load(f)["kernels"]
-            for name, d in pk.items():
-                if "k_columns" in name and "hbm_bytes_per_launch_corrected" in d:
-                    traffic = d["hbm_bytes_per_launch_corrected"]
-                    traffic_src = "profiles/r01_g_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 on gfx950)"
-    except Exception:
-        traffic = None
     steps = max(1, args.steps)
-    ms_c = phase["ms_phase_c"] / steps          # one k_columns launch per step (plus retries, if any)
+    ph = {k: v / steps for k, v in phase.items()}
+    step_ms = dt / steps * 1e3
+    R = int(t["pass2_cells"])
+    # ONE figure for the path -- 17 B per cell per pass-1 column update, pass 2's R cells at the
+    # same price, over the whole step (pass 1 + DP + traceback + merge + pass 2)
+    path_bytes = BYTES_PER_CELL * (m * n + R)
+    path_gbps = path_bytes / (step_ms * 1e-3) / 1e9
+    # per kernel: HIP-event time on the library's own stream (fseq_timings), algorithmic bytes of what the launch
+    # processes, and -- when profiles/ holds PMC passes of THIS workload taken on THESE kernel sources -- the HBM
+    # bytes rocprofv3 counted (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
+    pmc, pmc_src = load_pmc(args.workload)
     launches_c = 1 + t["retries"]
-    achieved = BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9
+    kernels = {
+        "phase_a k_colblock<RANK> (block-key ranks from the identity)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
+        "phase_b k_chain (boundary states)": {"ms": ph["ms_phase_b"], "algorithmic_bytes": 0},
+        "phase_c k_columns (per-column update + lists)": {"ms": ph["ms_phase_c"], "algorithmic_bytes": BYTES_PER_CELL * m * n * launches_c},
+        "phase_d k_dp<SPEC> sweeps + rebuild kernels": {"ms": ph["ms_dp"], "algorithmic_bytes": 0},
+        "pass_2 k_colblock<SNAP>": {"ms": ph["ms_pass2"], "algorithmic_bytes": BYTES_PER_CELL * R},
+        "host (traceback walk, merge, copies)": {"ms": ph["ms_host"], "algorithmic_bytes": 0},
+    }
+    traffic = None
+    if pmc:
+        traffic = 0.0
+        for label, d in kernels.items():
+            if label.split()[0] in pmc:
+                d["pmc_hbm_bytes_per_step"] = pmc[label.split()[0]]
+                traffic += pmc[label.split()[0]]
+    for d in kernels.values():
+        d["ms"] = round(d["ms"], 4)
+        d["algorithmic_GBps"] = round(d["algorithmic_bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 and d["algorithmic_bytes"] else None
+    ms_c = ph["ms_phase_c"]
     out = {
         "metric": "alignment cells/s (m*n/T) through pBWT+DP",
         "value": world * max(1, args.concurrent) * m * n * steps / dt,
@@ -181,7 +228,7 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / steps * 1e3,
+        "ms_per_step": step_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -193,24 +240,34 @@ def main():
                         % (args.workload, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2),
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
+            "dp_chunks": t["dp_chunks"], "dp_sweeps": t["dp_sweeps"],
             "segments": int(res.segment_count), "dp_segments": int(res.dp_segment_count),
             "max_segment_size": int(res.max_segment_size),
-            "phases_ms": {k: round(v / steps, 4) for k, v in phase.items()},
-            "pass2_cells": int(t["pass2_cells"]),
-            # pass 1 alone (pBWT phases A-C + DP; the DP may run beside phase C on large inputs)
-            "pass1_only_cells_per_s": m * n / (max(1e-9, (phase["ms_phase_a"] + phase["ms_phase_b"] + phase["ms_phase_c"] + phase["ms_dp"]) / steps) * 1e-3),
+            "phases_ms": {k: round(v, 4) for k, v in ph.items()},
+            "pass2_cells": R,
+            # pass 1 alone (pBWT phases A-C + DP)
+            "pass1_only_cells_per_s": m * n / (max(1e-9, ph["ms_phase_a"] + ph["ms_phase_b"] + ph["ms_phase_c"] + ph["ms_dp"]) * 1e-3),
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_columns (per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
-            "achieved": achieved,
+            "scope": "whole path, SURVEY.md 8(d): 17 B x (m*n + R) / step time; the block state lives in LDS, so the bytes "
+                     "HBM really moves (traffic) are far below this algorithmic figure",
+            "achieved": path_gbps,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS,
+            "frac": path_gbps / HBM_PEAK_GBPS,
+            "frac_vs_measured_copy_6290": path_gbps / 6290.0,
             "traffic": traffic,
-            "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
-            "avg_launch_ms": ms_c / launches_c,
+            "traffic_source": pmc_src,
+            "algorithmic_bytes_per_step": path_bytes,
+            "dominant_kernel": {
+                "name": "k_columns (phase C: per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
+                "avg_launch_ms": ms_c / launches_c,
+                "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
+                "achieved": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9,
+                "frac": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            },
+            "kernels": kernels,
         },
     }
     # secondary figure (not `value`): the DP of one alignment occupies one CU for ~2/3 of a step, so

@@ -70,10 +70,14 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+    "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
 
 JOIN_GREEDY, JOIN_BIPARTITE, JOIN_RANDOM = 0, 1, 2
+
+# fseq_allreduce_fn (include/fseq.h): all-reduce xbuf[offset .. offset + count) over the ranks, op 0 = sum, 1 = max
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int)
 
 _lib = None
 
@@ -121,6 +125,11 @@ def load_library():
     L.fseq_debug_block_state.argtypes = [vp, u64, vp, vp]
     L.fseq_debug_column_list.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.fseq_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.fseq_shard_xbuf_words.restype = u64
+    L.fseq_shard_xbuf_words.argtypes = [vp, C.c_uint32]
+    L.fseq_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u64, ALLREDUCE_FN, vp]
+    L.fseq_shard_columns.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
+    L.fseq_shard_owner.argtypes = [vp, u64, C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -245,6 +254,34 @@ class SegmentationContext:
         if rc == FSEQ_E_NO_REDUCTION:
             raise NoReduction(rc, msg)
         raise FseqError(rc, msg)
+
+    # ---- one alignment over several ranks (fseq_set_shard; the transport lives in founder-sequences_amd/dist.py)
+    def set_shard(self, rank, world, xbuf_ptr, xbuf_words, allreduce):
+        """allreduce(offset_words, count_words, op) -> 0: all-reduces that slice of the exchange buffer in place.
+        Call before the input is set; every rank then holds its own columns only."""
+        def _cb(_user, off, cnt, op):
+            try:
+                return int(allreduce(int(off), int(cnt), int(op)) or 0)
+            except Exception:                      # never let an exception cross the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._shard_cb = ALLREDUCE_FN(_cb)         # keep the thunk alive as long as the context
+        self._check(self.L.fseq_set_shard(self.h, rank, world, xbuf_ptr, xbuf_words, self._shard_cb, None))
+        self.rank, self.world = rank, world
+
+    def shard_xbuf_words(self, world):
+        return int(self.L.fseq_shard_xbuf_words(self.h, world))
+
+    def shard_columns(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._check(self.L.fseq_shard_columns(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def shard_owner(self, rb):
+        r = C.c_uint32()
+        self._check(self.L.fseq_shard_owner(self.h, int(rb), C.byref(r)))
+        return r.value
 
     # ---- input (delegate->sequences(), delegate->alphabet())
     def set_sequences(self, msa):

@@ -29,7 +29,7 @@ struct KernelSet {
 	uint32_t T, E, sigma, cap;
 	size_t lds_colblock, lds_snap;
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
-	             uint32_t *, uint32_t *, uint32_t *);
+	             uint32_t *, uint32_t *, uint32_t *, uint64_t col0);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
 	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
@@ -41,7 +41,7 @@ struct KernelSet {
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys);
+	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0);
 	hipError_t (*prepare)(size_t lds_columns);
 };
 
@@ -55,18 +55,18 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int T, int E, int SIGMA, bool PK>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys)
+	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0);
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
 	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
@@ -84,10 +84,10 @@ struct Launch {
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
+	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0)
 	{
 		hipLaunchKernelGGL((k_chain<T, E, PK>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
-		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
+		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	}
 	static hipError_t prepare(size_t lds_columns)
 	{
@@ -145,10 +145,33 @@ double now_ms()
 
 } // namespace
 
+// One alignment over several ranks (include/fseq.h, fseq_set_shard): which blocks / columns / DP chunks are mine
+struct Shard {
+	bool on = false;
+	uint32_t rank = 0, world = 1;
+	uint32_t *xbuf = nullptr;               // caller-owned exchange buffer (device)
+	uint64_t xwords = 0;
+	fseq_allreduce_fn fn = nullptr;
+	void *user = nullptr;
+	uint32_t bpr = 0;                       // blocks per rank = chain_G * chain_G2 (a rank is one hyper-block of phase B)
+	uint32_t active = 1;                    // ranks that own blocks
+	uint32_t b_lo = 0, b_hi = 0;            // my blocks
+	uint64_t c_lo = 0, c_hi = 0, c_end = 0; // my columns [c_lo, c_hi); held: [c_lo, c_end) (halo for my last DP round)
+};
+
 struct fseq_ctx {
 	fseq_params p{};
 	hipStream_t stream = nullptr;
 	std::string err;
+	Shard sh;
+	uint8_t *d_msa_alloc = nullptr;          // what was allocated; d_msa = d_msa_alloc - c_lo * ld (column k at d_msa + k * ld)
+	uint2 *d_ent_alloc = nullptr;
+	uint32_t *d_ss_a_alloc = nullptr, *d_ss_d_alloc = nullptr;
+	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
+	uint32_t chunk_cap = 0;
+	uint2 *d_tau = nullptr;                  // merge thresholds (k_seg_tau) / counts
+	size_t tau_cap = 0;
+	std::vector<int64_t> snap_slot;          // segment index -> slot in d_snap_* (-1: another rank's)
 
 	// input
 	uint8_t *d_msa = nullptr;
@@ -262,40 +285,74 @@ void dev_free(U **p)
 
 void free_msa(fseq_ctx *c)
 {
-	if (c->own_msa) dev_free(&c->d_msa);
+	if (c->own_msa) dev_free(&c->d_msa_alloc);
+	c->d_msa_alloc = nullptr;
 	c->d_msa = nullptr;
 	c->own_msa = false;
 	c->have_input = false;
 }
+
+// columns this context holds: all of them, or the rank's share of a sharded run
+uint64_t held_lo(fseq_ctx const *c) { return c->sh.on ? c->sh.c_lo : 0; }
+uint64_t held_hi(fseq_ctx const *c) { return c->sh.on ? c->sh.c_end : c->p.n; }
 
 int alloc_msa(fseq_ctx *c)
 {
 	free_msa(c);
 	c->bsh = c->sigma <= 4 ? 2u : c->sigma <= 16 ? 1u : 0u;
 	c->ld = ((size_t) sym_bytes(c->p.m, c->bsh) + 15) & ~size_t(15);
-	int rc = dev_alloc(c, &c->d_msa, c->ld * c->p.n + 16);
+	int rc = dev_alloc(c, &c->d_msa_alloc, c->ld * (held_hi(c) - held_lo(c)) + 16);
 	if (rc) return rc;
+	c->d_msa = c->d_msa_alloc - held_lo(c) * c->ld;          // column k at d_msa + k * ld for the held columns
 	c->own_msa = true;
 	return FSEQ_OK;
 }
 
-uint32_t auto_block_len(uint64_t n, bool streamed)
-{
-	// LDS-resident kernels: ~1024 blocks (2-4 workgroups per CU).  Streamed kernels stage a whole column
-	// in LDS (one workgroup per CU) and pay the phase-B chain per block and per row: ~256 blocks.
-	uint64_t const target = streamed ? 256 : 1024;
-	uint64_t b = (n + target - 1) / target;
-	if (b < 16) b = 16;
-	if (b > 4096) b = 4096;
-	return (uint32_t) b;
-}
-
-int prepare_geometry(fseq_ctx *c)
+// Block structure of phases A-C.  Sharded: every rank is one hyper-block of phase B (chain_G2 super-blocks of
+// chain_G blocks), so the only exchange of phase B is the W composite key blocks of the ranks.
+void block_geometry(fseq_ctx *c)
 {
 	fseq_params const &p = c->p;
-	c->B = p.block_len ? p.block_len : auto_block_len(p.n, p.m > 11264u);
+	bool const streamed = p.m > 11264u;
+	Shard &sh = c->sh;
+	if (p.block_len) c->B = p.block_len;
+	else
+	{
+		// LDS-resident kernels: ~1024 blocks per GPU; streamed kernels ~256 (auto_block_len)
+		uint64_t const target = (streamed ? 256u : 1024u) * (uint64_t) (sh.on ? sh.world : 1u);
+		uint64_t b = (p.n + target - 1) / target;
+		if (b < 16) b = 16;
+		if (b > 4096) b = 4096;
+		c->B = (uint32_t) b;
+	}
+	// sharded: the DP round that starts on a rank's last column reads the lists of the RL - 1 columns behind it; the
+	// rank produces them itself by running into the next rank's first block -- which must hold them: B >= RL
+	uint32_t halo = 0;
+	if (sh.on && p.n >= 2 * p.segment_length)
+	{
+		halo = dp_schedule((uint32_t) p.segment_length, (uint32_t) p.n).RL;
+		if (c->B < halo) c->B = halo;
+	}
 	if (c->B > p.n) c->B = (uint32_t) p.n;
 	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
+	if (sh.on)
+	{
+		uint32_t const per = (c->nblocks + sh.world - 1) / sh.world;
+		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) per));
+		if (g < 1) g = 1;
+		uint32_t const g2 = (per + g - 1) / g;
+		c->chain_G = g; c->chain_G2 = g2;
+		sh.bpr = g * g2;
+		c->n_super = (c->nblocks + g - 1) / g;
+		c->n_hyper = (c->n_super + g2 - 1) / g2;
+		sh.active = c->n_hyper;                                 // <= world
+		sh.b_lo = std::min<uint64_t>(c->nblocks, (uint64_t) sh.rank * sh.bpr);
+		sh.b_hi = std::min<uint64_t>(c->nblocks, (uint64_t) (sh.rank + 1) * sh.bpr);
+		sh.c_lo = std::min<uint64_t>(p.n, (uint64_t) sh.b_lo * c->B);
+		sh.c_hi = std::min<uint64_t>(p.n, (uint64_t) sh.b_hi * c->B);
+		sh.c_end = (sh.b_hi > sh.b_lo) ? std::min<uint64_t>(p.n, sh.c_hi + halo) : sh.c_hi;
+		return;
+	}
 	{
 		// two levels: super-blocks of G ~ sqrt(nblocks) blocks, serial depth of phase B = G + nblocks/G + G key
 		// blocks; from 216 blocks on three levels (G ~ cbrt(nblocks): 5 launches of ~G serial steps)
@@ -315,6 +372,12 @@ int prepare_geometry(fseq_ctx *c)
 			c->n_hyper = (c->n_super + g - 1) / g;
 		}
 	}
+}
+
+int prepare_geometry(fseq_ctx *c)
+{
+	fseq_params const &p = c->p;
+	block_geometry(c);
 	uint32_t n2 = 1;
 	while (n2 < p.m) n2 <<= 1;
 	if (n2 < 2) n2 = 2;
@@ -400,39 +463,45 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		c->ws_words = per_block * std::max<size_t>(c->nblocks, 1);
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) return rc;
 	}
+	uint64_t const k_lo = held_lo(c), k_cnt = held_hi(c) - k_lo;      // sharded: lists and stride states of my columns only
 	if (X && (!c->d_ent || c->X != X))
 	{
 		c->X = X;
 		c->stride = (X + 3) & ~1u;                // lump + up to X+1 entries, even
-		rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256);   // padded: the DP loads strips unconditionally
+		dev_free(&c->d_ent_alloc); c->d_ent = nullptr;
+		rc = dev_alloc(c, &c->d_ent_alloc, (size_t) k_cnt * c->stride + 256);   // padded: the DP loads strips unconditionally
 		if (rc == FSEQ_E_OOM && c->d_ss_a)
 		{
 			// the stride states were sized before the lists grew: give their memory back and size them again below
-			dev_free(&c->d_ss_a); dev_free(&c->d_ss_d);
-			rc = dev_alloc(c, &c->d_ent, (size_t) p.n * c->stride + 256);
+			dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
+			rc = dev_alloc(c, &c->d_ent_alloc, (size_t) k_cnt * c->stride + 256);
 		}
 		if (rc) return rc;
+		c->d_ent = c->d_ent_alloc - (size_t) k_lo * c->stride;   // list of column k at d_ent + k * stride
 	}
 	if (X && !c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
-		// stride states for pass 2: (n / stride + 1) x m words each for a and d.  Sized after the lists: what is
-		// free now, minus the boundary snapshots pass 2 will need at most (n / L of them) and a margin, within
-		// [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.
+		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
+		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
+		// within [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			{
-				uint64_t const reserve = (p.n / p.segment_length + 1) * (uint64_t) m * 8ull + (4ull << 30);
+				uint64_t const reserve = (k_cnt / p.segment_length + 1) * (uint64_t) m * 8ull + (4ull << 30);
 				uint64_t const avail = free_b > reserve ? free_b - reserve : 0;
 				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 64ull << 30));
 			}
 		}
 		uint64_t st_ = 16;
-		while ((p.n / st_ + 1) * (uint64_t) m * 8ull > budget) st_ *= 2;
+		while ((k_cnt / st_ + 2) * (uint64_t) m * 8ull > budget) st_ *= 2;
 		c->snap_stride = (uint32_t) st_;
-		if ((rc = dev_alloc(c, &c->d_ss_a, (size_t) (p.n / st_ + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_ss_d, (size_t) (p.n / st_ + 1) * m))) return rc;
+		uint64_t const q_lo = k_lo / st_, q_hi = held_hi(c) / st_;
+		if ((rc = dev_alloc(c, &c->d_ss_a_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_ss_d_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
+		c->d_ss_a = c->d_ss_a_alloc - (size_t) q_lo * m;         // state at column q * snap_stride at d_ss_* + q * m
+		c->d_ss_d = c->d_ss_d_alloc - (size_t) q_lo * m;
 	}
 	return FSEQ_OK;
 }
@@ -443,10 +512,12 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
-	dev_free(&c->d_ent); dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
+	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
+	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
-	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a); dev_free(&c->d_ss_d); dev_free(&c->d_gent); dev_free(&c->d_ghdr);
+	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
+	dev_free(&c->d_gent); dev_free(&c->d_ghdr);
 	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 }
@@ -454,27 +525,43 @@ void free_work(fseq_ctx *c)
 // Device-side input path (row N2): rows go up as they are (one copy per row), the alphabet scan
 // (consecutive_alphabet_as_builder, generate_context.cc:135-147: dense codes in ascending byte order,
 // Appendix B A2) and the row-major -> column-major transpose run on the GPU.
+int shard_exchange(fseq_ctx *c, uint64_t words, int op);
+
 int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 {
 	fseq_params const &p = c->p;
-	size_t const total = (size_t) p.m * p.n;
+	uint64_t const k_lo = held_lo(c), nloc = held_hi(c) - k_lo;      // sharded: this rank's columns only
+	size_t const total = (size_t) p.m * nloc;
 	uint8_t *d_raw = nullptr;
 	uint32_t *d_present = nullptr;
 	int rc;
 	if ((rc = dev_alloc(c, &d_raw, total + 16))) return rc;
 	if ((rc = dev_alloc(c, &d_present, 8))) { dev_free(&d_raw); return rc; }
 	auto cleanup = [&]() { dev_free(&d_raw); dev_free(&d_present); };
-	for (uint32_t r = 0; r < p.m; ++r)
+	for (uint32_t r = 0; r < p.m && nloc; ++r)
 	{
-		hipError_t const e = hipMemcpyAsync(d_raw + (size_t) r * p.n, rows[r], p.n, hipMemcpyHostToDevice, c->stream);
+		hipError_t const e = hipMemcpyAsync(d_raw + (size_t) r * nloc, rows[r] + k_lo, nloc, hipMemcpyHostToDevice, c->stream);
 		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "row upload", e); }
 	}
 	(void) hipMemsetAsync(d_present, 0, 32, c->stream);
-	hipLaunchKernelGGL(k_presence, dim3(1024), dim3(256), 0, c->stream, d_raw, total, d_present);
+	if (total) hipLaunchKernelGGL(k_presence, dim3(1024), dim3(256), 0, c->stream, d_raw, total, d_present);
 	uint32_t present[8];
 	hipError_t e = hipMemcpyAsync(present, d_present, 32, hipMemcpyDeviceToHost, c->stream);
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "alphabet scan", e); }
+	if (c->sh.on)
+	{
+		// the alphabet is that of the whole alignment: one presence word per byte value, max over the ranks
+		uint32_t pw[256];
+		for (int b = 0; b < 256; ++b) pw[b] = (present[b >> 5] >> (b & 31)) & 1u;
+		e = hipMemcpy(c->sh.xbuf, pw, sizeof(pw), hipMemcpyHostToDevice);
+		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "alphabet exchange", e); }
+		if ((rc = shard_exchange(c, 256, 1))) { cleanup(); return rc; }
+		e = hipMemcpy(pw, c->sh.xbuf, sizeof(pw), hipMemcpyDeviceToHost);
+		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "alphabet exchange", e); }
+		memset(present, 0, sizeof(present));
+		for (int b = 0; b < 256; ++b) if (pw[b]) present[b >> 5] |= 1u << (b & 31);
+	}
 	CodeTable tab;
 	memset(&tab, 0, sizeof(tab));
 	uint32_t sigma = 0;
@@ -482,8 +569,11 @@ int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 		if ((present[b >> 5] >> (b & 31)) & 1u) { tab.code_of[b] = (uint8_t) sigma; c->code_to_byte[sigma] = (uint8_t) b; ++sigma; }
 	c->sigma = sigma;
 	if ((rc = alloc_msa(c))) { cleanup(); return rc; }
-	dim3 const grid((uint32_t) ((p.n + 63) / 64), (uint32_t) ((p.m + 63) / 64));
-	hipLaunchKernelGGL(k_encode_transpose, grid, dim3(256), 0, c->stream, d_raw, tab, p.m, p.n, c->d_msa, c->ld, c->bsh);
+	if (nloc)
+	{
+		dim3 const grid((uint32_t) ((nloc + 63) / 64), (uint32_t) ((p.m + 63) / 64));
+		hipLaunchKernelGGL(k_encode_transpose, grid, dim3(256), 0, c->stream, d_raw, tab, p.m, nloc, c->d_msa_alloc, c->ld, c->bsh);
+	}
 	e = hipGetLastError();
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
 	cleanup();
@@ -516,9 +606,9 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	size_t const tile = std::max<size_t>(1, (size_t) (8u << 20) / c->ld);
 	std::vector<uint8_t> buf(tile * c->ld);
 	uint32_t const bsh = c->bsh, smask = (1u << bsh) - 1u, bits = 8u >> bsh;
-	for (uint64_t c0 = 0; c0 < p.n; c0 += tile)
+	for (uint64_t c0 = held_lo(c); c0 < held_hi(c); c0 += tile)
 	{
-		uint64_t const c1 = std::min<uint64_t>(p.n, c0 + tile);
+		uint64_t const c1 = std::min<uint64_t>(held_hi(c), c0 + tile);
 		std::fill(buf.begin(), buf.end(), 0);
 		for (uint32_t r = 0; r < p.m; ++r)
 		{
@@ -556,93 +646,180 @@ void follow_traceback(fseq_ctx *c)
 }
 
 // ---- launches: LDS-resident kernels, or their HBM-streamed counterparts for large m
-void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys)
+// grid workgroups = the blocks starting at column col0, col0 + B, ...; rank / keyd / nkeys point at the first of them
+void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0)
 {
 	fseq_params const &p = c->p;
+	if (!grid) return;
 	if (c->use_stream)
 		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
 		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
-		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr);
+		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0);
 	else
-		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys);
+		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys, col0);
 }
 
+// grid chains grp0 .. grp0 + grid - 1, chain g over the key blocks [g * G, min(nb_total, (g + 1) * G))
 void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t nb_total, uint32_t G,
                   uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d, uint32_t *out_a, uint32_t *out_d,
-                  uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys)
+                  uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0 = 0)
 {
+	if (!grid) return;
 	if (c->use_stream)
 		hipLaunchKernelGGL(k_chain_stream, dim3(grid), dim3(ST), stream_lds_bytes(0, true), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
-		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys);
+		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	else
 		c->ks.chain(c->stream, grid, c->ks.lds_chain, rank, keyd, nkeys, c->p.m, nb_total, G, cols_per_block, start_a, start_d, out_a, out_d,
-		            out_rank, out_keyd, out_nkeys);
+		            out_rank, out_keyd, out_nkeys, grp0);
 }
 
-// The chunk plan of the speculative DP (fseq_dpspec.hpp): 0 chunks = use the serial kernel.
-struct SpecPlan { uint32_t rounds_per_chunk = 0, nchunks = 0; };
+// ---- sharded runs: the one exchange primitive (include/fseq.h, fseq_set_shard) -------------------------------
+// all-reduce of xbuf[0 .. words) over the ranks through the caller's function; the data must already be queued
+// into xbuf on c->stream.  Not sharded: nothing to do.
+int shard_exchange(fseq_ctx *c, uint64_t words, int op)
+{
+	if (!c->sh.on) return FSEQ_OK;
+	if (words > c->sh.xwords) return fail(c, FSEQ_E_ARG, "exchange buffer too small (fseq_shard_xbuf_words)");
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (c->sh.fn(c->sh.user, 0, words, op) != 0) return fail(c, FSEQ_E_HIP, "the caller's all-reduce failed");
+	return FSEQ_OK;
+}
+
+// "every rank contributes its own slice": zero the buffer, copy my words [lo, hi) of src in, all-reduce (sum), copy
+// everything back over dst -- an all-gather of unequal slices through the one primitive
+int shard_gather_u32(fseq_ctx *c, uint32_t *d_array, uint64_t total, uint64_t lo, uint64_t hi, uint64_t extra = ~0ull)
+{
+	if (!c->sh.on) return FSEQ_OK;
+	hipStream_t st = c->stream;
+	HIP_TRY(c, hipMemsetAsync(c->sh.xbuf, 0, total * 4, st));
+	if (hi > lo) HIP_TRY(c, hipMemcpyAsync(c->sh.xbuf + lo, d_array + lo, (hi - lo) * 4, hipMemcpyDeviceToDevice, st));
+	if (extra != ~0ull) HIP_TRY(c, hipMemcpyAsync(c->sh.xbuf + extra, d_array + extra, 4, hipMemcpyDeviceToDevice, st));
+	int rc = shard_exchange(c, total, 0);
+	if (rc) return rc;
+	HIP_TRY(c, hipMemcpyAsync(d_array, c->sh.xbuf, total * 4, hipMemcpyDeviceToDevice, st));
+	return FSEQ_OK;
+}
+
+// The chunk plan of the speculative DP (fseq_dpspec.hpp): chunk k runs the rounds [r0[k], r0[k + 1]) (the last one
+// also the drain round and the final cell); no chunks = use the serial kernel.  Sharded: a round belongs to the
+// rank that owns its first column; every rank cuts its own rounds into chunks and every rank computes the same table.
+struct SpecPlan {
+	std::vector<uint32_t> r0;                // nchunks + 1 entries
+	uint32_t mine_lo = 0, mine_hi = 0;       // my chunks
+	uint32_t nchunks() const { return r0.empty() ? 0u : (uint32_t) r0.size() - 1u; }
+};
 
 SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 {
 	SpecPlan P;
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
-	return P;                                // the diagnostic builds instrument the serial kernel
+	if (!c->sh.on) return P;                 // the diagnostic builds instrument the serial kernel
 #endif
-	if (getenv("FSEQ_DP_SERIAL")) return P;
+	if (getenv("FSEQ_DP_SERIAL") && !c->sh.on) return P;
 	int ncu = 0;
 	(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
 	if (ncu < 1) ncu = 1;
 	// one chunk per CU, but chunks of at least max(1024, 8L) entries (several tail windows; the sweeps of shorter
 	// chunks are cheaper but more of them are needed)
 	uint32_t const min_entries = std::max<uint32_t>(1024u, 8u * S.L);
-	uint32_t rpc = std::max<uint32_t>((S.nreg + (uint32_t) ncu - 1u) / (uint32_t) ncu, (min_entries + S.RL - 1u) / S.RL);
-	if (char const *e = getenv("FSEQ_DP_SPEC_ROUNDS")) rpc = (uint32_t) std::max(1, atoi(e));   // tests: any chunk length
-	uint32_t const nch = (S.nreg + rpc - 1u) / rpc;
-	if (nch < 3u && !getenv("FSEQ_DP_SPEC_ROUNDS")) return P;
-	if (nch < 2u || nch > 65535u) return P;
-	P.rounds_per_chunk = rpc; P.nchunks = nch;
+	uint32_t forced = 0;
+	if (char const *e = getenv("FSEQ_DP_SPEC_ROUNDS")) forced = (uint32_t) std::max(1, atoi(e));   // tests: any chunk length
+	auto cut = [&](uint32_t lo, uint32_t hi) {
+		// rounds [lo, hi) of one rank into chunks
+		if (hi <= lo) return;
+		uint32_t rpc = std::max<uint32_t>((hi - lo + (uint32_t) ncu - 1u) / (uint32_t) ncu, (min_entries + S.RL - 1u) / S.RL);
+		if (forced) rpc = forced;
+		for (uint32_t r = lo; r < hi; r += rpc) P.r0.push_back(r);
+	};
+	if (!c->sh.on)
+	{
+		cut(0, S.nreg);
+		P.r0.push_back(S.nreg);
+		uint32_t const nch = P.nchunks();
+		if ((nch < 3u && !forced) || nch < 2u || nch > 65535u) { P.r0.clear(); return P; }
+		P.mine_lo = 0; P.mine_hi = nch;
+		return P;
+	}
+	Shard const &sh = c->sh;
+	uint32_t prev = 0;
+	for (uint32_t g = 0; g < sh.active; ++g)
+	{
+		// rounds whose first column (L + r RL - 1) lies in rank g's columns; the last active rank takes the rest
+		uint64_t const hi_col = std::min<uint64_t>(c->p.n, (uint64_t) (g + 1) * sh.bpr * c->B);
+		uint32_t r_hi = S.nreg;
+		if (g + 1 < sh.active)
+		{
+			uint64_t const need = hi_col + 1 > S.L ? hi_col + 1 - S.L : 0;      // first round with L + r RL - 1 >= hi_col
+			r_hi = (uint32_t) std::min<uint64_t>(S.nreg, (need + S.RL - 1) / S.RL);
+		}
+		if (r_hi < prev) r_hi = prev;
+		if (g == sh.rank) P.mine_lo = (uint32_t) P.r0.size();
+		cut(prev, r_hi);
+		if (g == sh.rank) P.mine_hi = (uint32_t) P.r0.size();
+		prev = r_hi;
+	}
+	P.r0.push_back(S.nreg);
+	if (sh.rank >= sh.active) P.mine_lo = P.mine_hi = P.nchunks();
 	return P;
 }
 
 // Phase D as chunk-speculative sweeps on the whole chip (fseq_dpspec.hpp).  Leaves M / LB / SZ exactly as
-// k_dp<DP_WHOLE> would; *overflow = some cell's list was too short.
+// k_dp<DP_WHOLE> would (on every rank of a sharded run); *overflow = some cell's list was too short.
 int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t st, uint32_t *overflow, uint32_t *sweeps_out)
 {
 	fseq_params const &p = c->p;
 	uint32_t const m = p.m, n = (uint32_t) p.n, L = (uint32_t) p.segment_length;
-	uint32_t const nch = P.nchunks;
+	uint32_t const nch = P.nchunks();
+	bool const sharded = c->sh.on;
 	int rc;
 	if (c->spec_cap < nch)
 	{
 		if ((rc = dev_alloc(c, &c->d_spec, (size_t) 6 * nch + 16))) return rc;
 		c->spec_cap = nch;
 	}
+	if (c->chunk_cap < nch + 1u)
+	{
+		if ((rc = dev_alloc(c, &c->d_chunk_r0, nch + 1u))) return rc;
+		c->chunk_cap = nch + 1u;
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->d_chunk_r0, P.r0.data(), (size_t) (nch + 1u) * 4, hipMemcpyHostToDevice, st));
 	uint32_t *d_active = c->d_spec, *d_changed = d_active + nch, *d_tailmin = d_changed + nch, *d_floor = d_tailmin + nch,
 	         *d_lift = d_floor + nch, *d_ovf = d_lift + nch;
 	SpecCtl *d_ctl = reinterpret_cast<SpecCtl *>(d_ovf + nch);
 	SpecGeom G;
-	G.entries_per_chunk = P.rounds_per_chunk * S.RL;
+	G.chunk_r0 = c->d_chunk_r0;
+	G.RL = S.RL;
 	G.nchunks = nch;
 	G.NR = n - 2u * L + 1u;
 	G.t_final = n - L;
 	G.win = std::max<uint32_t>(256u, 4u * L);
 	if (char const *e = getenv("FSEQ_DP_SPEC_WIN")) G.win = (uint32_t) std::max(1, atoi(e));
-	uint32_t const nblk = (G.NR + 63u) / 64u, ncomplete = G.NR / 64u;
+	uint32_t const ncomplete = G.NR / 64u;
 	uint32_t const grid_c = (uint32_t) ((c->dp_size + 255) / 256);          // 4 blocks of 64 entries per workgroup, incl. the final cell's
-	(void) nblk;
 	HIP_TRY(c, hipMemsetAsync(c->dp.M, 0, c->dp_size * 4, st));
 	HIP_TRY(c, hipMemsetAsync(c->d_Mprev, 0, c->dp_size * 4, st));
 	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 6 * nch + 16) * 4, st));
 	HIP_TRY(c, hipMemsetAsync(d_active, 0x01, (size_t) nch * 4, st));        // != 0: every chunk runs in sweep 1
+	if (sharded)
+	{
+		// LB / SZ are gathered over the ranks at the end: what nobody writes must be 0 everywhere
+		HIP_TRY(c, hipMemsetAsync(c->dp.LB, 0, c->dp_size * 4, st));
+		HIP_TRY(c, hipMemsetAsync(c->dp.SZ, 0, c->dp_size * 4, st));
+	}
 
 	DpSpecArgs SP;
-	SP.rounds_per_chunk = P.rounds_per_chunk; SP.nchunks = nch; SP.active = d_active; SP.ovf = d_ovf;
+	SP.chunk_r0 = c->d_chunk_r0; SP.nchunks = nch; SP.chunk0 = P.mine_lo; SP.active = d_active; SP.ovf = d_ovf;
 	SP.ctl = reinterpret_cast<uint32_t const *>(d_ctl);
+	uint32_t const mine = P.mine_hi - P.mine_lo;
+	// my entries: the chunks [mine_lo, mine_hi) are consecutive rounds
+	uint64_t const t_lo = mine ? (uint64_t) P.r0[P.mine_lo] * S.RL : 0, t_hi = mine ? (P.mine_hi == nch ? G.NR : (uint64_t) P.r0[P.mine_hi] * S.RL) : 0;
+	uint64_t const t_extra = (mine && P.mine_hi == nch) ? G.t_final : ~0ull;
 	auto sweep = [&](bool fresh) {
 		SP.fresh = fresh ? 1u : 0u;
-		hipLaunchKernelGGL(k_dp<DP_SPEC>, dim3(nch), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
-		                   c->d_flags, 0u, 0u, SP);
+		if (mine)
+			hipLaunchKernelGGL(k_dp<DP_SPEC>, dim3(mine), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
+			                   c->d_flags, 0u, 0u, SP);
 	};
 	auto compare = [&](bool first) {
 		hipLaunchKernelGGL(k_spec_scan, dim3(nch), dim3(256), 0, st, c->dp.M, c->d_Mprev, G, d_active, d_changed, d_tailmin, d_ctl);
@@ -657,39 +834,60 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	SpecCtl h{};
 	sweep(true);
 	uint32_t done_sweeps = 1;
-	// every kernel returns at once when the iteration has converged, so sweeps are queued ahead of the
-	// host's look at the control word: three further sweeps first (the measured common case needs three in all),
-	// then two at a time
-	uint32_t batch = 3;
-	while (true)
+	if (!sharded)
 	{
-		for (uint32_t i = 0; i < batch && done_sweeps < max_sweeps; ++i)
+		// every kernel returns at once when the iteration has converged, so sweeps are queued ahead of the
+		// host's look at the control word: three further sweeps first (the measured common case needs three in
+		// all), then one at a time
+		uint32_t batch = 3;
+		while (true)
 		{
+			for (uint32_t i = 0; i < batch && done_sweeps < max_sweeps; ++i)
+			{
+				compare(done_sweeps == 1);
+				rebuild();
+				sweep(false);
+				++done_sweeps;
+			}
 			compare(done_sweeps == 1);
+			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipStreamSynchronize(st));
+			HIP_TRY(c, hipGetLastError());
+			if (h.done || done_sweeps >= max_sweeps) break;
+			// the compare just queued has already chosen the next sweep's active set and lifts
+			rebuild();
+			sweep(false);
+			++done_sweeps;
+			batch = 1;
+		}
+	}
+	else
+	{
+		// sharded: after every sweep the ranks exchange the keys of their chunks; compare / lift / rebuild then run
+		// on the whole arrays on every rank (same inputs, same results), the next sweep again on the rank's own chunks
+		while (true)
+		{
+			if ((rc = shard_gather_u32(c, c->dp.M, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+			compare(done_sweeps == 1);
+			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipStreamSynchronize(st));
+			HIP_TRY(c, hipGetLastError());
+			if (h.done) break;                   // no serial fallback here: after sweep k the chunks 0..k-1 are exact, so this ends
+			if (done_sweeps > nch + 2u) return fail(c, FSEQ_E_HIP, "internal: speculative DP did not converge");
 			rebuild();
 			sweep(false);
 			++done_sweeps;
 		}
-		compare(done_sweeps == 1);
-		HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
-		HIP_TRY(c, hipStreamSynchronize(st));
-		HIP_TRY(c, hipGetLastError());
-		if (h.done || done_sweeps >= max_sweeps) break;
-		// the compare just queued has already chosen the next sweep's active set and lifts
-		rebuild();
-		sweep(false);
-		++done_sweeps;
-		batch = 1;
 	}
 	if (!h.done)
 	{
-		// bounded: finish serially behind the last chunk known to be exact (its masks and samples are rebuilt first)
+		// bounded (one GPU only): finish serially behind the last chunk known to be exact (its masks and samples are rebuilt first)
 		rebuild();
-		uint32_t const r0 = (h.first_changed + 1u) * P.rounds_per_chunk;
+		uint32_t const first_dirty = std::min(h.first_changed + 1u, nch);
+		uint32_t const r0 = first_dirty < nch ? P.r0[first_dirty] : S.nreg;
 		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
-		if (r0 < S.nrounds)
-			hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
-			                   c->d_flags, std::min(r0, S.nreg), S.nrounds, DpSpecArgs{});
+		hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
+		                   c->d_flags, r0, S.nrounds, DpSpecArgs{});
 		// overflow: the serial part reports through d_flags, the frozen chunks through their own words
 		std::vector<uint32_t> ovf(nch);
 		uint32_t fl[4] = {0, 0, 0, 0};
@@ -698,15 +896,34 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		HIP_TRY(c, hipStreamSynchronize(st));
 		HIP_TRY(c, hipGetLastError());
 		uint32_t o = fl[0] & 1u;
-		for (uint32_t k = 0; k <= h.first_changed && k < nch; ++k) o |= ovf[k] ? 1u : 0u;
+		for (uint32_t k = P.mine_lo; k < P.mine_hi && k <= h.first_changed; ++k) o |= ovf[k] ? 1u : 0u;
 		*overflow = o;
 		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] speculative DP: not converged after %u sweeps, serial from round %u\n", done_sweeps, r0);
 	}
 	else
-		*overflow = h.overflow;
+	{
+		// the chunks' "list too short" words are written by their owners only
+		std::vector<uint32_t> ovf(nch);
+		HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		uint32_t o = 0;
+		for (uint32_t k = P.mine_lo; k < P.mine_hi; ++k) o |= ovf[k] ? 1u : 0u;
+		*overflow = o;
+	}
+	if (sharded)
+	{
+		// lb and size of every entry from the rank that computed it (frozen chunks: from the sweep that last ran them)
+		if ((rc = shard_gather_u32(c, c->dp.LB, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+		if ((rc = shard_gather_u32(c, c->dp.SZ, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+		uint32_t o = *overflow;
+		HIP_TRY(c, hipMemcpyAsync(c->sh.xbuf, &o, 4, hipMemcpyHostToDevice, st));
+		if ((rc = shard_exchange(c, 1, 1))) return rc;
+		HIP_TRY(c, hipMemcpy(&o, c->sh.xbuf, 4, hipMemcpyDeviceToHost));
+		*overflow = o;
+	}
 	if (sweeps_out) *sweeps_out = h.done ? h.sweeps : done_sweeps + 1000u;
 	if (getenv("FSEQ_DEBUG"))
-		fprintf(stderr, "[fseq] speculative DP: %u chunks of %u rounds, %u sweeps compared, done=%u\n", nch, P.rounds_per_chunk, h.sweeps, h.done);
+		fprintf(stderr, "[fseq] speculative DP: %u chunks (mine %u..%u), %u sweeps compared, done=%u\n", nch, P.mine_lo, P.mine_hi, h.sweeps, h.done);
 	return FSEQ_OK;
 }
 
@@ -729,9 +946,14 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	if ((rc = ensure_work_buffers(c, 0))) return rc;
 
 	// ---- phase A + B (independent of X)
+	Shard const &sh = c->sh;
+	bool const sharded = sh.on;
+	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : c->nblocks;     // my blocks
+	uint32_t const my_blocks = b_hi - b_lo;
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
-	launch_rank(c, c->nblocks, c->B, c->nblocks, c->d_rank, c->d_keyd, c->d_nkeys);
+	launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
+	if (!sharded)
 	{
 		// phase B: compose groups of G blocks into super-blocks (parallel), -- three levels:
 		// compose groups of G2 super-blocks into hyper-blocks (parallel) -- chain the top level (one
@@ -760,14 +982,63 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
 		}
 	}
+	else
+	{
+		// Sharded phase B: rank r is hyper-block r.  Compose my super-blocks, compose them into my hyper key block,
+		// exchange the W hyper key blocks (the one collective of pass 1's column work), chain them (every rank, same
+		// result), expand my hyper-block to my super-block and then my block boundaries.
+		uint32_t const G = c->chain_G, NSB = c->n_super, G2 = c->chain_G2, NH = c->n_hyper;
+		bool const have = sh.rank < NH;
+		uint32_t const s_lo = std::min(NSB, sh.rank * G2), s_hi = std::min(NSB, (sh.rank + 1u) * G2);
+		launch_chain(c, s_hi - s_lo, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, nullptr, nullptr,
+		             nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys, s_lo);
+		if (have)
+			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, nullptr, nullptr,
+			             nullptr, nullptr, c->d_hrank, c->d_hkeyd, c->d_hnkeys, sh.rank);
+		{
+			// xbuf: [hrank NH x m][hkeyd NH x m][hnkeys NH]
+			size_t const w = (size_t) NH * m;
+			HIP_TRY(c, hipMemsetAsync(sh.xbuf, 0, (2 * w + NH) * 4, st));
+			if (have)
+			{
+				HIP_TRY(c, hipMemcpyAsync(sh.xbuf + (size_t) sh.rank * m, c->d_hrank + (size_t) sh.rank * m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+				HIP_TRY(c, hipMemcpyAsync(sh.xbuf + w + (size_t) sh.rank * m, c->d_hkeyd + (size_t) sh.rank * m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+				HIP_TRY(c, hipMemcpyAsync(sh.xbuf + 2 * w + sh.rank, c->d_hnkeys + sh.rank, 4, hipMemcpyDeviceToDevice, st));
+			}
+			if ((rc = shard_exchange(c, 2 * w + NH, 0))) return rc;
+			HIP_TRY(c, hipMemcpyAsync(c->d_hrank, sh.xbuf, w * 4, hipMemcpyDeviceToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_hkeyd, sh.xbuf + w, w * 4, hipMemcpyDeviceToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_hnkeys, sh.xbuf + 2 * w, (size_t) NH * 4, hipMemcpyDeviceToDevice, st));
+		}
+		launch_chain(c, 1, c->d_hrank, c->d_hkeyd, c->d_hnkeys, NH, NH, (uint64_t) G2 * G * c->B, nullptr, nullptr,
+		             c->d_hstate_a, c->d_hstate_d, nullptr, nullptr, nullptr);
+		if (have)
+		{
+			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, c->d_hstate_a, c->d_hstate_d,
+			             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr, sh.rank);
+			launch_chain(c, s_hi - s_lo, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
+			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr, s_lo);
+			// the state behind my last block = in front of the next rank's hyper-block (or behind the whole alignment,
+			// which the expansion has written itself): my halo block starts from it
+			if (b_hi < c->nblocks)
+			{
+				HIP_TRY(c, hipMemcpyAsync(c->d_bstate_a + (size_t) b_hi * m, c->d_hstate_a + (size_t) (sh.rank + 1u) * m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+				HIP_TRY(c, hipMemcpyAsync(c->d_bstate_d + (size_t) b_hi * m, c->d_hstate_d + (size_t) (sh.rank + 1u) * m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+			}
+		}
+	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
 	if (!p.list_cap && !c->X_hint)
 	{
 		// first run on this input: size the lists from the block boundary states (k_boundary_recent)
-		std::vector<uint32_t> recent(c->nblocks + 1);
-		hipLaunchKernelGGL(k_boundary_recent, dim3(c->nblocks + 1), dim3(256), 0, st, c->d_bstate_d, m, n, c->B, (uint32_t) L, c->d_recent);
-		HIP_TRY(c, hipMemcpyAsync(recent.data(), c->d_recent, recent.size() * 4, hipMemcpyDeviceToHost, st));
+		// (sharded: every rank looks at its own boundaries, the ranks then agree on the largest estimate)
+		std::vector<uint32_t> recent(my_blocks ? my_blocks + 1 : 0);
+		if (my_blocks)
+		{
+			hipLaunchKernelGGL(k_boundary_recent, dim3(my_blocks + 1), dim3(256), 0, st, c->d_bstate_d, m, n, c->B, (uint32_t) L, c->d_recent, b_lo);
+			HIP_TRY(c, hipMemcpyAsync(recent.data(), c->d_recent, recent.size() * 4, hipMemcpyDeviceToHost, st));
+		}
 		HIP_TRY(c, hipStreamSynchronize(st));
 		recent.erase(std::remove(recent.begin(), recent.end(), 0xFFFFFFFFu), recent.end());
 		if (!recent.empty())
@@ -780,6 +1051,12 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				fprintf(stderr, "[fseq] list capacity estimate: %zu boundaries, median recent count %llu -> X = %u\n",
 				        recent.size(), (unsigned long long) med, X);
 		}
+	}
+	if (sharded)
+	{
+		HIP_TRY(c, hipMemcpyAsync(sh.xbuf, &X, 4, hipMemcpyHostToDevice, st));
+		if ((rc = shard_exchange(c, 1, 1))) return rc;
+		HIP_TRY(c, hipMemcpy(&X, sh.xbuf, 4, hipMemcpyDeviceToHost));
 	}
 	if (X >= m) X = m;
 
@@ -799,7 +1076,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		if (getenv("FSEQ_POISON_LISTS"))
 		{
 			// tests of the DP-beside-phase-C forms: a list read before it is written must not look right by accident
-			HIP_TRY(c, hipMemsetAsync(c->d_ent, 0xFF, ((size_t) n * c->stride + 256) * sizeof(uint2), st));
+			HIP_TRY(c, hipMemsetAsync(c->d_ent_alloc, 0xFF, ((size_t) (held_hi(c) - held_lo(c)) * c->stride + 256) * sizeof(uint2), st));
 			HIP_TRY(c, hipMemsetAsync(c->d_hdr, 0xFF, (size_t) n * sizeof(uint4), st));
 		}
 		// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
@@ -811,7 +1088,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		// default: the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp);
 		// the forms that run the serial DP beside phase C remain for FSEQ_DP_SERIAL and the forced test schedules
 		SpecPlan const spec = spec_plan(c, S);
-		bool const use_spec = spec.nchunks > 0 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_HOST_FLAGS") && !getenv("FSEQ_DP_CHUNKS");
+		bool const use_spec = sharded || (spec.nchunks() > 0 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_HOST_FLAGS") && !getenv("FSEQ_DP_CHUNKS"));
+		if (sharded && spec.nchunks() < 1) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: no DP chunk plan");
+		// columns phase C covers here: all, or my blocks plus the halo block's first columns (the lists my last DP round reads)
+		uint64_t const n_c = sharded ? sh.c_end : n;
 		uint32_t spec_overflow = 0, spec_sweeps = 0;
 		uint32_t parts = 1, part_blocks = c->nblocks;
 		if (!use_spec)
@@ -837,10 +1117,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
 			if (c->use_stream)
-				hipLaunchKernelGGL(k_columns_stream, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+				hipLaunchKernelGGL(k_columns_stream, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
 				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 			else
-				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
+				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
 				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 		};
 		// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
@@ -896,7 +1176,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 		else if (parts <= 1)
 		{
-			launch_columns(0, c->nblocks);
+			if (!sharded) launch_columns(0, c->nblocks);
+			else if (my_blocks)
+			{
+				// my blocks, and the block behind them for as far as the halo reaches (k_columns stops at n_c)
+				uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
+				launch_columns(b_lo, nb);
+			}
 			HIP_TRY(c, hipEventRecord(c->ev[4], st));
 			// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
 			// each resuming from the arrays the one before it flushed
@@ -989,7 +1275,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		double const th0 = now_ms();
 		bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
 		c->tm.dp_sweeps = spec_sweeps;
-		c->tm.dp_chunks = use_spec ? spec.nchunks : 0u;
+		c->tm.dp_chunks = use_spec ? spec.nchunks() : 0u;
 
 		if (!overflow)
 		{
@@ -1000,64 +1286,90 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			c->res.short_path = 0;
 			size_t const S = c->traceback.size();
 
-			// ---- find_segments_greedy (lp.cc:335-390) from the per-column lists at the traceback rbs
+			// ---- find_segments_greedy (lp.cc:335-390).  Its test #{d_rb > current_lb} <= max_segment_size (:363-364)
+			// holds exactly for current_lb >= tau_rb; tau comes from the list of column rb - 1 where that list lives
+			// (k_seg_tau: one number per traceback boundary instead of the lists; sharded: every rank for its columns).
 			c->segments.clear();
 			if (max_seg < m)
 			{
+				uint64_t const own_lo = held_lo(c), own_hi = sharded ? sh.c_hi : n;      // columns whose lists I answer for
+				std::vector<uint2> tau(S);
 				if (S > 1)
 				{
-					if (c->cols_cap < S) { if ((rc = dev_alloc(c, &c->d_cols, S))) return rc; c->cols_cap = S; }
-					if (c->gather_cap < S || c->gather_stride != c->stride)
-					{
-						if ((rc = dev_alloc(c, &c->d_gent, S * (size_t) c->stride))) return rc;
-						if ((rc = dev_alloc(c, &c->d_ghdr, S))) return rc;
-						c->gather_cap = S; c->gather_stride = c->stride;
-					}
+					if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
+					if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
 					std::vector<uint64_t> cols(S);
 					for (size_t j = 0; j < S; ++j) cols[j] = c->traceback[j].rb - 1;
 					HIP_TRY(c, hipMemcpyAsync(c->d_cols, cols.data(), S * 8, hipMemcpyHostToDevice, st));
-					hipLaunchKernelGGL(k_gather_lists, dim3((uint32_t) S), dim3(64), 0, st, c->d_cols, c->stride, c->d_ent, c->d_hdr, c->d_gent, c->d_ghdr);
-					h_gent.resize(S * (size_t) c->stride);
-					h_ghdr.resize(S);
-					HIP_TRY(c, hipMemcpyAsync(h_gent.data(), c->d_gent, h_gent.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
-					HIP_TRY(c, hipMemcpyAsync(h_ghdr.data(), c->d_ghdr, S * sizeof(uint4), hipMemcpyDeviceToHost, st));
+					hipLaunchKernelGGL(k_seg_tau, dim3((uint32_t) S), dim3(64), 0, st, c->d_cols, own_lo, own_hi, max_seg, c->stride, c->d_ent, c->d_hdr, c->d_tau);
+					if (sharded)
+					{
+						HIP_TRY(c, hipMemcpyAsync(sh.xbuf, c->d_tau, S * 8, hipMemcpyDeviceToDevice, st));
+						if ((rc = shard_exchange(c, 2 * S, 0))) return rc;
+						HIP_TRY(c, hipMemcpyAsync(tau.data(), sh.xbuf, S * 8, hipMemcpyDeviceToHost, st));
+					}
+					else
+						HIP_TRY(c, hipMemcpyAsync(tau.data(), c->d_tau, S * 8, hipMemcpyDeviceToHost, st));
 					HIP_TRY(c, hipStreamSynchronize(st));
+					HIP_TRY(c, hipGetLastError());
 				}
+				// the walk itself; a merged segment's size is the count at its last boundary (:366), asked for afterwards
+				struct Pending { size_t seg; uint64_t col, lb; };
+				std::vector<Pending> ask;
 				uint64_t current_lb = 0;
 				uint64_t prev_size = c->traceback[0].segment_size;
+				bool prev_size_pending = false;
 				size_t prev = 0;
+				auto emit = [&]() {
+					fseq_segment sg{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
+					if (prev_size_pending) ask.push_back(Pending{c->segments.size(), c->traceback[prev].rb - 1, current_lb});
+					c->segments.push_back(sg);
+				};
 				for (size_t j = 1; j < S && !overflow; ++j)
 				{
-					// unique_substring_count_lhs(current_lb) = #{d > current_lb} (Appendix B A7)
-					uint4 const h = h_ghdr[j];
-					uint2 const *list = h_gent.data() + j * (size_t) c->stride;
-					uint64_t cnt = 0;
-					bool known = h.z != 0;
-					for (uint32_t i = 0; i < h.x; ++i)
-					{
-						if (list[i].x > current_lb) cnt += list[i].y;
-						else { known = true; break; }
-					}
-					if (!known && cnt <= max_seg) { overflow = true; break; }
-					if (cnt <= max_seg)
-						prev_size = cnt;
+					uint2 const t = tau[j];
+					bool const fits = t.y != SEG_TAU_NEVER && current_lb >= t.x;
+					if (!fits && t.y == SEG_TAU_OPEN) { overflow = true; break; }     // the list ended before it could tell
+					if (fits)
+						prev_size_pending = true;                                       // prev_size = the count at boundary j (:366)
 					else
 					{
-						fseq_segment s{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
-						c->segments.push_back(s);
+						emit();
 						prev_size = c->traceback[j].segment_size;
+						prev_size_pending = false;
 						current_lb = c->traceback[prev].rb;
 					}
 					prev = j;
 				}
 				if (!overflow)
 				{
-					fseq_segment s{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
-					c->segments.push_back(s);
+					emit();
+					if (!ask.empty())
+					{
+						size_t const Q = ask.size();
+						std::vector<uint64_t> qc(2 * Q);
+						for (size_t i = 0; i < Q; ++i) { qc[i] = ask[i].col; qc[Q + i] = ask[i].lb; }
+						std::vector<uint32_t> cnt(Q);
+						HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc.data(), 2 * Q * 8, hipMemcpyHostToDevice, st));
+						uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->d_tau);
+						hipLaunchKernelGGL(k_seg_count, dim3((uint32_t) Q), dim3(64), 0, st, c->d_cols, c->d_cols + Q, own_lo, own_hi, c->stride, c->d_ent, c->d_hdr, d_cnt);
+						if (sharded)
+						{
+							HIP_TRY(c, hipMemcpyAsync(sh.xbuf, d_cnt, Q * 4, hipMemcpyDeviceToDevice, st));
+							if ((rc = shard_exchange(c, Q, 0))) return rc;
+							HIP_TRY(c, hipMemcpyAsync(cnt.data(), sh.xbuf, Q * 4, hipMemcpyDeviceToHost, st));
+						}
+						else
+							HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, Q * 4, hipMemcpyDeviceToHost, st));
+						HIP_TRY(c, hipStreamSynchronize(st));
+						HIP_TRY(c, hipGetLastError());
+						for (size_t i = 0; i < Q; ++i) c->segments[ask[i].seg].segment_size = cnt[i];
+					}
 				}
 			}
 		}
 		ms_host += now_ms() - th0;
+		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
 		if (!overflow) break;
 		if (X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
 		X = (uint32_t) std::min<uint64_t>(m, (uint64_t) X * 2 + 1);
@@ -1074,38 +1386,51 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	if (S2)
 	{
 		if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
-		if (c->snap_cap < S2)
-		{
-			if ((rc = dev_alloc(c, &c->d_snap_a, S2 * (size_t) m))) return rc;
-			if ((rc = dev_alloc(c, &c->d_snap_d, S2 * (size_t) m))) return rc;
-			c->snap_cap = S2;
-		}
 		// every boundary starts from the nearest exact state at or below it: a block boundary state
 		// (phase B) or one of the states phase C dropped every snap_stride columns; boundaries that share
 		// a start state share one sweep (boundaries ascending)
-		std::vector<uint64_t> rbs(S2), srcs;
+		// sharded: a boundary belongs to the rank whose blocks hold the state in front of it
+		std::vector<uint64_t> rbs, srcs;
 		std::vector<uint2> grp;
 		uint64_t const sstr = c->snap_stride;
 		std::vector<uint64_t> starts;
+		c->snap_slot.assign(S2, -1);
 		for (size_t i = 0; i < S2; ++i)
 		{
-			rbs[i] = c->segments[i].rb;
-			uint64_t const blk = std::min<uint64_t>(rbs[i] / c->B, c->nblocks);
-			uint64_t const q = rbs[i] / sstr;
+			uint64_t const rb = c->segments[i].rb;
+			if (sharded)
+			{
+				uint32_t const owner = (uint32_t) std::min<uint64_t>(rb / ((uint64_t) sh.bpr * c->B), sh.active - 1u);
+				if (owner != sh.rank) continue;
+			}
+			c->snap_slot[i] = (int64_t) rbs.size();
+			rbs.push_back(rb);
+			uint64_t const blk = std::min<uint64_t>(rb / c->B, c->nblocks);
+			uint64_t const q = rb / sstr;
 			uint64_t src = blk, p0 = blk * c->B;
 			if (c->d_ss_a && q >= 1 && q * sstr > p0) { src = q | (1ull << 63); p0 = q * sstr; }
-			if (grp.empty() || srcs.back() != src) { grp.push_back(make_uint2((uint32_t) i, 1u)); srcs.push_back(src); starts.push_back(p0); }
+			if (grp.empty() || srcs.back() != src) { grp.push_back(make_uint2((uint32_t) (rbs.size() - 1), 1u)); srcs.push_back(src); starts.push_back(p0); }
 			else ++grp.back().y;
 		}
 		for (size_t g = 0; g < grp.size(); ++g)
 			pass2_cells += (rbs[grp[g].x + grp[g].y - 1] - starts[g]) * m;
+		size_t const S2m = rbs.size();                            // boundaries that are mine (all of them when not sharded)
+		if (c->snap_cap < S2m)
+		{
+			if ((rc = dev_alloc(c, &c->d_snap_a, S2m * (size_t) m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_snap_d, S2m * (size_t) m))) return rc;
+			c->snap_cap = S2m;
+		}
 		if (c->src_cap < srcs.size()) { if ((rc = dev_alloc(c, &c->d_src, srcs.size()))) return rc; c->src_cap = srcs.size(); }
 		HIP_TRY(c, hipMemcpyAsync(c->d_src, srcs.data(), srcs.size() * 8, hipMemcpyHostToDevice, st));
 		if (c->grp_cap < grp.size()) { if ((rc = dev_alloc(c, &c->d_grp, grp.size()))) return rc; c->grp_cap = grp.size(); }
-		HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
-		HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+		if (S2m) HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2m * 8, hipMemcpyHostToDevice, st));
+		if (!grp.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
-		if (c->use_stream)
+		if (grp.empty())
+		{
+		}
+		else if (c->use_stream)
 		{
 			// the streamed sweep needs 4m workspace words per workgroup: as many groups per launch as d_ws holds
 			size_t const cap = std::max<size_t>(1, c->ws_words / (4 * (size_t) m));
@@ -1114,7 +1439,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				size_t const cnt = std::min(cap, grp.size() - g0);
 				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
 				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
-				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d);
+				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d, (uint64_t) 0);
 			}
 		}
 		else
@@ -1125,6 +1450,18 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipStreamSynchronize(st));
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); ms_p2 = f;
+		if (sharded)
+		{
+			// R of SURVEY.md 8(d) is the sum over the ranks: one slot pair per rank
+			uint32_t slots[2] = {(uint32_t) pass2_cells, (uint32_t) (pass2_cells >> 32)};
+			std::vector<uint32_t> all(2 * sh.world);
+			HIP_TRY(c, hipMemsetAsync(sh.xbuf, 0, all.size() * 4, st));
+			HIP_TRY(c, hipMemcpyAsync(sh.xbuf + 2 * sh.rank, slots, 8, hipMemcpyHostToDevice, st));
+			if ((rc = shard_exchange(c, all.size(), 0))) return rc;
+			HIP_TRY(c, hipMemcpy(all.data(), sh.xbuf, all.size() * 4, hipMemcpyDeviceToHost));
+			pass2_cells = 0;
+			for (uint32_t g = 0; g < sh.world; ++g) pass2_cells += (uint64_t) all[2 * g] | ((uint64_t) all[2 * g + 1] << 32);
+		}
 	}
 
 	{
@@ -1296,7 +1633,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 		return fail(c, FSEQ_E_ARG, "device columns: ld must be >= m and a multiple of 16, base 16-byte aligned");
 	if (sigma == 0 || sigma > 256) return fail(c, FSEQ_E_ARG, "sigma out of range");
 	free_msa(c);
-	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_codes));
+	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_codes)) - held_lo(c) * ld;
 	c->ld = ld;
 	c->bsh = 0;                              // borrowed columns are one code per byte
 	c->own_msa = false;
@@ -1318,7 +1655,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	if (ld_bytes < sym_bytes(c->p.m, bsh) || (ld_bytes & 15) || (reinterpret_cast<uintptr_t>(d_packed) & 15))
 		return fail(c, FSEQ_E_ARG, "packed device columns: ld_bytes must cover a column and be a multiple of 16, base 16-byte aligned");
 	free_msa(c);
-	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_packed));
+	c->d_msa = const_cast<uint8_t *>(static_cast<uint8_t const *>(d_packed)) - held_lo(c) * ld_bytes;
 	c->ld = ld_bytes;
 	c->bsh = bsh;
 	c->own_msa = false;
@@ -1328,6 +1665,64 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	return FSEQ_OK;
+}
+
+uint64_t fseq_shard_xbuf_words(fseq_ctx const *c, uint32_t world)
+{
+	if (!c || 0 == world) return 0;
+	// the largest exchanges: a whole DP array (keys, then lb, then size, one at a time), the hyper key blocks of
+	// phase B (world x (2m + 1) words), the merge thresholds (2 words per traceback boundary <= n / L + 1)
+	uint64_t const dp = c->p.n >= c->p.segment_length ? c->p.n - c->p.segment_length + 1 : 1;
+	uint64_t const keys = (uint64_t) world * (2ull * c->p.m + 1);
+	uint64_t const tb = 2 * (c->p.n / std::max<uint64_t>(1, c->p.segment_length) + 2);
+	return std::max<uint64_t>(std::max(std::max(dp, tb), keys), 1024) + 64;
+}
+
+int fseq_set_shard(fseq_ctx *c, uint32_t rank, uint32_t world, void *xbuf_device, uint64_t xbuf_words, fseq_allreduce_fn fn, void *user)
+{
+	if (!c || 0 == world || rank >= world) return FSEQ_E_ARG;
+	if (c->have_input) return fail(c, FSEQ_E_ARG, "fseq_set_shard must be called before the input is set");
+	if (1 == world) { c->sh = Shard{}; return FSEQ_OK; }
+	if (!xbuf_device || !fn) return fail(c, FSEQ_E_ARG, "sharded run: exchange buffer and all-reduce function needed");
+	if (c->p.n < 2 * c->p.segment_length) return fail(c, FSEQ_E_UNSUPPORTED, "the short path (n < 2L) is one sweep and does not shard");
+	Shard sh;
+	sh.on = true; sh.rank = rank; sh.world = world;
+	sh.xbuf = static_cast<uint32_t *>(xbuf_device); sh.xwords = xbuf_words; sh.fn = fn; sh.user = user;
+	c->sh = sh;
+	block_geometry(c);
+	uint64_t const need = fseq_shard_xbuf_words(c, world);
+	if (xbuf_words < need) { c->sh = Shard{}; return fail(c, FSEQ_E_ARG, "exchange buffer too small (fseq_shard_xbuf_words)"); }
+	// every rank that owns blocks must own at least one regular DP round, and the last one the final cell's column
+	DpSchedule const S = dp_schedule((uint32_t) c->p.segment_length, (uint32_t) c->p.n);
+	SpecPlan const P = spec_plan(c, S);
+	bool ok = P.nchunks() >= 1;
+	if (ok && c->sh.rank < c->sh.active && P.mine_hi <= P.mine_lo) ok = false;
+	// (the plan is the same on every rank: check every rank's share here so that all ranks fail together)
+	for (uint32_t g = 0; ok && g < c->sh.active; ++g)
+	{
+		Shard probe = c->sh; probe.rank = g;
+		Shard const keep = c->sh; c->sh = probe;
+		SpecPlan const Q = spec_plan(c, S);
+		c->sh = keep;
+		if (Q.mine_hi <= Q.mine_lo) ok = false;
+		if (g + 1 == c->sh.active && Q.mine_hi != Q.nchunks()) ok = false;
+	}
+	if (!ok) { c->sh = Shard{}; return fail(c, FSEQ_E_UNSUPPORTED, "too few columns per rank for this segment length: use fewer ranks"); }
+	return FSEQ_OK;
+}
+
+int fseq_shard_columns(fseq_ctx const *c, uint64_t *first, uint64_t *last)
+{
+	if (!c || !first || !last) return FSEQ_E_ARG;
+	*first = held_lo(c); *last = held_hi(c);
+	return FSEQ_OK;
+}
+
+int fseq_shard_owner(fseq_ctx const *c, uint64_t rb, uint32_t *rank)
+{
+	if (!c || !rank || rb > c->p.n) return FSEQ_E_ARG;
+	*rank = c->sh.on ? (uint32_t) std::min<uint64_t>(rb / ((uint64_t) c->sh.bpr * c->B), c->sh.active - 1u) : 0u;
 	return FSEQ_OK;
 }
 
@@ -1351,8 +1746,12 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 		A.code_of_sym[i] = (uint8_t) rank;
 		c->code_to_byte[rank] = (uint8_t) alpha[i];
 	}
-	dim3 const grid((uint32_t) ((c->ld / 4 + 255) / 256), (uint32_t) std::min<uint64_t>(c->p.n, 65535));
-	hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, c->p.n, c->bsh);
+	uint64_t const k_lo = held_lo(c), k_hi = held_hi(c);     // sharded: this rank's columns only
+	if (k_hi > k_lo)
+	{
+		dim3 const grid((uint32_t) ((c->ld / 4 + 255) / 256), (uint32_t) std::min<uint64_t>(k_hi - k_lo, 65535));
+		hipLaunchKernelGGL(k_synth, grid, dim3(256), 0, c->stream, A, c->d_msa, c->ld, c->p.m, k_lo, k_hi, c->bsh);
+	}
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	c->have_input = true;
@@ -1365,6 +1764,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 int fseq_get_matrix(fseq_ctx *c, uint64_t c0, uint64_t c1, uint8_t *out, size_t row_stride, size_t col_stride)
 {
 	if (!c || !out || !c->have_input || c0 > c1 || c1 > c->p.n) return FSEQ_E_ARG;
+	if (c0 < held_lo(c) || c1 > held_hi(c)) return fail(c, FSEQ_E_ARG, "columns not held by this rank");
 	(void) hipSetDevice(c->p.device);
 	std::vector<uint8_t> buf((c1 - c0) * c->ld);
 	uint32_t const bsh = c->bsh, smask = (1u << bsh) - 1u, bits = 8u >> bsh, cmask = (1u << bits) - 1u;
@@ -1389,7 +1789,10 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 	}
 	// generate_context::calculate_segmentation, generate_context.cc:386-389
 	if (c->p.n < 2 * c->p.segment_length)
+	{
+		if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "the short path (n < 2L) is one sweep and does not shard");
 		return run_short_path(c, res);
+	}
 	return run_long_path(c, res);
 }
 
@@ -1427,8 +1830,10 @@ int fseq_boundary_state(fseq_ctx *c, uint64_t i, uint32_t *a_out, uint32_t *d_ou
 	if (!c || !c->have_result || i >= c->segments.size()) return FSEQ_E_ARG;
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m;
-	if (a_out) HIP_TRY(c, hipMemcpy(a_out, c->d_snap_a + i * m, m * 4, hipMemcpyDeviceToHost));
-	if (d_out) HIP_TRY(c, hipMemcpy(d_out, c->d_snap_d + i * m, m * 4, hipMemcpyDeviceToHost));
+	if (i >= c->snap_slot.size() || c->snap_slot[i] < 0) return fail(c, FSEQ_E_ARG, "boundary state held by another rank (fseq_shard_owner)");
+	size_t const slot = (size_t) c->snap_slot[i];
+	if (a_out) HIP_TRY(c, hipMemcpy(a_out, c->d_snap_a + slot * m, m * 4, hipMemcpyDeviceToHost));
+	if (d_out) HIP_TRY(c, hipMemcpy(d_out, c->d_snap_d + slot * m, m * 4, hipMemcpyDeviceToHost));
 	return FSEQ_OK;
 }
 
@@ -1483,6 +1888,7 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 {
 	if (!c || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
 	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
+	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use fseq_greedy_match_host");
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m, S = c->segments.size();
 	std::vector<uint32_t> A(S * m), D(S * m);
@@ -1499,6 +1905,7 @@ static int fetch_boundary_states(fseq_ctx *c, std::vector<uint32_t> &A, std::vec
 {
 	if (!c->have_result || c->res.short_path) return FSEQ_E_ARG;
 	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
+	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use the *_match_host entry points");
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m, S = c->segments.size();
 	A.resize(S * m); D.resize(S * m);

@@ -622,7 +622,9 @@ __device__ __forceinline__ void dp_push_samples(DpLds const &D, uint32_t blk, ui
 // Chunk-speculative sweeps (fseq_dpspec.hpp): the regular rounds are cut into chunks of rounds_per_chunk rounds,
 // workgroup c of the launch runs chunk c from whatever the arrays hold in front of it.
 struct DpSpecArgs {
-	uint32_t rounds_per_chunk, nchunks;
+	uint32_t const *chunk_r0;             // [nchunks + 1] first round of every chunk; chunk_r0[nchunks] = number of regular rounds
+	uint32_t nchunks;
+	uint32_t chunk0;                      // workgroup i of the launch runs chunk chunk0 + i (a rank of a sharded run owns a chunk range)
 	uint32_t fresh;                       // first sweep: nothing is known in front of a chunk (keys there count as 0)
 	uint32_t const *active;               // [nchunks] chunks to run in this sweep
 	uint32_t *ovf;                        // [nchunks] "list too short" flag of the sweep that last ran the chunk
@@ -643,8 +645,8 @@ __global__ __launch_bounds__(1024) void k_dp(
 	// of its last round before it flushes (pipelined schedule: one more iteration without cells).
 	if (MODE == DP_SPEC)
 	{
-		if (SP.ctl[0] != 0u || SP.active[blockIdx.x] == 0u) return;
-		flags = SP.ovf + blockIdx.x;
+		if (SP.ctl[0] != 0u || SP.active[blockIdx.x + SP.chunk0] == 0u) return;
+		flags = SP.ovf + blockIdx.x + SP.chunk0;
 	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	lds_char *const lds0 = (lds_char *) smem;
@@ -680,8 +682,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 	if (MODE == DP_SPEC)
 	{
 		// chunks tile the regular rounds; the last one also takes the drain round and the final cell
-		r_begin = blockIdx.x * SP.rounds_per_chunk;
-		r_end = (blockIdx.x + 1u == SP.nchunks) ? nrounds : r_begin + SP.rounds_per_chunk;
+		uint32_t const ch = blockIdx.x + SP.chunk0;
+		r_begin = SP.chunk_r0[ch];
+		r_end = (ch + 1u == SP.nchunks) ? nrounds : SP.chunk_r0[ch + 1u];
 	}
 	bool const fresh = MODE == DP_SPEC && SP.fresh != 0u && r_begin > 0u;
 	uint32_t const fresh_lo = fresh ? dp_round(S, r_begin).t0 : 0u;
@@ -699,6 +702,9 @@ __global__ __launch_bounds__(1024) void k_dp(
 		// waits for it), so the loop is kept to five instructions a load: M0 saved once, no address select
 		// while both cells of a load exist.
 		uint2 const *src = ent + (size_t) (R.e0 - 1u + (lane >> 5)) * stride + (lane & 31u) * 2u;
+		// cells the round does not have load the round's first list again (any address that is surely mapped: a rank
+		// of a sharded run holds the lists of its own columns only)
+		uint2 const *pad = ent + (size_t) (R.e0 - 1u) * stride + (lane & 31u) * 2u;
 		uint32_t dst = __builtin_amdgcn_readfirstlane(lds0_addr + off_LS + slot * DP_RL * 512u);
 		uint32_t const nfull = R.len / 2u;
 		uint32_t q = 0;
@@ -714,7 +720,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 		for (; q < npairs; ++q)
 		{
 			uint32_t const i = 2u * q + (lane >> 5);
-			dma16_m0(i < R.len ? (void const *) src : (void const *) ent, dst);
+			dma16_m0(i < R.len ? (void const *) src : (void const *) pad, dst);
 			src += 2u * (size_t) stride;
 			dst += 1024u;
 		}

@@ -31,17 +31,30 @@ struct SpecCtl {
 };
 
 struct SpecGeom {
-	uint32_t entries_per_chunk;   // rounds_per_chunk * RL
+	uint32_t const *chunk_r0;     // [nchunks + 1] first round of every chunk (device memory); [nchunks] = regular rounds
+	uint32_t RL;                  // entries per round
 	uint32_t nchunks;
 	uint32_t NR;                  // regular entries: t = 0 .. n - 2L
 	uint32_t t_final;             // n - L, the entry of the cell at rb = n
 	uint32_t win;                 // tail window
 };
 
-__device__ __forceinline__ uint32_t spec_chunk_lo(SpecGeom const &G, uint32_t c) { return c * G.entries_per_chunk; }
+__device__ __forceinline__ uint32_t spec_chunk_lo(SpecGeom const &G, uint32_t c) { return G.chunk_r0[c] * G.RL; }
 __device__ __forceinline__ uint32_t spec_chunk_hi(SpecGeom const &G, uint32_t c)
 {
-	return (c + 1u == G.nchunks) ? G.NR : (c + 1u) * G.entries_per_chunk;
+	return (c + 1u == G.nchunks) ? G.NR : G.chunk_r0[c + 1u] * G.RL;
+}
+// chunk of a regular entry: the last chunk whose first round is <= t / RL
+__device__ __forceinline__ uint32_t spec_chunk_of(SpecGeom const &G, uint32_t t)
+{
+	uint32_t const r = t / G.RL;
+	uint32_t lo = 0, hi = G.nchunks;          // chunk_r0[lo] <= r < chunk_r0[hi]
+	while (hi - lo > 1u)
+	{
+		uint32_t const mid = (lo + hi) >> 1;
+		if (G.chunk_r0[mid] <= r) lo = mid; else hi = mid;
+	}
+	return lo;
 }
 
 // A: one workgroup per chunk: did the sweep change a key of the chunk, and the minimum over its tail window
@@ -140,8 +153,7 @@ __global__ __launch_bounds__(256) void k_spec_rebuild(
 	uint32_t v = 0xFFFFFFFFu;
 	if (valid)
 	{
-		uint32_t const c = min(t / G.entries_per_chunk, G.nchunks - 1u);
-		v = max(A.M[t], lift[c]);
+		v = max(A.M[t], lift[spec_chunk_of(G, t)]);
 		A.M[t] = v;
 		Mprev[t] = v;
 	}

@@ -86,12 +86,13 @@ __device__ __forceinline__ uint32_t sym_digit(uint8_t const *col, uint32_t a, ui
 
 // one thread per 32-bit word of one column = 4 << bsh consecutive rows (coalesced stores down the column);
 // blockIdx.y strides over the columns (a launch holds fewer than 2^32 threads per dimension)
-__global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t bsh)
+// columns [c_begin, c_end) (a rank of a sharded run generates its own share), column c at msa + c * ld
+__global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t c_begin, uint64_t c_end, uint32_t bsh)
 {
 	uint32_t const words_per_col = (uint32_t) (ld / 4);
 	uint32_t const w = blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= words_per_col) return;
-	for (uint64_t c = blockIdx.y; c < n; c += gridDim.y)
+	for (uint64_t c = c_begin + blockIdx.y; c < c_end; c += gridDim.y)
 	{
 		uint32_t const spw = 4u << bsh, bits = 8u >> bsh;
 		uint32_t const r0 = w * spw;
@@ -230,8 +231,11 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
 	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
-	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d)
+	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
+	uint64_t col0)
 {
+	// MODE_RANK: workgroup i owns the block of columns starting at col0 + i * B (col0: first column of this
+	// launch -- a rank of a sharded run owns a contiguous block range); rank / keyd / nkeys are indexed by i
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// MODE_RANK keeps divergences relative to the block start (0..B: 16 bits when PK)
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint32_t t_first = 0, t_count = 0, t_next = 0;
 	if (MODE == MODE_RANK)
 	{
-		k0 = (uint64_t) blockIdx.x * B;
+		k0 = col0 + (uint64_t) blockIdx.x * B;
 		kend = (k0 + B < n) ? k0 + B : n;
 #pragma unroll
 		for (int e = 0; e < E; ++e)
@@ -398,8 +402,9 @@ __global__ __launch_bounds__(T) void k_chain(
 	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block,
 	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
 	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
-	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys)
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0)
 {
+	// workgroup i of the launch is chain grp = grp0 + i (a rank of a sharded run owns a contiguous range of chains)
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	using AT = std::conditional_t<PK, uint16_t, uint32_t>;     // row ids and ranks are < m
@@ -413,11 +418,12 @@ __global__ __launch_bounds__(T) void k_chain(
 
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = tid * E;
-	uint32_t const b0 = blockIdx.x * G;
+	uint32_t const grp = blockIdx.x + grp0;
+	uint32_t const b0 = grp * G;
 	uint32_t const b1 = min(nb_total, b0 + G);
 	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * cols_per_block);
 	{
-		size_t const sb = (size_t) blockIdx.x * m, rb = (size_t) b0 * m;
+		size_t const sb = (size_t) grp * m, rb = (size_t) b0 * m;
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
@@ -530,7 +536,7 @@ __global__ __launch_bounds__(T) void k_chain(
 		for (int e = 0; e < E; ++e) nf += (p0 + e < m && (p0 + e == 0 || d[e] > kstart)) ? 1u : 0u;
 		uint32_t total;
 		uint32_t r = block_excl_add<T>(nf, sscr, &total);
-		size_t const ob = (size_t) blockIdx.x * m;
+		size_t const ob = (size_t) grp * m;
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(T) void k_chain(
 				if (first) out_keyd[ob + r - 1u] = d[e];
 			}
 		}
-		if (tid == 0) out_nkeys[blockIdx.x] = total;
+		if (tid == 0) out_nkeys[grp] = total;
 	}
 }
 
@@ -816,13 +822,14 @@ __global__ __launch_bounds__(T) void k_columns(
 // rows; the median over the boundaries sizes the per-column lists before phase C runs (a wrong guess only
 // costs a retry, never the result).
 __global__ __launch_bounds__(256) void k_boundary_recent(
-	uint32_t const *__restrict__ bstate_d, uint32_t m, uint64_t n, uint32_t B, uint32_t L, uint32_t *__restrict__ out)
+	uint32_t const *__restrict__ bstate_d, uint32_t m, uint64_t n, uint32_t B, uint32_t L, uint32_t *__restrict__ out, uint32_t block0)
 {
-	uint64_t k = (uint64_t) blockIdx.x * B;
+	// boundary block0 + blockIdx.x (a rank of a sharded run looks at its own boundaries)
+	uint64_t k = (uint64_t) (blockIdx.x + block0) * B;
 	if (k > n) k = n;
 	if (k < L) { if (threadIdx.x == 0) out[blockIdx.x] = 0xFFFFFFFFu; return; }
 	uint32_t const thr = (uint32_t) (k - L);
-	uint32_t const *d = bstate_d + (size_t) blockIdx.x * m;
+	uint32_t const *d = bstate_d + (size_t) (blockIdx.x + block0) * m;
 	uint32_t cnt = 0;
 	for (uint32_t i = threadIdx.x; i < m; i += 256) cnt += d[i] > thr ? 1u : 0u;
 	__shared__ uint32_t red[4];
@@ -842,6 +849,67 @@ __global__ __launch_bounds__(64) void k_gather_lists(
 	if (threadIdx.x == 0) out_hdr[blockIdx.x] = h;
 	for (uint32_t i = threadIdx.x; i < h.x; i += 64)
 		out_ent[(size_t) blockIdx.x * stride + i] = ent[k * (size_t) stride + i];
+}
+
+// find_segments_greedy (segmentation_lp_context.cc:335-390) asks, traceback boundary after boundary, whether
+// unique_substring_count_lhs(current_lb) = #{d_rb > current_lb} <= max_segment_size (:363-364).  That holds exactly
+// for current_lb >= tau, tau = the value of the first list entry at which the cumulative count exceeds
+// max_segment_size -- one number per boundary, computed where the list lives (one wave per boundary; a rank of a
+// sharded run answers for the columns [col_lo, col_hi) it owns and leaves zeros elsewhere).
+//   out[j] = {tau, kind}: kind 0: merge iff current_lb >= tau (tau = 0: always);  1: the same, but the list ended
+//   (incomplete) before the count was exceeded: current_lb < tau is undecided (lists too short);  2: never (the
+//   values within L of the boundary alone exceed it).
+enum { SEG_TAU_EXACT = 0, SEG_TAU_OPEN = 1, SEG_TAU_NEVER = 2 };
+__global__ __launch_bounds__(64) void k_seg_tau(
+	uint64_t const *__restrict__ cols, uint64_t col_lo, uint64_t col_hi, uint32_t max_seg, uint32_t stride,
+	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint2 *__restrict__ out)
+{
+	uint64_t const k = cols[blockIdx.x];
+	uint32_t const lane = lane_id();
+	if (k < col_lo || k >= col_hi) { if (lane == 0) out[blockIdx.x] = make_uint2(0u, 0u); return; }
+	uint4 const h = hdr[k];
+	uint2 const *list = ent + k * (size_t) stride;
+	uint32_t cum_base = 0;
+	for (uint32_t s0 = 0; s0 < h.x; s0 += 64u)
+	{
+		uint32_t const i = s0 + lane;
+		uint2 const e = i < h.x ? list[i] : make_uint2(0u, 0u);
+		uint32_t const inc = cum_base + wave_incl_add(e.y);
+		uint64_t const over = __ballot(i < h.x && inc > max_seg);
+		if (over)
+		{
+			uint32_t const first = (uint32_t) __builtin_ctzll(over);
+			uint32_t const v = shfl_u32(e.x, (int) first);
+			if (lane == 0) out[blockIdx.x] = (s0 + first == 0u) ? make_uint2(0xFFFFFFFFu, SEG_TAU_NEVER) : make_uint2(v, SEG_TAU_EXACT);
+			return;
+		}
+		cum_base = readlane_u32(inc, 63);
+	}
+	if (lane == 0)
+		out[blockIdx.x] = h.z ? make_uint2(0u, SEG_TAU_EXACT) : make_uint2(list[h.x - 1u].x, SEG_TAU_OPEN);
+}
+
+// ... and the size of a merged segment: #{d_col+1 > lb} for (col, lb) pairs (lp.cc:363,366), same ownership rule
+__global__ __launch_bounds__(64) void k_seg_count(
+	uint64_t const *__restrict__ cols, uint64_t const *__restrict__ lbs, uint64_t col_lo, uint64_t col_hi, uint32_t stride,
+	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t *__restrict__ out)
+{
+	uint64_t const k = cols[blockIdx.x], lb = lbs[blockIdx.x];
+	uint32_t const lane = lane_id();
+	if (k < col_lo || k >= col_hi) { if (lane == 0) out[blockIdx.x] = 0u; return; }
+	uint4 const h = hdr[k];
+	uint2 const *list = ent + k * (size_t) stride;
+	uint32_t cnt = 0;
+	for (uint32_t s0 = 0; s0 < h.x; s0 += 64u)
+	{
+		uint32_t const i = s0 + lane;
+		uint2 const e = i < h.x ? list[i] : make_uint2(0u, 0u);
+		bool const in = i < h.x && (uint64_t) e.x > lb;
+		cnt += in ? e.y : 0u;
+		if (__ballot(i < h.x && !in)) break;           // values descend: nothing behind this strip counts
+	}
+	cnt = readlane_u32(wave_incl_add(cnt), 63);
+	if (lane == 0) out[blockIdx.x] = cnt;
 }
 
 } // namespace fseq

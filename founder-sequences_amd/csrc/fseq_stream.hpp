@@ -253,7 +253,8 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
 	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
-	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d)
+	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
+	uint64_t col0)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -270,7 +271,7 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	uint32_t t_first = 0, t_count = 0, t_next = 0;
 	if (MODE == MODE_RANK)
 	{
-		k0 = (uint64_t) blockIdx.x * B;
+		k0 = col0 + (uint64_t) blockIdx.x * B;
 		kend = (k0 + B < n) ? k0 + B : n;
 		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = i; buf[0][1][i] = (uint32_t) k0; }
 	}
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(ST) void k_chain_stream(
 	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t *ws, uint32_t staged,
 	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
 	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
-	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys)
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -337,13 +338,14 @@ __global__ __launch_bounds__(ST) void k_chain_stream(
 		uint32_t *w = ws + (size_t) blockIdx.x * 4u * m;
 		buf[0][0] = w; buf[0][1] = w + m; buf[1][0] = w + 2u * (size_t) m; buf[1][1] = w + 3u * (size_t) m;
 	}
-	uint32_t const b0 = blockIdx.x * G;
+	uint32_t const grp = blockIdx.x + grp0;                     // chain index (workspaces stay per workgroup)
+	uint32_t const b0 = grp * G;
 	uint32_t const b1 = min(nb_total, b0 + G);
 	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * cols_per_block);
 	for (uint32_t i = tid; i < m; i += ST)
 	{
-		buf[0][0][i] = start_a ? start_a[(size_t) blockIdx.x * m + i] : i;
-		buf[0][1][i] = start_d ? start_d[(size_t) blockIdx.x * m + i] : kstart;
+		buf[0][0][i] = start_a ? start_a[(size_t) grp * m + i] : i;
+		buf[0][1][i] = start_d ? start_d[(size_t) grp * m + i] : kstart;
 	}
 	__syncthreads();
 	uint32_t cur = 0;
@@ -370,8 +372,8 @@ __global__ __launch_bounds__(ST) void k_chain_stream(
 	if (out_state_a && b1 == nb_total)
 		for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) nb_total * m + i] = buf[cur][0][i]; out_state_d[(size_t) nb_total * m + i] = buf[cur][1][i]; }
 	if (out_rank)
-		stream_emit_ranks(m, buf[cur][0], buf[cur][1], kstart, out_rank + (size_t) blockIdx.x * m, out_keyd + (size_t) blockIdx.x * m,
-		                  out_nkeys + blockIdx.x, L);
+		stream_emit_ranks(m, buf[cur][0], buf[cur][1], kstart, out_rank + (size_t) grp * m, out_keyd + (size_t) grp * m,
+		                  out_nkeys + grp, L);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,11 +1,93 @@
-"""Launcher-side logic for N > 1: one process per GPU, independent alignments per rank.
+"""Launcher-side logic for N > 1: one process per GPU.
 
-The segmentation of one alignment is a chain of n/L dependent DP rounds and does not shard; what
-shards with no data-path collective is the set of alignments.  This module
-holds the pieces bench.py shares with the CPU (gloo) test: rank -> work assignment, the barrier +
-max-over-ranks timing bracket, and the aggregate throughput."""
+ONE alignment over the ranks: rank r owns a contiguous range of column blocks; the
+library (fseq_set_shard, include/fseq.h) asks for a handful of small all-reduces per step through one callback.
+ShardTransport is that callback over torch.distributed: RCCL (backend "nccl") on the exchange tensor when every
+rank has its own GPU, or gloo through a pinned host copy when ranks share a card (rehearsals on one GPU, tests).
+Also here: the pieces bench.py shares with the CPU (gloo) tests -- rank -> work assignment, the barrier +
+max-over-ranks timing bracket, the aggregate throughput."""
 import os
 import time
+
+
+class ShardTransport:
+    """The exchange buffer of a sharded context and its all-reduce (fseq_allreduce_fn)."""
+
+    def __init__(self, words, device, dist=None, via_host=False):
+        import torch
+        self.torch = torch
+        self.dist = dist
+        self.via_host = via_host
+        self.buf = torch.zeros(int(words), dtype=torch.int32, device=device)      # uint32 words; sums of one non-zero
+        self.words = int(words)                                                    # contribution and maxima of small values
+        self.calls = 0                                                             # are the same in int32
+        self.words_moved = 0
+        self._host = None
+
+    @property
+    def ptr(self):
+        return self.buf.data_ptr()
+
+    def allreduce(self, offset, count, op):
+        torch, dist = self.torch, self.dist
+        self.calls += 1
+        self.words_moved += count
+        if dist is None or count == 0:
+            return 0
+        view = self.buf[offset:offset + count]
+        rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        if self.via_host:
+            h = view.cpu()
+            dist.all_reduce(h, op=rop)
+            view.copy_(h)
+        else:
+            dist.all_reduce(view, op=rop)
+        torch.cuda.synchronize(self.buf.device)
+        return 0
+
+
+class ThreadWorld:
+    """W ranks as W threads of one process on one GPU (tests): the all-reduce is a barrier, a reduction by rank 0
+    over the ranks' exchange tensors, and a second barrier.  ctypes releases the GIL around the library call and
+    takes it again for the callback, so the ranks really run side by side."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.bufs = [None] * world
+
+    def attach(self, ctx, rank, device):
+        tr = ShardTransport(ctx.shard_xbuf_words(self.world), device, None)
+        self.bufs[rank] = tr.buf
+        torch = tr.torch
+
+        def allreduce(offset, count, op, self=self, tr=tr, rank=rank):
+            tr.calls += 1
+            tr.words_moved += count
+            self.barrier.wait()
+            if rank == 0:
+                views = [b[offset:offset + count] for b in self.bufs]
+                acc = views[0].clone()
+                for v in views[1:]:
+                    acc = acc + v if op == 0 else torch.maximum(acc, v)
+                for v in views:
+                    v.copy_(acc)
+                torch.cuda.synchronize(tr.buf.device)
+            self.barrier.wait()
+            return 0
+
+        ctx.set_shard(rank, self.world, tr.ptr, tr.words, allreduce)
+        ctx._transport = tr
+        return tr
+
+
+def shard_context(ctx, rank, world, dist, device, via_host=False):
+    """Makes ctx one rank of a sharded run; returns the transport (keep it alive with the context)."""
+    tr = ShardTransport(ctx.shard_xbuf_words(world), device, dist if world > 1 else None, via_host)
+    ctx.set_shard(rank, world, tr.ptr, tr.words, tr.allreduce)
+    ctx._transport = tr
+    return tr
 
 
 def env_rank():

@@ -125,6 +125,33 @@ int  fseq_generate_synthetic(fseq_ctx *ctx, fseq_synth_spec const *spec);
 /* Copy columns [c0,c1) back as raw bytes, out[r*row_stride + (c-c0)*col_stride] (tests, writers). */
 int  fseq_get_matrix(fseq_ctx *ctx, uint64_t c0, uint64_t c1, uint8_t *out, size_t row_stride, size_t col_stride);
 
+/* ---- one alignment over several GPUs (one process per GPU) ----
+ * replaces: the reference's only parallel axis for this path, independent update_pbwt_task's over column ranges
+ * on the global concurrent queue (segmentation_lp_context.cc:319-332, update_pbwt_task.cc:13-35), extended to
+ * pass 1: rank r of `world` owns a contiguous range of column blocks -- its share of the alignment, of phases A
+ * and C, of the DP chunks and of pass 2.  The exchange steps (the W composite key blocks of phase B, the DP keys
+ * after every sweep, the merge thresholds: a few MB in all) go through ONE caller-supplied all-reduce over a
+ * caller-owned device buffer; a C++ host passes a function that calls ncclAllReduce on it, the Python mirror one
+ * that calls torch.distributed.all_reduce (RCCL) on the tensor that owns the buffer.
+ *   fn(user, offset_words, count_words, op): all-reduce xbuf[offset .. offset + count) (uint32 words; op 0 = sum,
+ *   1 = max) over all ranks, IN PLACE, and return 0 once the result is visible to work submitted afterwards on
+ *   any stream of this device (the library has synchronised its own stream before the call).
+ * Call before the input is set (each rank then generates / uploads / borrows only its own columns; borrowed
+ * device columns hold the columns [first, last) fseq_shard_columns reports, column `first` at the base pointer).
+ * Every rank must make the same calls in the same order; results (fseq_result, traceback, segments, timings)
+ * are identical on all ranks, fseq_boundary_state(i) answers on the rank that owns segments[i].rb
+ * (fseq_shard_owner) and returns FSEQ_E_ARG elsewhere. */
+typedef int (*fseq_allreduce_fn)(void *user, uint64_t offset_words, uint64_t count_words, int op);
+/* device words (uint32) the exchange buffer must hold for this context's shape on `world` ranks */
+uint64_t fseq_shard_xbuf_words(fseq_ctx const *ctx, uint32_t world);
+int  fseq_set_shard(fseq_ctx *ctx, uint32_t rank, uint32_t world, void *xbuf_device, uint64_t xbuf_words,
+                    fseq_allreduce_fn fn, void *user);
+/* columns [*first, *last) this rank holds (its block range plus the few columns of the next rank that its last
+ * DP round reads) */
+int  fseq_shard_columns(fseq_ctx const *ctx, uint64_t *first, uint64_t *last);
+/* rank that owns the boundary state at column rb */
+int  fseq_shard_owner(fseq_ctx const *ctx, uint64_t rb, uint32_t *rank);
+
 /* replaces: generate_traceback + update_samples_to_traceback_positions + find_segments_greedy
  * (segmentation_lp_context.cc:26-390) or segmentation_sp_context::process
  * (segmentation_sp_context.cc:21-28) when n < 2L.  Returns FSEQ_E_NO_REDUCTION exactly when the

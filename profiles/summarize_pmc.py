@@ -1,65 +1,110 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 outputs of profiles/collect_profiles.sh into the committed summaries:
 
-    python profiles/summarize_pmc.py gpurun_out/prof_<tag> r01_<tag>
+    python profiles/summarize_pmc.py gpurun_out/prof_<tag> r02_<tag> <workload> [steps+warmup]
 
-writes profiles/r01_<tag>_kernel_stats.csv, _pmc_fetch_size.csv, _pmc_write_size.csv, _bench.json and
-_pmc_traffic.json (average HBM bytes per launch and kernel: FETCH_SIZE and WRITE_SIZE are in KiB; on
-gfx950 FETCH_SIZE counts half of a wide coalesced read stream -- MI355X_MICROARCH.md, HBM section --
-so reads are doubled; calibrated on k_synth / k_colblock<MODE_RANK>, whose traffic is known)."""
+writes profiles/<prefix>_kernel_stats_<workload>.csv, _pmc_*.csv (per-kernel averages of every counter pass
+found), _bench_<workload>.json and _pmc_traffic_<workload>.json: HBM bytes per launch and kernel, and per step
+and phase (FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half of a wide coalesced read
+stream -- MI355X_MICROARCH.md, HBM section -- so reads are doubled; calibrated in round 1 on k_synth /
+k_colblock<MODE_RANK>, whose traffic is known).  The JSON records the hash of the kernel sources it was taken
+on; bench.py quotes it only while that hash matches."""
 import csv
 import glob
 import json
 import os
+import re
 import shutil
 import sys
 
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
 
-def one(pattern):
-    hits = sorted(glob.glob(pattern, recursive=True))
-    if not hits:
-        raise SystemExit("no file matches " + pattern)
-    return hits[0]
+
+def find(pattern):
+    return sorted(glob.glob(pattern, recursive=True))
 
 
 def per_kernel(path):
+    """{kernel: {counter: (sum, launches)}} from a rocprofv3 counter_collection.csv"""
     acc = {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"].split("(")[0]
-            a = acc.setdefault(name, [0.0, 0])
+            a = acc.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0])
             a[0] += float(row["Counter_Value"])
             a[1] += 1
-    return {k: v[0] / v[1] for k, v in acc.items()}
+    return acc
+
+
+def phase_of(name):
+    mo = re.search(r"k_colblock<[^>]*?,\s*(\d),\s*(true|false)>", name) or re.search(r"k_colblock_stream<(\d)>", name)
+    if mo:
+        return "phase_a" if mo.group(1) == "0" else "pass_2"
+    if "k_chain" in name or "k_boundary_recent" in name:
+        return "phase_b"
+    if "k_columns" in name:
+        return "phase_c"
+    if "k_dp<" in name or "k_spec_" in name:
+        return "phase_d"
+    if "k_gather" in name or "k_seg_" in name or "copyBuffer" in name or "fillBuffer" in name:
+        return "host"
+    return None
 
 
 def main():
-    src, tag = sys.argv[1], sys.argv[2]
-    here = os.path.dirname(os.path.abspath(__file__))
-    stats = one(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
-    fetch = one(os.path.join(src, "fetch", "**", "*counter_collection.csv"))
-    write = one(os.path.join(src, "write", "**", "*counter_collection.csv"))
-    shutil.copy(stats, os.path.join(here, tag + "_kernel_stats.csv"))
-    shutil.copy(fetch, os.path.join(here, tag + "_pmc_fetch_size.csv"))
-    shutil.copy(write, os.path.join(here, tag + "_pmc_write_size.csv"))
-    shutil.copy(os.path.join(src, "bench.json"), os.path.join(here, tag + "_bench.json"))
-    fk, wk = per_kernel(fetch), per_kernel(write)
-    kernels = {}
-    for name in fk:
-        kernels[name] = {
-            "FETCH_SIZE_KiB_avg_per_launch": fk[name],
-            "WRITE_SIZE_KiB_avg_per_launch": wk.get(name, 0.0),
-            "hbm_bytes_per_launch_corrected": (2.0 * fk[name] + wk.get(name, 0.0)) * 1024.0,
+    src, prefix, workload = sys.argv[1], sys.argv[2], sys.argv[3]
+    nsteps = int(sys.argv[4]) if len(sys.argv) > 4 else 7
+    import bench
+    stats = find(os.path.join(src, "trace", "**", "*kernel_stats.csv"))
+    if stats:
+        shutil.copy(stats[0], os.path.join(HERE, "%s_kernel_stats_%s.csv" % (prefix, workload)))
+    if os.path.exists(os.path.join(src, "bench.json")):
+        shutil.copy(os.path.join(src, "bench.json"), os.path.join(HERE, "%s_bench_%s.json" % (prefix, workload)))
+    counters = {}
+    for d in sorted(os.listdir(src)):
+        for path in find(os.path.join(src, d, "**", "*counter_collection.csv")):
+            for k, cs in per_kernel(path).items():
+                for cname, (tot, cnt) in cs.items():
+                    counters.setdefault(k, {})[cname] = {"sum": tot, "launches": cnt, "avg_per_launch": tot / cnt}
+    # flat csv of every counter
+    with open(os.path.join(HERE, "%s_pmc_counters_%s.csv" % (prefix, workload)), "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(["kernel", "counter", "launches", "avg_per_launch", "sum"])
+        for k in sorted(counters):
+            for cname in sorted(counters[k]):
+                c = counters[k][cname]
+                wr.writerow([k, cname, c["launches"], "%.6g" % c["avg_per_launch"], "%.6g" % c["sum"]])
+    kernels, phases = {}, {}
+    for k, cs in counters.items():
+        if "FETCH_SIZE" not in cs and "WRITE_SIZE" not in cs:
+            continue
+        f_ = cs.get("FETCH_SIZE", {"sum": 0.0, "launches": 1, "avg_per_launch": 0.0})
+        w_ = cs.get("WRITE_SIZE", {"sum": 0.0, "launches": 1, "avg_per_launch": 0.0})
+        per_step = (2.0 * f_["sum"] + w_["sum"]) * 1024.0 / nsteps
+        kernels[k] = {
+            "launches_per_step": max(f_["launches"], w_["launches"]) / nsteps,
+            "FETCH_SIZE_KiB_avg_per_launch": f_["avg_per_launch"],
+            "WRITE_SIZE_KiB_avg_per_launch": w_["avg_per_launch"],
+            "hbm_bytes_per_launch_corrected": (2.0 * f_["avg_per_launch"] + w_["avg_per_launch"]) * 1024.0,
+            "hbm_bytes_per_step_corrected": per_step,
+            "phase": phase_of(k),
         }
+        if phase_of(k):
+            phases[phase_of(k)] = phases.get(phase_of(k), 0.0) + per_step
     out = {
-        "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline "
-                   "--no-batched (one pass per counter, profiles/collect_profiles.sh); workload C2 m=2500 n=100000",
+        "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload %s --steps 5 --warmup 2 "
+                   "--no-cpu-baseline --no-batched (one pass per counter set, profiles/collect_profiles.sh)" % workload,
+        "workload": workload,
+        "steps_profiled": nsteps,
+        "csrc_sha": bench.csrc_sha(),
         "units": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x2 on gfx950 (wide coalesced reads are under-counted by half)",
+        "phases_hbm_bytes_per_step": phases,
         "kernels": kernels,
     }
-    with open(os.path.join(here, tag + "_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(HERE, "%s_pmc_traffic_%s.json" % (prefix, workload)), "w") as f:
         json.dump(out, f, indent=1)
-    print(json.dumps({k: round(v["hbm_bytes_per_launch_corrected"] / 1e6, 2) for k, v in kernels.items()}, indent=1))
+    print(json.dumps({k: round(v / 1e6, 2) for k, v in phases.items()}, indent=1))
 
 
 if __name__ == "__main__":
