@@ -12,8 +12,9 @@ BASELINE.json labels 1xMI355X (C2 is too small for a roofline fraction to mean a
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1 (this round): every rank segments its own alignment of the same shape (different seed), no
-data-path collective -> "scaling": "weak"; value = all ranks' cells / max-over-ranks time.
+N > 1: ONE alignment (BASELINE.json configs[3], C4: m=100,000 x n=5,000,000, L=200) sharded over the ranks by
+contiguous column blocks (fseq_set_shard; exchanges through torch.distributed / RCCL, founder-sequences_amd/dist.py)
+-> "scaling": "strong"; value = the alignment's cells / max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -117,7 +118,8 @@ def main():
     ap.add_argument("--list-cap", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--no-batched", action="store_true", help="skip the secondary 4-alignments-in-flight measurement")
+    ap.add_argument("--no-batched", action="store_true", help="(default) skip the secondary 8-alignments-in-flight measurement")
+    ap.add_argument("--batched", action="store_true", help="also measure 8 alignments in flight on the one GPU (secondary figure)")
     ap.add_argument("--concurrent", type=int, default=1,
                     help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
     args = ap.parse_args()
@@ -148,17 +150,20 @@ def main():
     pkg = importlib.import_module("founder-sequences_amd")
     fdist = importlib.import_module("founder-sequences_amd.dist")
     if args.workload is None:
-        args.workload = "C3"
+        args.workload = "C3" if world == 1 else "C4"
     w = dict(WORKLOADS[args.workload])
     m, n, L = w["m"], w["n"], w["L"]
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
-    # one alignment per rank (alignment id = rank), generated on the device
-    ctx.generate_synthetic(fdist.seed_for_alignment(w["seed"], rank), w["K"], w["B"], w["mu"], w["kind"])
+    transport = None
+    if world > 1:
+        # ONE alignment over the ranks: this rank generates and keeps its own column blocks only
+        transport = fdist.shard_context(ctx, rank, world, dist, torch.device("cuda", local_rank), via_host=rehearsal)
+    ctx.generate_synthetic(w["seed"], w["K"], w["B"], w["mu"], w["kind"])
     # optional: more alignments in flight on the same GPU (the DP of one alignment occupies one CU)
     extra = []
     for j in range(1, max(1, args.concurrent)):
         e = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
-        e.generate_synthetic(fdist.seed_for_alignment(w["seed"], world * j + rank), w["K"], w["B"], w["mu"], w["kind"])
+        e.generate_synthetic(fdist.seed_for_alignment(w["seed"], j), w["K"], w["B"], w["mu"], w["kind"])
         extra.append(e)
 
     phase = {}
@@ -223,21 +228,26 @@ def main():
     ms_c = ph["ms_phase_c"]
     out = {
         "metric": "alignment cells/s (m*n/T) through pBWT+DP",
-        "value": world * max(1, args.concurrent) * m * n * steps / dt,
+        "value": max(1, args.concurrent) * m * n * steps / dt,
         "unit": "cells/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": step_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if world > 1 else "weak",
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
         "config": {
             "workload": "%s: m=%d x n=%d synthetic founder-mosaic DNA (sigma=%d), segment-length-bound L=%d, "
-                        "input resident in HBM column-major, %d bits per cell; per rank one alignment"
-                        % (args.workload, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2),
+                        "input resident in HBM column-major, %d bits per cell; %s"
+                        % (args.workload, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2,
+                           "one alignment on one GPU" if world == 1 else
+                           "ONE alignment sharded over %d ranks by contiguous column blocks (each rank holds its own columns)" % world),
+            "parallelism": "1 GPU" if world == 1 else "column-block shards x%d: phase A/C/pass 2 and the DP chunks local, %d all-reduces (%.1f MB) per step over %s"
+                           % (world, transport.calls // max(1, args.steps + args.warmup), transport.words_moved * 4 / max(1, args.steps + args.warmup) / 1e6,
+                              "gloo via host (rehearsal: ranks share a GPU)" if rehearsal else "RCCL"),
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "dp_chunks": t["dp_chunks"], "dp_sweeps": t["dp_sweeps"],
@@ -272,7 +282,7 @@ def main():
     }
     # secondary figure (not `value`): the DP of one alignment occupies one CU for ~2/3 of a step, so
     # several alignments (chromosomes) in flight share the chip; measured with 8 contexts / host threads
-    if world == 1 and args.concurrent == 1 and not args.no_batched:
+    if world == 1 and args.concurrent == 1 and args.batched:
         import threading
         others = []
         for j in range(1, 8):

@@ -316,13 +316,27 @@ void block_geometry(fseq_ctx *c)
 	bool const streamed = p.m > 11264u;
 	Shard &sh = c->sh;
 	if (p.block_len) c->B = p.block_len;
-	else
+	else if (!sh.on)
 	{
-		// LDS-resident kernels: ~1024 blocks per GPU; streamed kernels ~256 (auto_block_len)
-		uint64_t const target = (streamed ? 256u : 1024u) * (uint64_t) (sh.on ? sh.world : 1u);
+		// LDS-resident kernels: ~1024 blocks (2-4 workgroups per CU).  Streamed kernels stage a whole column
+		// in LDS (one workgroup per CU) and pay the phase-B chain per block and per row: ~256 blocks.
+		uint64_t const target = streamed ? 256u : 1024u;
 		uint64_t b = (p.n + target - 1) / target;
 		if (b < 16) b = 16;
 		if (b > 4096) b = 4096;
+		c->B = (uint32_t) b;
+	}
+	else
+	{
+		// sharded: the same per rank, and -- streamed kernels are one workgroup per CU -- a whole number of waves of
+		// workgroups per rank (256 CUs x k blocks of <= 4096 columns), so that no rank ends on a nearly empty wave
+		int ncu = 0;
+		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
+		if (ncu < 1) ncu = 256;
+		uint64_t const cols = (p.n + sh.world - 1) / sh.world;
+		uint64_t per = streamed ? (uint64_t) ncu * ((cols + (uint64_t) ncu * 4096 - 1) / ((uint64_t) ncu * 4096)) : 1024u;
+		uint64_t b = (p.n + per * sh.world - 1) / (per * sh.world);
+		if (b < 16) b = 16;
 		c->B = (uint32_t) b;
 	}
 	// sharded: the DP round that starts on a rank's last column reads the lists of the RL - 1 columns behind it; the
@@ -340,6 +354,10 @@ void block_geometry(fseq_ctx *c)
 		uint32_t const per = (c->nblocks + sh.world - 1) / sh.world;
 		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) per));
 		if (g < 1) g = 1;
+		// a rank is G2 super-blocks of G blocks: G x G2 = per exactly when per has a divisor near its root (the block
+		// counts chosen above do), else the next product above it (the last ranks then own fewer blocks)
+		for (uint32_t t = g; t >= 1 && 2 * t >= g; --t)
+			if (per % t == 0) { g = t; break; }
 		uint32_t const g2 = (per + g - 1) / g;
 		c->chain_G = g; c->chain_G2 = g2;
 		sh.bpr = g * g2;

@@ -1,0 +1,364 @@
+"""Pure-Python model of the two things round 2 added on top of tests/proto_blocks.py (same role: TEST
+INFRASTRUCTURE that states the device / host algorithm readably so that the CPU suite can prove it against the
+oracle; the product never imports it):
+
+* the chunk-speculative DP (founder-sequences_amd/csrc/fseq_dpspec.hpp): fresh chunk sweeps, the (min,max)-linear
+  floor lift, verify sweeps until no key changes;
+* ONE alignment over several ranks (fseq_set_shard, csrc/fseq_api.hip run_long_path): contiguous column-block
+  shares, the hyper key block exchange of phase B, the per-sweep key exchange of the DP, the merge by
+  per-boundary thresholds (k_seg_tau), pass 2 on the owners.  Every exchange goes through ONE callback
+  allreduce(np.int64 array, op) -> array, exactly the primitive the library asks its caller for.
+"""
+import math
+
+import numpy as np
+
+import proto_blocks as pb
+
+U32MAX = pb.U32MAX
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DP schedule (fseq_dp.hpp dp_schedule / dp_round)
+# ---------------------------------------------------------------------------------------------------------
+def dp_schedule(L, n):
+    pipe = L >= 96
+    half = min(L // 2, 48)
+    RL = (half // 12) * 12 if pipe else min(L, 56)
+    nreg = ((n - L) - L) // RL + 1
+    return dict(L=L, n=n, RL=RL, nreg=nreg, pipe=pipe)
+
+
+def chunk_plan(S, ranks_cols, rank, ncu=4, min_entries=None, forced=0):
+    """spec_plan(): first round of every chunk (+ the end), and this rank's chunk range.  ranks_cols: list of
+    (c_lo, c_hi) per active rank (one entry (0, n) when not sharded).  A round belongs to the rank that owns its
+    first column L + r RL - 1; the last rank takes the rest."""
+    L, RL, nreg, n = S["L"], S["RL"], S["nreg"], S["n"]
+    if min_entries is None:
+        min_entries = max(1024, 8 * L)
+    r0, mine = [], (0, 0)
+    prev = 0
+    for g, (_, c_hi) in enumerate(ranks_cols):
+        r_hi = nreg
+        if g + 1 < len(ranks_cols):
+            need = max(0, c_hi + 1 - L)
+            r_hi = min(nreg, (need + RL - 1) // RL)
+        r_hi = max(r_hi, prev)
+        lo_idx = len(r0)
+        if r_hi > prev:
+            rpc = forced or max((r_hi - prev + ncu - 1) // ncu, (min_entries + RL - 1) // RL)
+            r0.extend(range(prev, r_hi, rpc))
+        if g == rank:
+            mine = (lo_idx, len(r0))
+        prev = r_hi
+    r0.append(nreg)
+    return r0, mine
+
+
+# ---------------------------------------------------------------------------------------------------------
+# rmq state rebuilt from the keys in closed form (k_spec_rebuild + k_spec_table)
+# ---------------------------------------------------------------------------------------------------------
+def rmq_from_keys(M, count, size):
+    """DeviceRmq holding entries [0, count) of M, built as the rebuild kernels do: masks per 64-block, level 0 =
+    first block minimum, level p at j = first strict minimum over the blocks j + 2^q - 1, q = 0..p."""
+    r = pb.DeviceRmq(size)
+    r.M[:count] = M[:count]
+    for t in range(count):
+        base = t - (t % 64)
+        mask, runmin = 1 << (t - base), M[t]
+        for p in range(t - 1, base - 1, -1):
+            if M[p] <= runmin:
+                mask |= 1 << (p - base)
+            runmin = min(runmin, M[p])
+        r.K[t] = mask
+    nb = count // 64
+    bm = [b * 64 + int(np.argmin(M[b * 64:b * 64 + 64])) for b in range(nb)]
+    r.T = [list(bm)]
+    p = 1
+    while (1 << p) <= nb:
+        lvl = []
+        for j in range(nb - (1 << p) + 1):
+            prev = r.T[p - 1][j]
+            new = bm[j + (1 << p) - 1]
+            lvl.append(new if M[new] < M[prev] else prev)
+        r.T.append(lvl)
+        p += 1
+    r.filled = count
+    return r
+
+
+class FreshRmq:
+    """Sweep 1 of a chunk: nothing is known in front of entry t0 -- a range that reaches there holds a key 0."""
+
+    def __init__(self, inner, t0):
+        self.inner, self.t0, self.M = inner, t0, inner.M
+
+    def query(self, beg, end):
+        if beg < self.t0:
+            return beg
+        return self.inner.query(beg, end)
+
+
+def run_chunk(lists, M, LB, SZ, S, m, r_begin, r_end, last, fresh):
+    """k_dp<DP_SPEC> for one chunk: rounds [r_begin, r_end) (+ the final cell when `last`) from the arrays as they
+    stand; writes the chunk's entries of M / LB / SZ.  Returns overflow."""
+    L, n, RL = S["L"], S["n"], S["RL"]
+    size = n - L + 1
+    t0 = r_begin * RL
+    t1 = min(r_end * RL, n - 2 * L + 1)
+    if fresh and r_begin > 0:
+        Mz = M.copy()
+        Mz[:t0] = 0
+        rmq = rmq_from_keys(Mz, t0, size)
+        q = FreshRmq(rmq, t0)
+    else:
+        rmq = rmq_from_keys(M, t0, size)
+        q = rmq
+    p2lim = min(2 * L, n - L) - 1
+    overflow = False
+    for t in range(t0, t1):
+        end = t + L
+        rec = lists[end - 1]
+        if end <= p2lim:
+            lb, mx, sz = 0, m - rec["cnt0"], m - rec["cnt0"]
+        else:
+            lb, mx, sz, ov = pb.dp_from_list(rec, q, LB, m, L, end)
+            overflow |= ov
+        M[t], LB[t], SZ[t] = mx, lb, sz
+        rmq.append(t, mx)
+    if last:
+        lb, mx, sz, ov = pb.dp_from_list(lists[n - 1], q, LB, m, L, n)
+        overflow |= ov
+        M[n - L], LB[n - L], SZ[n - L] = mx, lb, sz
+    return overflow
+
+
+def speculative_dp(lists, S, m, r0, mine, exchange=None, win=None, stats=None):
+    """The iteration of fseq_dpspec.hpp / run_dp_spec.  lists[k]: list of column k (only this rank's columns need
+    to be there).  exchange(array, lo, hi, extra) -> array gathers every rank's own slice (None: one rank)."""
+    L, n, RL = S["L"], S["n"], S["RL"]
+    size = n - L + 1
+    NR = n - 2 * L + 1
+    nch = len(r0) - 1
+    if win is None:
+        win = max(256, 4 * L)
+    M = np.zeros(size, dtype=np.int64)
+    LB = np.zeros(size, dtype=np.int64)
+    SZ = np.zeros(size, dtype=np.int64)
+    lo = lambda c: r0[c] * RL
+    hi = lambda c: NR if c + 1 == nch else r0[c + 1] * RL
+    t_lo, t_hi = (lo(mine[0]), hi(mine[1] - 1)) if mine[1] > mine[0] else (0, 0)
+    extra = (n - L) if (mine[1] == nch and mine[1] > mine[0]) else None
+    active = [True] * nch
+    floor_ = [0] * nch
+    ovf = [False] * nch
+    Mprev = M.copy()
+    sweeps = 0
+    while True:
+        fresh = sweeps == 0
+        for c in range(mine[0], mine[1]):
+            if active[c]:
+                ovf[c] = run_chunk(lists, M, LB, SZ, S, m, r0[c], r0[c + 1], c + 1 == nch, fresh)
+        sweeps += 1
+        if exchange is not None:
+            M = exchange(M, t_lo, t_hi, extra)
+        # k_spec_scan + k_spec_decide
+        changed = [active[c] and (not np.array_equal(M[lo(c):hi(c)], Mprev[lo(c):hi(c)]) or
+                                  (c + 1 == nch and M[n - L] != Mprev[n - L])) for c in range(nch)]
+        tailmin = [int(M[max(lo(c), hi(c) - win):hi(c)].min()) for c in range(nch)]
+        first = 0 if fresh else next((c for c in range(nch) if changed[c]), None)
+        if first is None:
+            break
+        G = 0
+        for c in range(nch):
+            dirty = c > first
+            if dirty and G > floor_[c]:
+                M[lo(c):hi(c)] = np.maximum(M[lo(c):hi(c)], G)      # k_spec_rebuild applies the lift
+                floor_[c] = G
+            active[c] = dirty
+            G = max(G, tailmin[c])
+        Mprev = M.copy()
+        assert sweeps <= nch + 2, "the iteration must end: after sweep k the chunks 0..k-1 are exact"
+    if exchange is not None:
+        LB = exchange(LB, t_lo, t_hi, extra)
+        SZ = exchange(SZ, t_lo, t_hi, extra)
+    if stats is not None:
+        stats["sweeps"] = sweeps
+    return M, LB, SZ, any(ovf[mine[0]:mine[1]])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# merge by thresholds (k_seg_tau / k_seg_count + the host walk in run_long_path)
+# ---------------------------------------------------------------------------------------------------------
+TAU_EXACT, TAU_OPEN, TAU_NEVER = 0, 1, 2
+
+
+def seg_tau(rec, max_seg):
+    cum = 0
+    for i, (v, c) in enumerate(zip(rec["vals"], rec["cnts"])):
+        cum += c
+        if cum > max_seg:
+            return (U32MAX, TAU_NEVER) if i == 0 else (v, TAU_EXACT)
+    return (0, TAU_EXACT) if rec["complete"] else (rec["vals"][-1], TAU_OPEN)
+
+
+def seg_count(rec, lb):
+    return sum(c for v, c in zip(rec["vals"], rec["cnts"]) if v > lb)
+
+
+def merge_by_thresholds(tb, max_seg, tau, count_of):
+    """tb: traceback [(lb, rb, max, size)]; tau[j] = (value, kind) of boundary j; count_of(queries) -> counts for
+    [(col, lb)].  Returns (reduced [(lb, rb, size)], overflow)."""
+    red, ask = [], []
+    cur_lb, prev_size, pending, prev = 0, tb[0][3], False, 0
+
+    def emit():
+        if pending:
+            ask.append((len(red), tb[prev][1] - 1, cur_lb))
+        red.append([cur_lb, tb[prev][1], prev_size])
+
+    for j in range(1, len(tb)):
+        v, kind = tau[j]
+        fits = kind != TAU_NEVER and cur_lb >= v
+        if not fits and kind == TAU_OPEN:
+            return None, True
+        if fits:
+            pending = True
+        else:
+            emit()
+            prev_size, pending, cur_lb = tb[j][3], False, tb[prev][1]
+        prev = j
+    emit()
+    if ask:
+        for (seg, _, _), cnt in zip(ask, count_of([(col, lb) for _, col, lb in ask])):
+            red[seg][2] = cnt
+    return [tuple(r) for r in red], False
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the sharded run (block_geometry + run_long_path with sh.on)
+# ---------------------------------------------------------------------------------------------------------
+def shard_geometry(n, L, B, world, rank):
+    S = dp_schedule(L, n)
+    B = min(max(B, S["RL"]), n)
+    nblocks = (n + B - 1) // B
+    per = (nblocks + world - 1) // world
+    g = max(1, math.ceil(math.sqrt(per)))
+    g2 = (per + g - 1) // g
+    bpr = g * g2
+    active = (nblocks + bpr - 1) // bpr
+    b_lo, b_hi = min(nblocks, rank * bpr), min(nblocks, (rank + 1) * bpr)
+    c_lo, c_hi = min(n, b_lo * B), min(n, b_hi * B)
+    c_end = min(n, c_hi + S["RL"]) if b_hi > b_lo else c_hi
+    cols = [(min(n, r * bpr * B), min(n, (r + 1) * bpr * B)) for r in range(active)]
+    return dict(S=S, B=B, nblocks=nblocks, bpr=bpr, active=active, b_lo=b_lo, b_hi=b_hi, c_lo=c_lo, c_hi=c_hi, c_end=c_end, cols=cols)
+
+
+def compose(m, kstart, key_blocks, digit_bits=2):
+    """k_chain from the identity over consecutive key blocks -> their composite key block (rank, keyd, D)."""
+    a = np.arange(m, dtype=np.int64)
+    d = np.full(m, kstart, dtype=np.int64)
+    for rank, keyd, D in key_blocks:
+        a, d = pb.phase_b_step(a, d, rank, keyd, D, digit_bits)
+    first = np.ones(m, dtype=bool)
+    first[1:] = d[1:] > kstart
+    rk = np.empty(m, dtype=np.int64)
+    rk[a] = np.cumsum(first) - 1
+    return rk, d[first], int(first.sum())
+
+
+def segment_sharded(codes, L, B, X, rank, world, allreduce, forced_rounds=0, stats=None):
+    """One rank's view of the sharded long path.  codes: the whole [m, n] matrix of dense symbols (the model only
+    READS this rank's columns [c_lo, c_end)); allreduce(np.int64 array, op) with op 0 = sum, 1 = max."""
+    m, n = codes.shape
+    G = shard_geometry(n, L, B, world, rank)
+    S, B = G["S"], G["B"]
+    held = np.zeros_like(codes)
+    held[:, G["c_lo"]:G["c_end"]] = codes[:, G["c_lo"]:G["c_end"]]
+    codes = held                                            # anything outside my share reads as garbage-free zeros
+    have = rank < G["active"]
+    blocks = [(b * B, min(B, n - b * B)) for b in range(G["b_lo"], G["b_hi"])]
+    keyb = [pb.phase_a(codes, k0, nb) for k0, nb in blocks]
+    # phase B: my hyper key block, exchanged; the W hyper blocks chained by everybody; my blocks expanded
+    NH = G["active"]
+    slot = np.zeros((NH, 2 * m + 1), dtype=np.int64)
+    if have:
+        rk, kd, D = compose(m, G["c_lo"], keyb)
+        slot[rank, :m], slot[rank, m:m + D], slot[rank, 2 * m] = rk, kd, D
+    slot = allreduce(slot.reshape(-1), 0).reshape(NH, 2 * m + 1)
+    a, d = np.arange(m, dtype=np.int64), np.zeros(m, dtype=np.int64)
+    hstate = []
+    for h in range(NH):
+        hstate.append((a, d))
+        D = int(slot[h, 2 * m])
+        a, d = pb.phase_b_step(a, d, slot[h, :m], slot[h, m:m + D], D, 2)
+    hstate.append((a, d))
+    bstate = {}
+    if have:
+        a, d = hstate[rank]
+        for b, kb in zip(range(G["b_lo"], G["b_hi"]), keyb):
+            bstate[b] = (a, d)
+            a, d = pb.phase_b_step(a, d, kb[0], kb[1], kb[2], 2)
+        bstate[G["b_hi"]] = hstate[rank + 1] if G["b_hi"] < G["nblocks"] else (a, d)
+    while True:
+        # phase C: my blocks, and the next block as far as the halo reaches
+        lists = {}
+        if have:
+            for b in range(G["b_lo"], G["b_hi"] + (1 if G["c_end"] > G["c_hi"] else 0)):
+                k0 = b * B
+                nb = min(B, G["c_end"] - k0)
+                recs, _ = pb.phase_c(codes, bstate[b][0], bstate[b][1], k0, nb, X, L)
+                for j, r_ in enumerate(recs):
+                    lists[k0 + j] = r_
+        r0, mine = chunk_plan(S, G["cols"], rank, forced=forced_rounds)
+        size = n - L + 1
+
+        def gather(arr, lo, hi, extra):
+            buf = np.zeros(size, dtype=np.int64)
+            buf[lo:hi] = arr[lo:hi]
+            if extra is not None:
+                buf[extra] = arr[extra]
+            return allreduce(buf, 0)
+
+        M, LB, SZ, ovf = speculative_dp(lists, S, m, r0, mine, exchange=gather, stats=stats)
+        overflow = bool(allreduce(np.array([int(ovf)], dtype=np.int64), 1)[0])
+        red = None
+        if not overflow:
+            tb, t = [], n - L
+            while True:
+                tb.append((int(LB[t]), t + L, int(M[t]), int(SZ[t])))
+                if LB[t] == 0:
+                    break
+                t = int(LB[t]) - L
+            tb.reverse()
+            max_seg = tb[-1][2]
+            own = lambda col: G["c_lo"] <= col < G["c_hi"]
+            tau = np.zeros((len(tb), 2), dtype=np.int64)
+            for j, e in enumerate(tb):
+                if own(e[1] - 1):
+                    tau[j] = seg_tau(lists[e[1] - 1], max_seg)
+            tau = allreduce(tau.reshape(-1), 0).reshape(-1, 2)
+
+            def count_of(qs):
+                out = np.array([seg_count(lists[col], lb) if own(col) else 0 for col, lb in qs], dtype=np.int64)
+                return [int(x) for x in allreduce(out, 0)]
+
+            if max_seg < m:
+                red, overflow = merge_by_thresholds(tb, max_seg, [tuple(int(x) for x in t_) for t_ in tau], count_of)
+            else:
+                red = []
+        if not overflow:
+            break
+        assert X < m
+        X = min(m, 2 * X + 1)
+    # pass 2 on the owners
+    snaps = {}
+    for i, (_, rb, _) in enumerate(red):
+        if min(rb // (G["bpr"] * B), G["active"] - 1) != rank:
+            continue
+        b = min(rb // B, G["nblocks"])
+        sa, sd = bstate[b]
+        for k in range(b * B, rb):
+            sa, sd = pb.colstep(sa, sd, codes[sa, k], k + 1)
+        snaps[i] = (sa, sd)
+    return dict(M=M, LB=LB, SZ=SZ, traceback=tb, max_segment_size=max_seg, reduced=red, snaps=snaps, geometry=G, X=X)

@@ -1,14 +1,22 @@
-"""world_size-2 gloo test (CPU) of the N > 1 launcher logic bench.py uses: rank -> alignment
-assignment, barrier + max-over-ranks timing, aggregate throughput.  The step function here is a
-stand-in sleep; the GPU work itself is covered by the -m gpu tests."""
+"""world_size-2 gloo tests (CPU) of the N > 1 path.
+
+The real shard arithmetic -- block range per rank, hyper key block exchange, sharded speculative DP with its
+per-sweep key exchange, threshold merge, pass 2 on the owners -- runs here as its Python model
+(tests/proto_shard.py, the statement of what csrc/fseq_api.hip does with sh.on) in two processes whose ONLY
+connection is torch.distributed all_reduce over gloo, the same primitive (fseq_allreduce_fn) the library asks
+bench.py's ShardTransport for on the GPUs.  Every rank's result must equal the oracle's serial walk.  Also the
+launcher logic bench.py uses: env ranks, barrier + max-over-ranks timing."""
 import importlib
 import os
 import socket
-import time
+import sys
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def _free_port():
@@ -21,25 +29,50 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fso
+    import proto_shard as ps
     d = importlib.import_module("founder-sequences_amd.dist")
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         assert d.env_rank() == (rank, rank, world)
-        mine = d.alignments_for_rank(5, rank, world)
         calls = []
 
-        def step():
-            calls.append(1)
-            time.sleep(0.02 * (rank + 1))          # rank 1 is the slow one
+        def allreduce(arr, op):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+            calls.append(t.numel())
+            return t.numpy()
 
-        dt = d.timed_steps(step, steps=3, warmup=1, dist=dist, device_sync=None,
+        m, n, L, B, X = 14, 900, 8, 20, 2                      # X = 2: the ranks find the lists too short together and retry
+        msa = fso.synth_msa(fso.synth_spec(31, 3, 70, 5e-3, 0), m, n)
+        codes = np.searchsorted(np.unique(msa), msa).astype(np.int64)
+        out = {}
+
+        def step():
+            out["r"] = ps.segment_sharded(codes, L, B, X, rank, world, allreduce, forced_rounds=3)
+
+        dt = d.timed_steps(step, steps=1, warmup=0, dist=dist, device_sync=None,
                            tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64))
-        q.put((rank, mine, len(calls), dt, d.seed_for_alignment(0x5EED0002, mine[0])))
+        r = out["r"]
+        ref = fso.segment_long(msa, L, keep_dp=True, threads=1)
+        w = np.ones(n - L + 1, dtype=bool)
+        w[n - 2 * L + 1:n - L] = False
+        ok = (r["max_segment_size"] == ref["max_segment_size"]
+              and np.array_equal(r["M"][w], ref["dp"]["segment_max_size"][w])
+              and np.array_equal(r["LB"][w], ref["dp"]["lb"][w].astype(np.int64))
+              and np.array_equal(r["SZ"][w], ref["dp"]["segment_size"][w])
+              and [tuple(x) for x in r["reduced"]] == [(int(x["lb"]), int(x["rb"]), int(x["segment_size"])) for x in ref["reduced"]]
+              and all(np.array_equal(sa, ref["a"][i]) and np.array_equal(sd, ref["d"][i]) for i, (sa, sd) in r["snaps"].items()))
+        g = r["geometry"]
+        q.put((rank, ok, sorted(r["snaps"]), len(ref["reduced"]), (g["c_lo"], g["c_hi"], g["c_end"]), len(calls), dt, r["X"]))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_timing_and_assignment():
+def test_two_ranks_shard_one_alignment_over_gloo():
     world = 2
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -47,18 +80,19 @@ def test_two_rank_timing_and_assignment():
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    out = sorted(q.get(timeout=120) for _ in range(world))
+    out = sorted(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, a0, c0, t0, s0), (r1, a1, c1, t1, s1) = out
-    assert a0 == [0, 1, 2] and a1 == [3, 4]                 # contiguous, sizes differ by <= 1
-    assert c0 == c1 == 4                                    # warmup + steps
+    (r0, ok0, snaps0, S, cols0, calls0, t0, x0), (r1, ok1, snaps1, _, cols1, calls1, t1, x1) = out
+    assert ok0 and ok1                                      # both ranks hold the oracle's result
+    assert snaps0 and snaps1 and not set(snaps0) & set(snaps1)
+    assert sorted(snaps0 + snaps1) == list(range(S))        # every boundary state on exactly one rank
+    assert cols0[0] == 0 and cols0[1] == cols1[0] and cols1[1] == 900      # contiguous shares of the columns
+    assert cols0[2] > cols0[1]                              # rank 0 reads a halo of the next rank's columns
+    assert calls0 == calls1 and calls0 >= 8                 # the same exchanges on both sides
     assert abs(t0 - t1) < 1e-9                              # both ranks report the max over ranks
-    assert t0 >= 3 * 0.04 * 0.9                             # ... which is the slow rank's time
-    assert s0 != s1
-    d = importlib.import_module("founder-sequences_amd.dist")
-    assert d.aggregate_cells_per_second(10, 3, 2, 2.0) == 30.0
+    assert x0 == x1 and x0 > 2                              # the retry with longer lists happened on both
 
 
 def test_assignment_covers_everything_once():
@@ -67,3 +101,4 @@ def test_assignment_covers_everything_once():
         for world in (1, 2, 3, 8):
             got = sum((d.alignments_for_rank(n, r, world) for r in range(world)), [])
             assert got == list(range(n))
+    assert d.aggregate_cells_per_second(10, 3, 2, 2.0) == 30.0
