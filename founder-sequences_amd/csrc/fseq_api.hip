@@ -10,6 +10,7 @@
 #include "fseq_dp.hpp"
 #include "fseq_dpspec.hpp"
 #include "fseq_stream.hpp"
+#include "fseq_blockkeys.hpp"
 #include "fseq_join.hpp"
 
 #include <algorithm>
@@ -33,6 +34,9 @@ struct KernelSet {
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
 	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
+	void (*blockkeys)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t bsh,
+	                  uint32_t *, uint32_t *, uint32_t *, uint64_t col0, uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced);
+	hipError_t (*prepare_blockkeys)(size_t lds);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
@@ -68,6 +72,14 @@ struct Launch {
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0);
 	}
+	static void blockkeys(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+	                      uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
+	                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced)
+	{
+		hipLaunchKernelGGL((k_blockkeys<T>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0,
+		                   scratch, scratch_per_block, cap_words, sliced);
+	}
+	static hipError_t prepare_blockkeys(size_t lds) { return allow_lds(k_blockkeys<T>, lds); }
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
@@ -104,6 +116,7 @@ struct Launch {
 		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
 		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
 		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
+		k.blockkeys = &blockkeys; k.prepare_blockkeys = &prepare_blockkeys;
 		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
 		k.lds_chain = chain_lds_bytes<T, E, PK>();
 		k.chain = &chain; k.prepare = &prepare;
@@ -167,6 +180,10 @@ struct fseq_ctx {
 	uint8_t *d_msa_alloc = nullptr;          // what was allocated; d_msa = d_msa_alloc - c_lo * ld (column k at d_msa + k * ld)
 	uint2 *d_ent_alloc = nullptr;
 	uint32_t *d_ss_a_alloc = nullptr, *d_ss_d_alloc = nullptr;
+	uint16_t *d_bk = nullptr;                // phase A in key space (fseq_blockkeys.hpp): per-block scratch (leaf words, group ids)
+	size_t bk_per_block = 0, bk_blocks = 0;
+	uint32_t bk_cap_words = 0;
+	size_t bk_lds = 0;
 	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
 	uint32_t chunk_cap = 0;
 	uint2 *d_tau = nullptr;                  // merge thresholds (k_seg_tau) / counts
@@ -426,6 +443,21 @@ int prepare_geometry(fseq_ctx *c)
 		if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
 			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
+		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the bitmap takes what is left of ~76 KiB
+		// (two workgroups per CU) when that is worth at least the leaf bitmap twice over, else of the whole CU
+		{
+			size_t const arrays = blockkeys_lds_bytes(p.m, 0, (int) c->ks.T, c->ld, c->bsh);
+			size_t budget = 76 * 1024;
+			if (arrays + 6 * 4096 > budget) budget = LDS_LIMIT - 1024;
+			size_t cap = (budget - arrays) / 6;
+			cap = std::min<size_t>(cap & ~size_t(63), 32768);
+			if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) cap = (size_t) std::max(2048, atoi(e));     // tests: force the fallback
+			c->bk_cap_words = (uint32_t) cap;
+			c->bk_lds = blockkeys_lds_bytes(p.m, c->bk_cap_words, (int) c->ks.T, c->ld, c->bsh);
+			// (a leaf's columns are staged with two 16-byte pieces per thread)
+			if (cap >= 2048 && c->bk_lds <= LDS_LIMIT && (size_t) (8u >> (2u - c->bsh)) * c->ld <= (size_t) c->ks.T * 32) HIP_TRY(c, c->ks.prepare_blockkeys(c->bk_lds));
+			else c->bk_cap_words = 0;
+		}
 	}
 	HIP_TRY(c, allow_lds(k_dp<DP_WHOLE>, dp_lds_bytes()));
 	HIP_TRY(c, allow_lds(k_dp<DP_PARTIAL>, dp_lds_bytes()));
@@ -532,6 +564,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
 	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
+	dev_free(&c->d_bk); c->bk_blocks = 0;
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
@@ -969,7 +1002,22 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : c->nblocks;     // my blocks
 	uint32_t const my_blocks = b_hi - b_lo;
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
-	launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
+	bool const keyspace = !c->use_stream && c->bk_cap_words && my_blocks && !getenv("FSEQ_PHASE_A_CLASSIC");
+	if (keyspace)
+	{
+		// phase A in key space (fseq_blockkeys.hpp)
+		size_t const per = (blockkeys_scratch_halfwords(m, c->B, c->bsh) + 7) & ~size_t(7);
+		if (c->bk_per_block != per || c->bk_blocks < my_blocks)
+		{
+			if ((rc = dev_alloc(c, &c->d_bk, per * my_blocks))) return rc;
+			c->bk_per_block = per; c->bk_blocks = my_blocks;
+		}
+		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
+		ks.blockkeys(st, my_blocks, c->bk_lds, c->d_msa, c->ld, m, n, c->B, c->bsh, c->d_rank + (size_t) b_lo * m,
+		             c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64);
+	}
+	else
+		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	if (!sharded)
 	{
@@ -1257,6 +1305,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemcpyAsync(c->h_M.data(), c->dp.M, c->dp_size * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipMemcpyAsync(c->h_SZ.data(), c->dp.SZ, c->dp_size * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+		if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipStreamSynchronize(st));
 		{
 			float f = 0;

@@ -223,7 +223,7 @@ __host__ __device__ inline size_t colblock_lds_bytes()
 // predecessor differs in a lower digit already carry k+1 (the largest value there is) through the
 // range maximum of the later passes, so the result equals the single sigma-bucket partition.
 template <int T, int E, int SIGMA, int MODE, bool PK>
-__global__ __launch_bounds__(T) void k_colblock(
+__device__ __forceinline__ void colblock_body(char *smem,
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh,
 	// MODE_RANK outputs
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
@@ -237,7 +237,6 @@ __global__ __launch_bounds__(T) void k_colblock(
 	// MODE_RANK: workgroup i owns the block of columns starting at col0 + i * B (col0: first column of this
 	// launch -- a rank of a sharded run owns a contiguous block range); rank / keyd / nkeys are indexed by i
 	constexpr uint32_t CAP = T * E;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// MODE_RANK keeps divergences relative to the block start (0..B: 16 bits when PK)
 	using AT = std::conditional_t<PK, uint16_t, uint32_t>;
 	using DT = std::conditional_t<(PK && MODE == MODE_RANK), uint16_t, uint32_t>;
@@ -365,6 +364,21 @@ __global__ __launch_bounds__(T) void k_colblock(
 		}
 		if (tid == 0) nkeys[blockIdx.x] = total;
 	}
+}
+
+template <int T, int E, int SIGMA, int MODE, bool PK>
+__global__ __launch_bounds__(T) void k_colblock(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh,
+	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
+	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
+	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
+	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
+	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
+	uint64_t col0)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	colblock_body<T, E, SIGMA, MODE, PK>(smem, msa, ld, m, n, B, nblocks, npass, bsh, rank, keyd, nkeys, bstate_a, bstate_d, task_rb, task_grp,
+	                                     snap_a, snap_d, task_src, snap_stride, ss_a, ss_d, col0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -537,6 +537,43 @@ def test_speculative_dp_matches_serial_walk(pkg, monkeypatch, rounds, max_sweeps
             assert t["dp_sweeps"] <= max_sweeps + 1 or t["dp_sweeps"] >= 1000, t
 
 
+@pytest.mark.parametrize("mode", ["tree", "tiny_bitmap", "classic"])
+def test_phase_a_in_key_space_matches_the_column_sweep(pkg, monkeypatch, mode):
+    """Phase A ranks the block keys as a tree over the columns (fseq_blockkeys.hpp) instead of sweeping the pBWT over
+    the block; merges too large for its LDS bitmap run in slices (forced here with a bitmap of 2048 words, and on
+    random rows where every row is its own key), FSEQ_PHASE_A_CLASSIC runs the sweep everywhere.  Block boundary
+    states, lists, DP, traceback, segments and boundary states are compared with the oracle in every mode."""
+    if mode == "tiny_bitmap":
+        monkeypatch.setenv("FSEQ_BLOCKKEYS_CAP", "2048")
+    if mode == "classic":
+        monkeypatch.setenv("FSEQ_PHASE_A_CLASSIC", "1")
+    fallbacks = 0
+    for (m, n, L, K, Brec, mu, seed, kind, B) in SPEC_SHAPES + [(64, 4000, 6, 5, 90, 5e-3, 29, 0, 4), (8, 1000, 10, 3, 100, 5e-3, 0x5EED0001, 0, 0),
+                                                                   (700, 1500, 12, 300, 40, 3e-2, 77, 1, 333)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctx, _ = compare_long(pkg, msa, L, block_len=B)
+        fallbacks += ctx.timings()["phase_a_fallbacks"]
+        bl = ctx.timings()["block_len"]
+        p = fso.Pbwt(msa)
+        for b in range(0, ctx.timings()["n_blocks"] + 1, max(1, ctx.timings()["n_blocks"] // 5)):
+            while p.idx < min(n, b * bl):
+                p.step()
+            a, d = ctx.debug_block_state(b)
+            assert np.array_equal(a, p.a) and np.array_equal(d, p.d), (m, n, b)
+    # random rows: every row its own key in every block -- far beyond a 2048-word bitmap
+    rng = np.random.default_rng(3)
+    msa = (rng.integers(0, 4, size=(900, 600)) + 65).astype(np.uint8)
+    ctx = run_gpu(pkg, msa, 8, block_len=150)
+    ref = fso.segment_long(msa, 8, keep_dp=True, threads=4)
+    lb, mx, sz = ctx.debug_dp()
+    assert np.array_equal(mx[:600 - 16 + 1], ref["dp"]["segment_max_size"][:600 - 16 + 1])
+    fallbacks += ctx.timings()["phase_a_fallbacks"]
+    if mode == "tiny_bitmap":
+        assert fallbacks > 0
+    if mode == "classic":
+        assert fallbacks == 0
+
+
 def test_speculative_dp_with_short_lists_retries(pkg, monkeypatch):
     """A list too short to prove a cell is reported per chunk by the sweep that last ran the chunk; the run
     retries with longer lists and stays exact."""
