@@ -180,6 +180,8 @@ struct fseq_ctx {
 	uint8_t *d_msa_alloc = nullptr;          // what was allocated; d_msa = d_msa_alloc - c_lo * ld (column k at d_msa + k * ld)
 	uint2 *d_ent_alloc = nullptr;
 	uint32_t *d_ss_a_alloc = nullptr, *d_ss_d_alloc = nullptr;
+	uint32_t *d_bkws = nullptr;              // ... streamed rows: per-workgroup workspace (id arrays, group ids)
+	size_t bkws_words = 0;
 	uint16_t *d_bk = nullptr;                // phase A in key space (fseq_blockkeys.hpp): per-block scratch (leaf words, group ids)
 	size_t bk_per_block = 0, bk_blocks = 0;
 	uint32_t bk_cap_words = 0;
@@ -436,6 +438,12 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
+		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
+		c->bk_cap_words = 18432;
+		if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) c->bk_cap_words = (uint32_t) std::max(2048, atoi(e));
+		c->bk_lds = blockkeys_stream_lds_bytes(c->bk_cap_words, 1024);
+		if (c->bk_lds <= LDS_LIMIT) HIP_TRY(c, allow_lds(k_blockkeys_stream, c->bk_lds));
+		else c->bk_cap_words = 0;
 	}
 	else
 	{
@@ -564,7 +572,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
 	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
-	dev_free(&c->d_bk); c->bk_blocks = 0;
+	dev_free(&c->d_bk); c->bk_blocks = 0; dev_free(&c->d_bkws); c->bkws_words = 0;
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
@@ -1002,8 +1010,25 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : c->nblocks;     // my blocks
 	uint32_t const my_blocks = b_hi - b_lo;
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
-	bool const keyspace = !c->use_stream && c->bk_cap_words && my_blocks && !getenv("FSEQ_PHASE_A_CLASSIC");
-	if (keyspace)
+	bool const keyspace = c->bk_cap_words && my_blocks && !getenv("FSEQ_PHASE_A_CLASSIC");
+	if (keyspace && c->use_stream)
+	{
+		// phase A in key space, streamed rows: one workgroup per CU with its own workspace, blocks round-robin
+		int ncu = 0;
+		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+		uint32_t const groups = std::min<uint32_t>(my_blocks, (uint32_t) std::max(1, ncu));
+		size_t const per = (blockkeys_stream_ws_words(m, c->B, c->bsh) + 15) & ~size_t(15);
+		if (c->bkws_words < per * groups)
+		{
+			if ((rc = dev_alloc(c, &c->d_bkws, per * groups))) return rc;
+			c->bkws_words = per * groups;
+		}
+		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
+		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
+		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64);
+	}
+	else if (keyspace)
 	{
 		// phase A in key space (fseq_blockkeys.hpp)
 		size_t const per = (blockkeys_scratch_halfwords(m, c->B, c->bsh) + 7) & ~size_t(7);
