@@ -11,8 +11,6 @@
 #include <cstddef>
 #include <cstdint>
 #include <limits>
-#include <list>
-#include <map>
 #include <numeric>
 #include <random>
 #include <utility>
@@ -25,78 +23,87 @@ struct JoinSegment {
 	uint64_t lb, rb;
 };
 
+// ------------------------------------------------------------------------------------------------
+// Greedy joiner (row N1).  Behaviour of greedy_matcher::match (founder-sequences/greedy_matcher.cc:204-465,
+// entered through join_context.cc:211-229) in flat arrays: one class table per segment, copy numbers by a counting
+// sort of the class sizes, the (lhs class, rhs class) co-occurrence edges as one array ordered by (count
+// descending, pair ascending) that is compacted round after round, slot FIFOs as linked lists over one `next`
+// array.  What must come out the same (oracle/greedy_oracle.py restates it independently; tests/test_join.py):
+//   * a row starts a new class at pBWT position i iff seg_start < d[i] (:51); the class's representative is the
+//     row at its first position (:54)
+//   * copies (:81-105): every class one slot, the X - #classes spare slots handed out in rounds over the classes
+//     in descending size (ties: earlier class first, A8), ceil(size / m * spare) at a time (double arithmetic)
+//   * first segment (:128-160, :241-262): classes in pBWT order take consecutive slots
+//   * later segments (:266-463): edges are tried in the order above; an edge is drawn while both of its classes
+//     have copies left (the slot comes off the front of the lhs class's FIFO and goes to the back of the rhs
+//     class's), an edge that cannot be drawn is dropped; rounds repeat while one drew anything (:353-408); what is
+//     left is paired off by two ascending pointers (:412-439)
+// ------------------------------------------------------------------------------------------------
 namespace join_detail {
 
-typedef uint32_t seq_index;
-typedef std::vector<seq_index> seq_index_vector;
-typedef std::vector<std::pair<seq_index, seq_index>> seq_occurrence_vector;
-typedef std::vector<std::list<seq_index>> index_list_vector;
+constexpr uint32_t NIL = 0xFFFFFFFFu;
 
-// greedy_matcher.cc:31-68
-inline void update_string_mappings(
-	size_t const seq_count, uint64_t const seg_start_pos, uint32_t const *permutation, uint32_t const *divergence,
-	seq_index &distinct_substrings, seq_index_vector &seq_index_mapping, seq_index_vector &seq_inverse_mapping,
-	seq_index_vector &run_lengths)
-{
-	size_t current_run_length = 0;
-	distinct_substrings = 0;
-	for (size_t i = 0; i < seq_count; ++i)
+// the distinct substrings of one segment, in pBWT order
+struct ClassTable {
+	uint32_t count = 0;
+	std::vector<uint32_t> rep;        // [class] representative row
+	std::vector<uint32_t> size;       // [class] rows in the class
+	std::vector<uint32_t> of_row;     // [row] class
+	std::vector<uint32_t> copies;     // [class] slots the class gets
+
+	void build(uint32_t m, uint64_t seg_start, uint32_t const *a, uint32_t const *d, uint32_t X)
 	{
-		auto const string_idx = permutation[i];
-		if (seg_start_pos < divergence[i])                           // :51
+		rep.clear(); size.clear();
+		of_row.assign(m, NIL);
+		for (uint32_t i = 0; i < m; ++i)
 		{
-			run_lengths[distinct_substrings] = (seq_index) current_run_length;   // run_lengths[0] stays 0
-			seq_index_mapping[distinct_substrings++] = string_idx;
-			current_run_length = 0;
+			if (seg_start < d[i]) { rep.push_back(a[i]); size.push_back(0); }
+			of_row[a[i]] = (uint32_t) rep.size() - 1u;
+			++size.back();
 		}
-		seq_inverse_mapping[string_idx] = distinct_substrings - 1;  // :60
-		++current_run_length;
+		count = (uint32_t) rep.size();
+		// classes by descending size, earlier class first among equals: counting sort on the size
+		std::vector<uint32_t> start(m + 2, 0), order(count);
+		for (uint32_t c = 0; c < count; ++c) ++start[m - size[c] + 1];
+		for (uint32_t v = 0; v <= m; ++v) start[v + 1] += start[v];
+		for (uint32_t c = 0; c < count; ++c) order[start[m - size[c]]++] = c;
+		copies.assign(count, 1);
+		size_t const spare = X - count;
+		size_t left = spare;
+		while (left)
+			for (uint32_t k = 0; k < count && left; ++k)
+			{
+				uint32_t const c = order[k];
+				size_t const give = std::min(left, size_t(std::ceil(1.0 * size[c] / m * spare)));
+				copies[c] += (uint32_t) give;
+				left -= give;
+			}
 	}
-	run_lengths[distinct_substrings] = (seq_index) current_run_length;          // :67
-}
+};
 
-// greedy_matcher.cc:71-78 followed by lb::radix_sort<true>::sort(..., pair.second) (:259,:290; A8)
-inline void sorted_occurrences(seq_index const distinct_substrings, seq_index_vector const &run_lengths, seq_occurrence_vector &occ)
-{
-	occ.clear();
-	for (size_t i = 0; i < distinct_substrings; ++i)
-		occ.emplace_back((seq_index) i, run_lengths[1 + i]);
-	std::stable_sort(occ.begin(), occ.end(), [](auto const &x, auto const &y) { return x.second > y.second; });
-}
-
-// greedy_matcher.cc:81-105
-inline void update_copies(seq_occurrence_vector const &occ, size_t const max_segment_size, size_t const seq_count, seq_index_vector &cn)
-{
-	std::fill(cn.begin(), cn.end(), 1);
-	size_t const to_fill = max_segment_size - occ.size();
-	size_t rem_size = to_fill;
-	while (true)
+// FIFO of founder slots per class: singly linked through `next` (a slot sits in one queue at a time)
+struct SlotQueues {
+	std::vector<uint32_t> head, tail;
+	void reset(uint32_t classes) { head.assign(classes, NIL); tail.assign(classes, NIL); }
+	void push(std::vector<uint32_t> &next, uint32_t c, uint32_t slot)
 	{
-		for (auto const &pr : occ)
-		{
-			size_t const copy_count = std::min(rem_size, size_t(std::ceil(1.0 * pr.second / seq_count * to_fill)));   // :97
-			rem_size -= copy_count;
-			cn[pr.first] += (seq_index) copy_count;
-			if (0 == rem_size)
-				return;
-		}
+		next[slot] = NIL;
+		if (tail[c] == NIL) head[c] = slot; else next[tail[c]] = slot;
+		tail[c] = slot;
 	}
-}
+	uint32_t pop(std::vector<uint32_t> const &next, uint32_t c)
+	{
+		uint32_t const slot = head[c];
+		head[c] = next[slot];
+		if (head[c] == NIL) tail[c] = NIL;
+		return slot;
+	}
+};
 
-// greedy_matcher.cc:163-198
-inline void draw_edge(seq_index const lhs_idx, seq_index const rhs_idx, seq_index_vector const &rhs_seq_mapping,
-                      index_list_vector &lhs_slots, index_list_vector &rhs_slots, uint32_t *permutation)
-{
-	auto &slot_list = lhs_slots[lhs_idx];
-	auto const slot = slot_list.front();
-	slot_list.pop_front();
-	rhs_slots[rhs_idx].push_back(slot);
-	permutation[slot] = rhs_seq_mapping[rhs_idx];
-}
+struct Edge { uint32_t l, r, rows; };
 
 } // namespace join_detail
 
-// greedy_matcher::match, greedy_matcher.cc:204-465.
 // A, D: segment_count x m (input_permutation / input_divergence at each segment's rb).
 // permutations: segment_count x max_segment_size, permutations[s][row] = input row whose substring
 // [lb_s, rb_s) is placed in founder `row`.
@@ -105,143 +112,96 @@ inline void greedy_match(
 	uint32_t const *A, uint32_t const *D, uint32_t *permutations)
 {
 	using namespace join_detail;
-	size_t const X = max_segment_size;
-	seq_index lhs_distinct = 0, rhs_distinct = 0;
-	seq_index_vector lhs_seq_mapping(X, UINT32_MAX), rhs_seq_mapping(X, UINT32_MAX);
-	seq_index_vector lhs_inverse(seq_count, UINT32_MAX), rhs_inverse(seq_count, UINT32_MAX);
-	seq_index_vector lhs_rl(1 + X, 0), rhs_rl(1 + X, 0);
-	seq_index_vector lhs_cn(X, 0), rhs_cn(X, 0), rhs_rc(X, 0);
-	seq_occurrence_vector occ;
-	std::vector<uint64_t> index_pairs(seq_count, 0);
-	uint64_t seg_start_idx = 0;
-	typedef std::list<std::pair<seq_index, seq_index>> index_pair_list;
-	std::map<size_t, index_pair_list, std::greater<size_t>> index_pairs_by_count;
-	index_list_vector lhs_slots(X), rhs_slots(X);
-
+	uint32_t const m = seq_count, X = max_segment_size;
 	if (segs.empty()) return;
-	std::fill(permutations, permutations + segs.size() * X, 0u);
+	std::fill(permutations, permutations + segs.size() * (size_t) X, 0u);
 
-	// first segment (:241-262)
+	ClassTable L, R;
+	SlotQueues lq, rq;
+	std::vector<uint32_t> next(X, NIL);
+	std::vector<uint64_t> keys(m);
+	std::vector<Edge> edges, ordered;
+	std::vector<uint32_t> bucket;
+
+	// first segment: classes in pBWT order take consecutive slots
+	L.build(m, 0, A, D, X);
+	lq.reset(L.count);
 	{
-		update_string_mappings(seq_count, seg_start_idx, A, D, lhs_distinct, lhs_seq_mapping, lhs_inverse, lhs_rl);
-		seg_start_idx = segs[0].rb;                                              // :257, sequence_idx()
-		sorted_occurrences(lhs_distinct, lhs_rl, occ);
-		update_copies(occ, X, seq_count, lhs_cn);
-		// update_initial_permutation (:128-160)
-		size_t i = 0;
-		for (size_t seq_idx = 0; seq_idx < lhs_distinct; ++seq_idx)
-		{
-			auto const copy_count = lhs_cn[seq_idx];
-			lhs_slots[seq_idx].clear();
-			for (size_t j = 0; j < copy_count; ++j)
-				lhs_slots[seq_idx].emplace_back((seq_index) (j + i));
-			std::fill(permutations + i, permutations + i + copy_count, lhs_seq_mapping[seq_idx]);
-			i += copy_count;
-		}
+		uint32_t slot = 0;
+		for (uint32_t c = 0; c < L.count; ++c)
+			for (uint32_t k = 0; k < L.copies[c]; ++k, ++slot)
+			{
+				permutations[slot] = L.rep[c];
+				lq.push(next, c, slot);
+			}
 	}
+	uint64_t seg_start = segs[0].rb;
 
-	for (size_t target = 1; target < segs.size(); ++target)                      // :266
+	for (size_t s = 1; s < segs.size(); ++s)
 	{
-		uint32_t const *permutation_in = A + target * (size_t) seq_count;
-		uint32_t const *divergence_in = D + target * (size_t) seq_count;
-		uint32_t *permutation = permutations + target * X;
-		index_pairs_by_count.clear();
+		uint32_t const *a = A + s * (size_t) m, *d = D + s * (size_t) m;
+		uint32_t *perm = permutations + s * (size_t) X;
+		R.build(m, seg_start, a, d, X);
+		rq.reset(R.count);
 
-		update_string_mappings(seq_count, seg_start_idx, permutation_in, divergence_in, rhs_distinct, rhs_seq_mapping, rhs_inverse, rhs_rl);
-		sorted_occurrences(rhs_distinct, rhs_rl, occ);
-		update_copies(occ, X, seq_count, rhs_cn);
-
-		// edges as (lhs class, rhs class) pairs, sorted ascending (:294-311)
-		for (size_t i = 0; i < seq_count; ++i)
+		// co-occurrence edges: how many rows go from lhs class l to rhs class r
+		for (uint32_t row = 0; row < m; ++row) keys[row] = ((uint64_t) L.of_row[row] << 32) | R.of_row[row];
+		std::sort(keys.begin(), keys.end());
+		edges.clear();
+		for (uint32_t i = 0; i < m;)
 		{
-			auto const seq_idx = permutation_in[i];
-			index_pairs[i] = ((uint64_t) lhs_inverse[seq_idx] << 32) | rhs_inverse[seq_idx];
+			uint32_t j = i + 1;
+			while (j < m && keys[j] == keys[i]) ++j;
+			edges.push_back(Edge{(uint32_t) (keys[i] >> 32), (uint32_t) keys[i], j - i});
+			i = j;
 		}
-		std::sort(index_pairs.begin(), index_pairs.end());
+		// ... by descending row count, pairs ascending within a count (the edges are in ascending pair order now)
+		bucket.assign(m + 2, 0);
+		for (Edge const &e : edges) ++bucket[m - e.rows + 1];
+		for (uint32_t v = 0; v <= m; ++v) bucket[v + 1] += bucket[v];
+		ordered.resize(edges.size());
+		for (Edge const &e : edges) ordered[bucket[m - e.rows]++] = e;
 
-		// counts -> lists of unique edges in ascending pair order (:316-343)
+		std::vector<uint32_t> &lhs_left = L.copies;            // copies of an lhs class not yet continued
+		std::vector<uint32_t> rhs_left = R.copies;             // copies of an rhs class not yet placed
+		auto connect = [&](uint32_t l, uint32_t r) {
+			uint32_t const slot = lq.pop(next, l);
+			rq.push(next, r, slot);
+			perm[slot] = R.rep[r];
+			--lhs_left[l];
+			--rhs_left[r];
+		};
+		// rounds over the surviving edges
+		size_t alive = ordered.size();
+		bool drew = true;
+		while (drew)
 		{
-			uint64_t prev_item = index_pairs.front();
-			size_t current_count = 1;
-			for (size_t i = 1; i < seq_count; ++i)
+			drew = false;
+			size_t keep = 0;
+			for (size_t i = 0; i < alive; ++i)
 			{
-				auto const current_item = index_pairs[i];
-				if (prev_item == current_item)
-					++current_count;
-				else
+				Edge const e = ordered[i];
+				if (lhs_left[e.l] && rhs_left[e.r])
 				{
-					index_pairs_by_count[current_count].emplace_back((seq_index) (prev_item >> 32), (seq_index) (prev_item & 0xFFFFFFFFu));
-					prev_item = current_item;
-					current_count = 1;
+					connect(e.l, e.r);
+					ordered[keep++] = e;
+					drew = true;
 				}
 			}
-			index_pairs_by_count[current_count].emplace_back((seq_index) (prev_item >> 32), (seq_index) (prev_item & 0xFFFFFFFFu));
+			alive = keep;
 		}
-
-		// draw the edges (:346-408)
-		rhs_rc = rhs_cn;
-		bool did_draw_edge = true;
-		while (did_draw_edge)
+		// leftovers: ascending classes on both sides
+		for (uint32_t l = 0, r = 0;;)
 		{
-			did_draw_edge = false;
-			auto ip_it = index_pairs_by_count.begin();
-			while (ip_it != index_pairs_by_count.end())
-			{
-				auto &list = ip_it->second;
-				auto it = list.begin();
-				while (it != list.end())
-				{
-					auto const lhs_idx = it->first, rhs_idx = it->second;
-					if (lhs_cn[lhs_idx] && rhs_rc[rhs_idx])                         // :380
-					{
-						did_draw_edge = true;
-						--lhs_cn[lhs_idx];
-						--rhs_rc[rhs_idx];
-						draw_edge(lhs_idx, rhs_idx, rhs_seq_mapping, lhs_slots, rhs_slots, permutation);
-						++it;
-					}
-					else
-						it = list.erase(it);
-				}
-				if (!list.empty())
-					++ip_it;
-				else
-					ip_it = index_pairs_by_count.erase(ip_it);
-			}
+			while (l < L.count && 0 == lhs_left[l]) ++l;
+			while (r < R.count && 0 == rhs_left[r]) ++r;
+			if (l == L.count || r == R.count) break;
+			connect(l, r);
 		}
 
-		// the remaining edges (:412-439)
-		{
-			size_t i = 0, j = 0;
-			while (true)
-			{
-				bool done = false;
-				while (0 == lhs_cn[i])
-				{
-					++i;
-					if (i == lhs_distinct) { done = true; break; }
-				}
-				if (done) break;
-				while (0 == rhs_rc[j])
-				{
-					++j;
-					if (j == rhs_distinct) { done = true; break; }
-				}
-				if (done) break;
-				draw_edge((seq_index) i, (seq_index) j, rhs_seq_mapping, lhs_slots, rhs_slots, permutation);
-				--lhs_cn[i];
-				--rhs_rc[j];
-			}
-		}
-
-		using std::swap;                                                         // :453-460
-		swap(lhs_distinct, rhs_distinct);
-		swap(lhs_seq_mapping, rhs_seq_mapping);
-		swap(lhs_inverse, rhs_inverse);
-		swap(lhs_rl, rhs_rl);
-		swap(lhs_cn, rhs_cn);
-		swap(lhs_slots, rhs_slots);
-		seg_start_idx = segs[target].rb;
+		std::swap(L, R);
+		std::swap(lq, rq);
+		seg_start = segs[s].rb;
 	}
 }
 
