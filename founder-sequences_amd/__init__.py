@@ -70,7 +70,7 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
-    "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
+    "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
 
@@ -125,6 +125,7 @@ def load_library():
     L.fseq_debug_block_state.argtypes = [vp, u64, vp, vp]
     L.fseq_debug_column_list.argtypes = [vp, u64, vp, vp, vp, vp, vp]
     L.fseq_get_timings.argtypes = [vp, C.POINTER(Timings)]
+    L.fseq_debug_rmq.argtypes = [C.c_int, vp, C.c_uint32, vp, vp, C.c_uint32, vp, vp]
     L.fseq_shard_xbuf_words.restype = u64
     L.fseq_shard_xbuf_words.argtypes = [vp, C.c_uint32]
     L.fseq_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u64, ALLREDUCE_FN, vp]
@@ -155,6 +156,20 @@ def greedy_match_host(m, max_segment_size, lb, rb, a, d):
     if rc != FSEQ_OK:
         raise FseqError(rc, L.fseq_strerror(rc).decode())
     return perm
+
+
+def debug_rmq(keys, beg, end, device=0):
+    """rmq.hh as the device routines restate it, on caller keys: (index by the HBM path, index by the LDS path)."""
+    L = load_library()
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    beg = np.ascontiguousarray(beg, dtype=np.uint32)
+    end = np.ascontiguousarray(end, dtype=np.uint32)
+    a = np.zeros(len(beg), dtype=np.uint32)
+    b = np.zeros(len(beg), dtype=np.uint32)
+    rc = L.fseq_debug_rmq(device, keys.ctypes.data, len(keys), beg.ctypes.data, end.ctypes.data, len(beg), a.ctypes.data, b.ctypes.data)
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return a, b
 
 
 def dp_schedule(segment_length, n, col_hi):

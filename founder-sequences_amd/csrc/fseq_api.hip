@@ -1252,15 +1252,17 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 					r_done = r1;
 					continue;
 				}
-				if (hipStreamQuery(st) == hipSuccess && prefix < c->nblocks)
+				hipError_t const q = hipStreamQuery(st);
+				if (q != hipErrorNotReady && prefix < c->nblocks)
 				{
-					// phase C has finished but a flag is missing: should not happen; do not spin for ever
+					// phase C is over: either it failed (report that, not a time-out) or every flag is there
+					if (q != hipSuccess) return fail(c, FSEQ_E_HIP, "phase C failed", q);
 					while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
-					if (prefix < c->nblocks) prefix = c->nblocks;
+					if (prefix < c->nblocks) return fail(c, FSEQ_E_HIP, "internal: phase C finished without flagging every block");
 					continue;
 				}
 				if (now_ms() - t_wait0 > 600e3) return fail(c, FSEQ_E_HIP, "timed out waiting for phase C");
-				std::this_thread::yield();
+				if (now_ms() - t_wait0 > 50.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
 			}
 			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
 			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
@@ -1598,7 +1600,41 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 		c->ws_words = (size_t) 4 * m;
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
 	}
-	launch_rank(c, 1, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
+	// one block [0, n): ranked in key space (fseq_blockkeys.hpp); FSEQ_PHASE_A_CLASSIC: the per-column sweep
+	if (c->bk_cap_words && !getenv("FSEQ_PHASE_A_CLASSIC"))
+	{
+		if (c->use_stream)
+		{
+			size_t const per = (blockkeys_stream_ws_words(m, (uint32_t) p.n, c->bsh) + 15) & ~size_t(15);
+			if (c->bkws_words < per)
+			{
+				if ((rc = dev_alloc(c, &c->d_bkws, per))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+				c->bkws_words = per;
+			}
+			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
+			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr);
+		}
+		else
+		{
+			size_t const per = (blockkeys_scratch_halfwords(m, (uint32_t) p.n, c->bsh) + 7) & ~size_t(7);
+			if (c->bk_per_block != per || c->bk_blocks < 1)
+			{
+				if ((rc = dev_alloc(c, &c->d_bk, per))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+				c->bk_per_block = per; c->bk_blocks = 1;
+			}
+			c->ks.blockkeys(st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr);
+		}
+	}
+	else
+	{
+		// the 16-bit LDS kernels keep block-relative divergences in 16 bits: one block of 65536 columns or more would wrap
+		if (!c->use_stream && c->ks.cap > 7168u && p.n > 65535u)
+		{
+			dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk);
+			return fail(c, FSEQ_E_UNSUPPORTED, "short path by column sweep: more than 65535 columns with 16-bit LDS state (unset FSEQ_PHASE_A_CLASSIC)");
+		}
+		launch_rank(c, 1, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
+	}
 	std::vector<uint32_t> rank(m);
 	uint32_t nk = 0;
 	hipError_t e1 = hipMemcpyAsync(rank.data(), d_rank, (size_t) m * 4, hipMemcpyDeviceToHost, st);
@@ -2152,6 +2188,58 @@ int fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi,
 	if (rounds_within) *rounds_within = dp_rounds_within(S, col_hi);
 	if (pipelined) *pipelined = S.pipe ? 1 : 0;
 	return FSEQ_OK;
+}
+
+int fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
+                   uint32_t *index_hbm, uint32_t *index_lds)
+{
+	if (!keys || !count || (n_queries && (!beg || !end || !index_hbm))) return FSEQ_E_ARG;
+	for (uint32_t q = 0; q < n_queries; ++q)
+		if (beg[q] >= end[q] || end[q] > count) return FSEQ_E_ARG;
+	if (hipSetDevice(device) != hipSuccess) return FSEQ_E_HIP;
+	DpArrays A{};
+	A.tstride = count / 64 + 2;
+	uint32_t *d_prev = nullptr, *d_lift = nullptr, *d_r0 = nullptr;
+	uint2 *d_q = nullptr, *d_out = nullptr;
+	SpecCtl *d_ctl = nullptr;
+	int rc = FSEQ_E_HIP;
+	auto A_free = [&]() {
+		(void) hipFree(A.M); (void) hipFree(A.K); (void) hipFree(A.Tb); (void) hipFree(A.Tbv); (void) hipFree(d_prev); (void) hipFree(d_lift);
+		(void) hipFree(d_r0); (void) hipFree(d_q); (void) hipFree(d_out); (void) hipFree(d_ctl);
+	};
+	std::vector<uint2> hq(n_queries), ho(n_queries);
+	for (uint32_t q = 0; q < n_queries; ++q) hq[q] = make_uint2(beg[q], end[q]);
+	uint32_t const r0[2] = {0u, count};                       // one "chunk" of `count` rounds of one entry
+	do
+	{
+		if (hipMalloc((void **) &A.M, ((size_t) count + 64) * 4) != hipSuccess) break;
+		if (hipMalloc((void **) &A.K, ((size_t) count + 64) * 8) != hipSuccess) break;
+		if (hipMalloc((void **) &A.Tb, (size_t) 32 * A.tstride * 4) != hipSuccess) break;
+		if (hipMalloc((void **) &A.Tbv, (size_t) 32 * A.tstride * 4) != hipSuccess) break;
+		if (hipMalloc((void **) &d_prev, ((size_t) count + 64) * 4) != hipSuccess) break;
+		if (hipMalloc((void **) &d_lift, 16) != hipSuccess) break;
+		if (hipMalloc((void **) &d_r0, 16) != hipSuccess) break;
+		if (hipMalloc((void **) &d_q, std::max<size_t>(1, n_queries) * 8) != hipSuccess) break;
+		if (hipMalloc((void **) &d_out, std::max<size_t>(1, n_queries) * 8) != hipSuccess) break;
+		if (hipMalloc((void **) &d_ctl, sizeof(SpecCtl)) != hipSuccess) break;
+		if (hipMemcpy(A.M, keys, (size_t) count * 4, hipMemcpyHostToDevice) != hipSuccess) break;
+		if (hipMemset(d_lift, 0, 16) != hipSuccess || hipMemset(d_ctl, 0, sizeof(SpecCtl)) != hipSuccess) break;
+		if (hipMemcpy(d_r0, r0, 8, hipMemcpyHostToDevice) != hipSuccess) break;
+		if (n_queries && hipMemcpy(d_q, hq.data(), (size_t) n_queries * 8, hipMemcpyHostToDevice) != hipSuccess) break;
+		SpecGeom G;
+		G.chunk_r0 = d_r0; G.RL = 1; G.nchunks = 1; G.NR = count; G.t_final = count + 32u; G.win = 1;
+		hipLaunchKernelGGL(k_spec_rebuild, dim3((count + 255u) / 256u), dim3(256), 0, 0, A, d_prev, G, d_lift, d_ctl);
+		hipLaunchKernelGGL(k_spec_table, dim3((count / 64u + 255u) / 256u + 1u), dim3(256), 0, 0, A, count / 64u, d_ctl);
+		size_t const lds = (size_t) DPW * 12 + (size_t) DP_LEVELS * DP_TRN * 8 + 64;
+		if (allow_lds(k_debug_rmq, lds) != hipSuccess) break;
+		hipLaunchKernelGGL(k_debug_rmq, dim3(1), dim3(1024), lds, 0, A, count, d_q, n_queries, d_out);
+		if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) break;
+		if (n_queries && hipMemcpy(ho.data(), d_out, (size_t) n_queries * 8, hipMemcpyDeviceToHost) != hipSuccess) break;
+		for (uint32_t q = 0; q < n_queries; ++q) { index_hbm[q] = ho[q].x; if (index_lds) index_lds[q] = ho[q].y; }
+		rc = FSEQ_OK;
+	} while (false);
+	A_free();
+	return rc;
 }
 
 int fseq_get_timings(fseq_ctx const *c, fseq_timings *out)

@@ -186,4 +186,47 @@ __global__ __launch_bounds__(256) void k_spec_table(DpArrays const A, uint32_t n
 	}
 }
 
+// ---- test hook (fseq_debug_rmq): the restated rmq.hh on caller-supplied keys --------------------------------
+// One workgroup.  The keys' masks and sparse table must have been built (k_spec_rebuild + k_spec_table, i.e. the
+// closed forms the sweeps rely on).  Every query [beg, end) is answered twice: by rmq_query with everything read
+// from HBM, and -- when the whole array fits the LDS rings (count <= DPW entries, <= DP_TRN blocks) -- by
+// rmq_query_lds, the path practically every DP candidate takes.  out[q] = {index by the HBM path, index by the LDS
+// path or 0xFFFFFFFF}.
+__global__ __launch_bounds__(1024) void k_debug_rmq(DpArrays const A, uint32_t count, uint2 const *__restrict__ queries, uint32_t nq, uint2 *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	lds_char *const lds0 = (lds_char *) smem;
+	DpLds D{};
+	uint32_t off = 0;
+	auto take = [&](size_t bytes) { uint32_t const o = off; off += (uint32_t) ((bytes + 15) & ~size_t(15)); return o; };
+	D.Kr = (lds_u64 *) (lds0 + take((size_t) DPW * 8));
+	D.Mr = (lds_u32 *) (lds0 + take((size_t) DPW * 4));
+	D.Tr = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	D.Trv = (lds_u32 *) (lds0 + take((size_t) DP_LEVELS * DP_TRN * 4));
+	bool const fits = count <= DPW && (count >> 6) <= DP_TRN;
+	if (fits)
+	{
+		for (uint32_t t = threadIdx.x; t < count; t += 1024u) { D.Mr[t] = A.M[t]; D.Kr[t] = A.K[t]; }
+		uint32_t const nb = count >> 6;
+		for (uint32_t idx = threadIdx.x; idx < DP_LEVELS * DP_TRN; idx += 1024u)
+		{
+			uint32_t const p = idx / DP_TRN, j = idx % DP_TRN;
+			if (p < 31u && j + (1u << p) <= nb) { D.Tr[idx] = A.Tb[(size_t) p * A.tstride + j]; D.Trv[idx] = A.Tbv[(size_t) p * A.tstride + j]; }
+		}
+	}
+	__syncthreads();
+	DpView V;
+	V.safe_lo = 0xFFFFFFFFu;              // nothing is taken from the rings ...
+	V.cb = 0xFFFFFF00u;                   // ... nor any sample
+	V.fresh_lo = 0;
+	for (uint32_t q = threadIdx.x; q < nq; q += 1024u)
+	{
+		uint32_t v;
+		uint2 const qq = queries[q];
+		uint32_t const a = rmq_query(A, D, V, qq.x, qq.y, &v);
+		uint32_t const b = fits ? rmq_query_lds(D, qq.x, qq.y, &v) : 0xFFFFFFFFu;
+		out[q] = make_uint2(a, b);
+	}
+}
+
 } // namespace fseq

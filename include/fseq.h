@@ -230,6 +230,13 @@ int  fseq_debug_block_state(fseq_ctx *ctx, uint64_t block_idx, uint32_t *a_out, 
 int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_t *counts,
                             uint32_t *n_entries, uint32_t *cnt0, uint32_t *complete);
 
+/* The restated rmq.hh (rmq<..., 64>, include/founder_sequences/rmq.hh:61-118, quirks included) on caller-supplied
+ * keys, straight on the device routines the DP uses (debug / tests): the stack masks and the sparse table are
+ * built in closed form from the keys, every query [beg, end) is answered by the HBM path (index_hbm) and, when
+ * the array fits the LDS rings (count <= 4096), by the LDS path (index_lds, else 0xFFFFFFFF). */
+int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
+                    uint32_t *index_hbm, uint32_t *index_lds);
+
 int  fseq_get_timings(fseq_ctx const *ctx, fseq_timings *out);
 
 #ifdef __cplusplus

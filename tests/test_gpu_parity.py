@@ -182,16 +182,50 @@ def test_unreducible_input_reports_no_reduction(pkg):
     assert ref["status"] == 1 and ctx.result.max_segment_size == ref["max_segment_size"]
 
 
-def test_short_path_matches_oracle(pkg):
-    spec = fso.synth_spec(3, 3, 1000, 1e-3)
-    msa = fso.synth_msa(spec, 50, 30)
-    ctx = pkg.SegmentationContext(50, 30, 20)       # n < 2L
+SHORT_SHAPES = [
+    # m, n, L, K, Brec, mu, seed, kind
+    (50, 30, 20, 3, 1000, 1e-3, 3, 0),
+    (300, 999, 500, 6, 200, 2e-3, 41, 0),
+    (700, 1200, 900, 8, 150, 3e-3, 42, 1),               # sigma = 16
+    (9000, 2000, 1500, 16, 400, 2e-4, 43, 0),            # 16-bit LDS state (m > 7168)
+    (12000, 1500, 800, 12, 300, 3e-4, 44, 0),            # streamed rows
+    (10000, 70000, 40000, 32, 5000, 1e-4, 45, 1),        # m > 7168 AND more than 65535 columns in the one block (16-bit divergences would wrap)
+]
+
+
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed,kind", SHORT_SHAPES)
+def test_short_path_matches_oracle(pkg, m, n, L, K, Brec, mu, seed, kind):
+    """segmentation_sp_context::process (n < 2L): the distinct rows with their representatives and copy numbers."""
+    msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+    ctx = pkg.SegmentationContext(m, n, L)
     ctx.set_sequences(msa)
-    res = ctx.run()
+    try:
+        res = ctx.run()
+    except pkg.NoReduction:
+        res = ctx.result
     assert res.short_path == 1
     f, r = fso.segment_short(msa)
     gf, gr = ctx.short_path_runs()
     assert res.max_segment_size == len(f)
+    assert np.array_equal(gf, f) and np.array_equal(gr, r)
+
+
+def test_short_path_by_column_sweep_refuses_what_would_wrap(pkg, monkeypatch):
+    """The classic per-column sweep keeps block-relative divergences in 16 bits for 7168 < m <= 11264: one block of
+    more than 65535 columns must fail loudly there instead of returning a wrong count (round-1 advice)."""
+    monkeypatch.setenv("FSEQ_PHASE_A_CLASSIC", "1")
+    ctx = pkg.SegmentationContext(8000, 66000, 40000)
+    ctx.generate_synthetic(7, 8, 5000, 1e-4, 0)
+    with pytest.raises(pkg.FseqError) as e:
+        ctx.run()
+    assert e.value.code == pkg.FSEQ_E_UNSUPPORTED
+    # ... and still runs the shapes it can
+    msa = fso.synth_msa(fso.synth_spec(41, 6, 200, 2e-3, 0), 300, 999)
+    c2 = pkg.SegmentationContext(300, 999, 500)
+    c2.set_sequences(msa)
+    c2.run()
+    f, r = fso.segment_short(msa)
+    gf, gr = c2.short_path_runs()
     assert np.array_equal(gf, f) and np.array_equal(gr, r)
 
 
