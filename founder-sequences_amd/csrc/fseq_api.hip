@@ -1754,6 +1754,37 @@ int fseq_set_rows(fseq_ctx *c, uint8_t const *const *rows)
 	return upload_rows_device(c, rows);
 }
 
+// borrowed columns: every code must be < sigma (the owned upload paths build the code table themselves)
+static int check_borrowed_codes(fseq_ctx *c)
+{
+	if (c->sigma >= (1u << (8u >> c->bsh))) return FSEQ_OK;          // every code the width can hold is allowed
+	uint64_t const ncols = held_hi(c) - held_lo(c);
+	if (!ncols) return FSEQ_OK;
+	uint32_t *d_mx = nullptr;
+	int rc = dev_alloc(c, &d_mx, 1);
+	if (rc) return rc;
+	uint32_t mx = 0;
+	uint32_t const col_bytes = sym_bytes(c->p.m, c->bsh), tail = c->p.m & ((1u << c->bsh) - 1u);
+	hipError_t e = hipMemsetAsync(d_mx, 0, 4, c->stream);
+	if (e == hipSuccess)
+	{
+		hipLaunchKernelGGL(k_max_code, dim3((uint32_t) std::min<uint64_t>(ncols, 4096)), dim3(256), 0, c->stream,
+		                   c->d_msa + held_lo(c) * c->ld, c->ld, col_bytes, ncols, c->bsh, tail, d_mx);
+		e = hipMemcpyAsync(&mx, d_mx, 4, hipMemcpyDeviceToHost, c->stream);
+	}
+	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+	dev_free(&d_mx);
+	if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "checking the borrowed columns", e);
+	if (mx >= c->sigma)
+	{
+		c->have_input = false;
+		char what[128];
+		snprintf(what, sizeof(what), "borrowed device columns hold the code %u but sigma is %u", mx, c->sigma);
+		return fail(c, FSEQ_E_ARG, what);
+	}
+	return FSEQ_OK;
+}
+
 int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_t sigma)
 {
 	if (!c || !d_codes) return FSEQ_E_ARG;
@@ -1771,7 +1802,8 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	return FSEQ_OK;
+	(void) hipSetDevice(c->p.device);
+	return check_borrowed_codes(c);
 }
 
 int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_bytes, uint32_t sigma, uint32_t bits)
@@ -1793,7 +1825,8 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	return FSEQ_OK;
+	(void) hipSetDevice(c->p.device);
+	return check_borrowed_codes(c);
 }
 
 uint64_t fseq_shard_xbuf_words(fseq_ctx const *c, uint32_t world)

@@ -158,6 +158,30 @@ __global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ ra
 	if (threadIdx.x < 8 && bm[threadIdx.x]) atomicOr(&present[threadIdx.x], bm[threadIdx.x]);
 }
 
+// Largest symbol code in borrowed device columns (fseq_set_device_columns*: the caller promises codes < sigma; a
+// larger code would silently lose its high digits in the 2-bit digit passes).  bits per code = 8 >> bsh.
+__global__ __launch_bounds__(256) void k_max_code(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t ncols, uint32_t bsh,
+                                                  uint32_t tail_rows, uint32_t *__restrict__ out)
+{
+	uint32_t const bits = 8u >> bsh, smask = (1u << bits) - 1u;
+	uint32_t mx = 0;
+	for (uint64_t c = blockIdx.x; c < ncols; c += gridDim.x)
+		for (uint32_t b = threadIdx.x; b < col_bytes; b += 256u)
+		{
+			uint32_t const v = msa[c * ld + b];
+			// the last byte of a column may hold fewer rows than it has room for (the rest is padding)
+			uint32_t const rows = (b + 1u == col_bytes && tail_rows) ? tail_rows : (1u << bsh);
+			for (uint32_t j = 0; j < rows; ++j) mx = max(mx, (v >> (j * bits)) & smask);
+		}
+	mx = max(mx, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, mx));
+	mx = max(mx, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, mx));
+	mx = max(mx, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, mx));
+	mx = max(mx, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, mx));
+	mx = max(mx, dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, mx));
+	mx = max(mx, dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, mx));
+	if (lane_id() == 63) atomicMax(out, mx);
+}
+
 struct CodeTable { uint8_t code_of[256]; };
 
 // ... and the encode + transpose + pack: raw[r * n + c] -> code_of[byte] at row r of packed column c; 64 x 64

@@ -42,25 +42,23 @@ int main(int argc, char **argv)
 	for (auto const &n : out_names) if (!aux::create_output(n, overwrite)) return EXIT_FAILURE;
 
 	std::cerr << "Handing input…" << std::endl;                                   // main.cc:201 (sic)
-	std::vector<std::ifstream> ins(in_names.size());
-	std::vector<std::ofstream> outs(in_names.size());
-	for (size_t i = 0; i < in_names.size(); ++i)
-	{
-		ins[i].open(in_names[i], std::ios::binary);
-		if (!ins[i]) { std::cerr << "Unable to open '" << in_names[i] << "'." << std::endl; return EXIT_FAILURE; }
-		outs[i].open(out_names[i], std::ios::binary | std::ios::app);
-	}
+	// One 32 KiB chunk of every text at a time; a file is opened, read at its offset and closed again per chunk
+	// (as the reference does, main.cc fill_buffers / output_buffer_contents), so that thousands of haplotype files
+	// work under the default descriptor limit.
 	size_t const chunk = 32 * 1024;                                             // main.cc:68
 	std::vector<std::string> bufs(in_names.size());
-	std::string mask;
-	while (true)
+	std::string mask, kept;
+	for (std::streamoff offset = 0;; offset += (std::streamoff) chunk)
 	{
 		std::streamsize count = -1;
-		for (size_t i = 0; i < ins.size(); ++i)
+		for (size_t i = 0; i < in_names.size(); ++i)
 		{
+			std::ifstream in(in_names[i], std::ios::binary);
+			if (!in) { std::cerr << "Unable to open '" << in_names[i] << "'." << std::endl; return EXIT_FAILURE; }
+			in.seekg(offset);
 			bufs[i].resize(chunk);
-			ins[i].read(&bufs[i][0], (std::streamsize) chunk);
-			std::streamsize const got = ins[i].gcount();
+			in.read(&bufs[i][0], (std::streamsize) chunk);
+			std::streamsize const got = in.gcount();
 			if (-1 == count) count = got;
 			else if (got != count) { std::cerr << "Got an unexpected number of characters from input." << std::endl; return EXIT_FAILURE; }   // main.cc:92-96
 		}
@@ -74,12 +72,20 @@ int main(int argc, char **argv)
 			if (same) { mask[(size_t) k] = '1'; ++skipped; }
 		}
 		if (skipped != (size_t) count)
-			for (size_t i = 0; i < outs.size(); ++i)
+			for (size_t i = 0; i < out_names.size(); ++i)
+			{
+				kept.clear();
 				for (std::streamsize k = 0; k < count; ++k)
-					if ('0' == mask[(size_t) k]) outs[i].put(bufs[i][(size_t) k]);
+					if ('0' == mask[(size_t) k]) kept.push_back(bufs[i][(size_t) k]);
+				std::ofstream out(out_names[i], std::ios::binary | std::ios::app);
+				if (!out) { std::cerr << "Unable to open the output file '" << out_names[i] << "'." << std::endl; return EXIT_FAILURE; }
+				out.write(kept.data(), (std::streamsize) kept.size());
+				out.flush();
+				if (!out) { std::cerr << "Unable to write to '" << out_names[i] << "'." << std::endl; return EXIT_FAILURE; }
+			}
 		std::cout << mask;
+		if (count < (std::streamsize) chunk) break;
 	}
-	for (auto &o : outs) o.flush();
 	std::cout << std::endl;
 	return EXIT_SUCCESS;
 }

@@ -27,6 +27,34 @@ def _texts(rng, m, n, identity_frac):
     return t
 
 
+def test_remove_identity_columns_with_more_texts_than_descriptors(tools, tmp_path):
+    """Thousands of haplotype files must not need thousands of open descriptors (the reference reopens every file
+    per 32 KiB chunk, remove-identity-columns/main.cc fill_buffers; round-1 advice): 200 texts under a limit of 64."""
+    import resource
+    rng = np.random.default_rng(9)
+    m, n = 200, 40000
+    t = _texts(rng, m, n, 0.5)
+    src, work = tmp_path / "src", tmp_path / "work"
+    src.mkdir()
+    work.mkdir()
+    names = []
+    for i in range(m):
+        (src / ("h%d.txt" % i)).write_bytes(bytes(t[i]))
+        names.append(str(src / ("h%d.txt" % i)))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+
+    def limit():
+        resource.setrlimit(resource.RLIMIT_NOFILE, (64, 64))
+
+    r = subprocess.run([tools["remove_identity_columns"], "-i", str(tmp_path / "list.txt")], cwd=work, capture_output=True, timeout=300, preexec_fn=limit)
+    assert r.returncode == 0, r.stderr
+    want_mask = "".join("1" if len(set(t[:, c].tolist())) == 1 else "0" for c in range(n))
+    assert r.stdout.decode().strip() == want_mask
+    keep = np.array([ch == "0" for ch in want_mask])
+    for i in (0, 77, m - 1):
+        assert (work / ("h%d.txt" % i)).read_bytes() == bytes(t[i][keep])
+
+
 @pytest.mark.parametrize("m,n", [(5, 300), (12, 70000), (3, 32768)])      # 70000 > two 32 KiB chunks
 def test_remove_then_insert_identity_columns_round_trip(tools, tmp_path, m, n):
     rng = np.random.default_rng(n)

@@ -398,15 +398,16 @@ def test_degenerate_alignments(pkg, name):
     compare_long(pkg, np.ascontiguousarray(msa), 10, block_len=37)
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("FSEQ_TEST_C4"), reason="125 GB of HBM and ~1 minute: set FSEQ_TEST_C4=1")
-def test_config_c4_full_size_properties(pkg):
-    """BASELINE config C4 at full size on one GPU (m = 100,000 x n = 5,000,000, 2 bits per cell): the
-    size-independent properties, and oracle parity of the DP on a column prefix of the same alignment."""
-    c = fso.CONFIGS["C4"]
-    m, n, L = c["m"], c["n"], c["L"]
-    ctx = pkg.SegmentationContext(m, n, L)
-    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
-    res = ctx.run()
+def _free_hbm_bytes():
+    import torch
+    free, _total = torch.cuda.mem_get_info(0)
+    return free
+
+
+def check_full_size_properties(pkg, ctx, res, m, n, L, prefix_cols):
+    """What holds at any size: the traceback tiles [0, n) with segments of length >= L, the merged segments are a
+    coarsening of it, sizes are what the boundary states say (#{d > lb}), and -- a DP cell depends on nothing behind
+    its own column -- the DP array on a column prefix equals the oracle's run on that prefix alone."""
     tb = ctx.traceback()
     red = ctx.reduced_traceback()
     assert tb["lb"][0] == 0 and tb["rb"][-1] == n
@@ -420,14 +421,39 @@ def test_config_c4_full_size_properties(pkg):
         assert np.array_equal(np.sort(a), np.arange(m))
         assert int((d > red["lb"][i]).sum()) == red["segment_size"][i]
         assert d[0] == red["rb"][i]
-    # the DP array on the first columns does not depend on the columns behind them: compare with the oracle
-    # run on a prefix (cells with end <= ncols - L have seen everything they depend on)
-    ncols = 2400
     lb, mx, sz = ctx.debug_dp()
-    ref = fso.segment_long(ctx.get_sequences(0, ncols), L, keep_dp=True, threads=8)
-    k = ncols - 2 * L                                        # DP entries of regular cells of the prefix run
+    ref = fso.segment_long(ctx.get_sequences(0, prefix_cols), L, keep_dp=True, threads=8)
+    k = prefix_cols - 2 * L                                  # DP entries of regular cells of the prefix run
     assert np.array_equal(mx[:k], ref["dp"]["segment_max_size"][:k])
     assert np.array_equal(lb[:k], ref["dp"]["lb"][:k].astype(np.uint32))
+    assert np.array_equal(sz[:k], ref["dp"]["segment_size"][:k])
+
+
+def test_config_c5_full_size_properties(pkg):
+    """BASELINE config C5 at full size (m = 10,000 x n = 1,000,000, sigma = 16, 4 bits per cell, 16-bit LDS state)."""
+    c = fso.CONFIGS["C5"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    t = ctx.timings()
+    assert t["dp_chunks"] > 100 and t["dp_sweeps"] < 1000
+    check_full_size_properties(pkg, ctx, res, m, n, L, 6000)
+
+
+def test_config_c4_full_size_properties(pkg):
+    """BASELINE config C4 at full size on one GPU (m = 100,000 x n = 5,000,000, 2 bits per cell, streamed block
+    state): the size-independent properties, and oracle parity of the DP on a column prefix of the same alignment.
+    Needs ~250 GB of free HBM (125 GB alignment + lists + stride states): skipped on a card that has less free."""
+    if _free_hbm_bytes() < 200e9:
+        pytest.skip("less than 200 GB of HBM free")
+    c = fso.CONFIGS["C4"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    check_full_size_properties(pkg, ctx, res, m, n, L, 2400)
+    ctx.close()
 
 
 @pytest.mark.parametrize("bits", [8, 4, 2])
@@ -465,6 +491,30 @@ def test_borrowed_device_columns(pkg, bits):
         assert np.array_equal(red[f], ref["reduced"][f])
     a, d = ctx.boundary_state(len(red) - 1)
     assert np.array_equal(a, ref["a"][len(red) - 1]) and np.array_equal(d, ref["d"][len(red) - 1])
+
+
+def test_borrowed_columns_with_a_code_beyond_sigma_are_refused(pkg):
+    """fseq_set_device_columns trusts nothing: a borrowed code >= sigma would lose its high digits in the 2-bit digit
+    passes and merge with another symbol (round-1 advice) -- one pass over the columns finds it, FSEQ_E_ARG."""
+    import torch
+    m, n = 100, 64
+    cols = np.zeros((n, 112), dtype=np.uint8)
+    cols[:, :m] = np.random.default_rng(1).integers(0, 5, size=(n, m))
+    cols[17, 33] = 5                                          # sigma = 5: codes 0..4 only
+    dev = torch.from_numpy(cols).to("cuda")
+    ctx = pkg.SegmentationContext(m, n, 8)
+    with pytest.raises(pkg.FseqError) as e:
+        ctx.set_device_columns(dev.data_ptr(), 112, 5, keepalive=dev)
+    assert e.value.code == pkg.FSEQ_E_ARG and "code 5" in str(e.value)
+    cols[17, 33] = 4
+    dev2 = torch.from_numpy(cols).to("cuda")
+    ctx.set_device_columns(dev2.data_ptr(), 112, 5, keepalive=dev2)
+    # padding behind the last row of a packed column is not a code: m = 5 rows at 4 bits, garbage in the spare nibble
+    pk = np.zeros((16, 16), dtype=np.uint8)
+    pk[:, 2] = 0xF2                                           # row 4 = code 2, spare high nibble = 15
+    devp = torch.from_numpy(pk).to("cuda")
+    c2 = pkg.SegmentationContext(5, 16, 4)
+    c2.set_device_columns_packed(devp.data_ptr(), 16, 3, 4, keepalive=devp)
 
 
 def _random_case(rng):
@@ -618,9 +668,9 @@ def test_speculative_dp_with_short_lists_retries(pkg, monkeypatch):
 
 
 def test_host_flag_overlap_under_load(pkg, monkeypatch):
-    """The path large 16-bit inputs take by themselves (one phase C launch flagging the host, resumed DP launches
-    beside it), repeated while another context keeps the chip unevenly busy: every run must equal the run
-    with the overlap switched off."""
+    """The serial DP beside phase C (round 1's path for large inputs, still there under FSEQ_HOST_FLAGS: one phase C
+    launch flagging the host, resumed DP launches beside it), repeated while another context keeps the chip unevenly
+    busy: every run must equal the default run (chunk-speculative DP after phase C)."""
     import threading
     m, n, L = 10000, 600000, 100                      # 600 blocks of 1000 columns, one workgroup per CU
     monkeypatch.setenv("FSEQ_NO_HOST_FLAGS", "1")
@@ -631,6 +681,7 @@ def test_host_flag_overlap_under_load(pkg, monkeypatch):
     a0, d0 = ref.boundary_state(len(want) // 2)
     ref.close()
     monkeypatch.delenv("FSEQ_NO_HOST_FLAGS")
+    monkeypatch.setenv("FSEQ_HOST_FLAGS", "1")
     monkeypatch.setenv("FSEQ_POISON_LISTS", "1")
     stop = []
 
