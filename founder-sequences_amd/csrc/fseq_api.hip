@@ -56,7 +56,8 @@ hipError_t allow_lds(K kernel, size_t bytes)
 	return hipFuncSetAttribute(reinterpret_cast<void const *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
 }
 
-template <int T, int E, int SIGMA, bool PK>
+// EW: phase C keeps wave 0 free of rows for the per-column list (k_columns, fseq_kernels.hpp): m <= (T - 64) * E
+template <int T, int E, int SIGMA, bool PK, bool EW = false>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0)
@@ -85,13 +86,13 @@ struct Launch {
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
 	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
+		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
 		                   snap_stride, ss_a, ss_d, block0, done_host, epoch);
 	}
 	static uint32_t columns_resident(size_t lds)
 	{
 		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns<T, E, SIGMA, PK>, T, lds) != hipSuccess || nb < 1) nb = 1;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns<T, E, SIGMA, PK, EW>, T, lds) != hipSuccess || nb < 1) nb = 1;
 		return (uint32_t) nb;
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -106,7 +107,7 @@ struct Launch {
 		hipError_t e;
 		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>())) != hipSuccess) return e;
 		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_columns<T, E, SIGMA, PK>, lds_columns)) != hipSuccess) return e;
+		if ((e = allow_lds(k_columns<T, E, SIGMA, PK, EW>, lds_columns)) != hipSuccess) return e;
 		if ((e = allow_lds(k_chain<T, E, PK>, chain_lds_bytes<T, E, PK>())) != hipSuccess) return e;
 		return hipSuccess;
 	}
@@ -126,21 +127,33 @@ struct Launch {
 
 bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 {
+	if (sigma > 256) return false;
+	// 1024-thread configurations spare wave 0 for the per-column lists when the rows allow it (measured: C5 phase C
+	// 86 -> 75 ms with it, while 512-thread workgroups lose as much to the longer per-thread chunks as they gain)
+	bool const ew_ok = !getenv("FSEQ_NO_EMITTER_WAVE");
+#define FSEQ_TRY_EW(T_, E_, PK_)                                                               \
+	if (ew_ok && m <= (uint32_t) ((T_) - 64) * (E_))                                           \
+	{                                                                                          \
+		*out = Launch<T_, E_, 4, PK_, true>::make();                                            \
+		return true;                                                                           \
+	}
 #define FSEQ_TRY(T_, E_, PK_)                                                                  \
 	if (m <= (uint32_t) (T_) * (E_))                                                           \
 	{                                                                                          \
 		*out = Launch<T_, E_, 4, PK_>::make();                                                  \
 		return true;                                                                           \
 	}
-	if (sigma > 256) return false;
 	FSEQ_TRY(64, 1, false)
 	FSEQ_TRY(64, 7, false)
 	FSEQ_TRY(256, 5, false)
 	FSEQ_TRY(512, 5, false)
 	FSEQ_TRY(512, 7, false)
+	FSEQ_TRY_EW(1024, 7, false)
 	FSEQ_TRY(1024, 7, false)
-	FSEQ_TRY(1024, 11, true)      // 16-bit LDS state: m <= 11,264 (BASELINE config C5)
+	FSEQ_TRY_EW(1024, 11, true)   // 16-bit LDS state: m <= 10,560 with the list wave (BASELINE config C5), 11,264 without
+	FSEQ_TRY(1024, 11, true)
 #undef FSEQ_TRY
+#undef FSEQ_TRY_EW
 	return false;
 }
 

@@ -199,11 +199,29 @@ struct TileCarry {
 // __syncthreads(); the caller must barrier again before the scratch is reused.
 // TILE: the T*E positions are one tile of a longer order; *tc carries the prefix of the tiles
 // before it (and is advanced past this tile), bucket starts come from tc->start.
-template <int T, int E, int SIGMA, bool TILE = false>
+// IDLE0: wave 0 owns no rows (phase C keeps it free for the per-column list, fseq_kernels.hpp): it contributes the
+// identity summary and skips the arithmetic, but meets the step's barrier.
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
 	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr)
 {
+	if (IDLE0 && wave_id() == 0)
+	{
+		static_assert(!IDLE0 || (T / WAVE > 1 && !TILE), "an idle wave needs other waves");
+		if (lane_id() == 63)
+		{
+#pragma unroll
+			for (int i = 0; i < SIGMA / 2; ++i) scr.cnt[0][i] = 0;
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) scr.val[0][x] = 0;
+			scr.has[0] = 0;
+		}
+#pragma unroll
+		for (int e = 0; e < E; ++e) { dst[e] = 0; dnew[e] = 0; }
+		__syncthreads();
+		return;
+	}
 	static_assert(!TILE || (SIGMA == 4 && T / WAVE > 4), "tile mode: 4 buckets, second-level scan path");
 	static_assert(E <= 15, "local counts are nibble-packed");
 	static_assert(SIGMA == 4 || SIGMA == 16, "sigma instantiations");

@@ -220,9 +220,9 @@ __global__ __launch_bounds__(256) void k_encode_transpose(
 // PK ("packed") kernels keep row ids -- and, where the values allow it, divergences -- as 16-bit
 // LDS words: m <= 65535 rows then fit the 160 KiB of a CU (BASELINE config C5: m = 10,000).
 template <int T, int E, typename PA, typename PD>
-__device__ __forceinline__ void read_chunk(PA const *a_l, PD const *d_l, uint32_t (&a)[E], uint32_t (&d)[E])
+__device__ __forceinline__ void read_chunk(PA const *a_l, PD const *d_l, uint32_t (&a)[E], uint32_t (&d)[E], uint32_t p0 = 0xFFFFFFFFu)
 {
-	uint32_t const p0 = threadIdx.x * E;
+	if (p0 == 0xFFFFFFFFu) p0 = threadIdx.x * E;
 #pragma unroll
 	for (int e = 0; e < E; ++e) { a[e] = a_l[p0 + e]; d[e] = d_l[p0 + e]; }
 }
@@ -641,8 +641,12 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 }
 
 // header of a per-column list: {n_entries, cnt0, complete, cum}
-template <int T, int E, int SIGMA, bool PK>
-__global__ __launch_bounds__(T) void k_columns(
+// EW ("emitter wave"): wave 0 owns no rows -- thread t >= 64 owns the positions (t - 64) * E .. -- and spends its
+// time on the per-column list alone.  Measured on BASELINE C3: with the list on a wave that also carries 1/8 of the
+// rows, the list's serial chain (~150 instructions under 8-way issue contention) stretched EVERY column's critical
+// path: 2.9 of 10.8 ms.  Needs m <= (T - 64) * E.
+template <int T, int E, int SIGMA, bool PK, bool EW = false>
+__global__ __launch_bounds__(T, 4) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
@@ -665,7 +669,8 @@ __global__ __launch_bounds__(T) void k_columns(
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
 
 	uint32_t const tid = threadIdx.x;
-	uint32_t const p0 = tid * E;
+	uint32_t const p0 = EW ? (tid >= 64u ? (tid - 64u) * E : 0x7FFF0000u) : tid * E;     // 0x7FFF0000: owns nothing (every p0 + e >= m)
+	bool const rows = !EW || tid >= 64u;
 	uint64_t const k0 = (uint64_t) (blockIdx.x + block0) * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	uint32_t const nb = (uint32_t) (kend - k0);
@@ -742,7 +747,8 @@ __global__ __launch_bounds__(T) void k_columns(
 		}
 	}
 #pragma unroll
-	for (int e = 0; e < E; ++e) { a_l[p0 + e] = (AT) a[e]; d_l[p0 + e] = (AT) id[e]; }
+	for (int e = 0; e < E; ++e)
+		if (rows) { a_l[p0 + e] = (AT) a[e]; d_l[p0 + e] = (AT) id[e]; }
 
 	bool const has_chunk = tid * 16u < sym_bytes(m, bsh);
 	uint4 nxt = make_uint4(0, 0, 0, 0);
@@ -766,11 +772,11 @@ __global__ __launch_bounds__(T) void k_columns(
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
 			uint32_t s[E], dst[E], dnew[E];
-			read_chunk<T, E>(a_l, d_l, a, d);
+			if (rows) read_chunk<T, E>(a_l, d_l, a, d, p0);
 #pragma unroll
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
-			partition_step<T, E, SIGMA>(d, s, D0 + j, scr, dst, dnew);
+			partition_step<T, E, SIGMA, false, EW>(d, s, D0 + j, scr, dst, dnew);
 
 #pragma unroll
 			for (int e = 0; e < E; ++e)
@@ -816,33 +822,67 @@ __global__ __launch_bounds__(T) void k_columns(
 		// count, so the list always reaches X counts past the smallest value the cell can take).
 		if (wave_id() == 0)
 		{
+			// The list is one wave's serial chain (LDS reads -> scan -> ballots -> stores) on every column's critical
+			// path: issue priority over the other waves of the SIMD, and four ids per lane (256 per step) -- the id
+			// space is sparse (one id per column and boundary value, most of them with count 0 by now), so a step of
+			// 64 ids needed 5-8 rounds of that chain per column, 256 need 1-2.
+			__builtin_amdgcn_s_setprio(3);
 			uint32_t const lane = lane_id();
 			uint64_t const k = k0 + j;
 			uint32_t const thr = (k + 2 > (uint64_t) L) ? (uint32_t) (k + 2 - L) : 0u;
 			uint2 *out = ent + k * (size_t) stride;
 			int32_t const top = (int32_t) (D0 + j);
 			uint32_t cumN = 0, nent = 1, R = 0;       // cumN: count of the values below thr taken so far
-			for (int32_t base = top; base >= 0; base -= 64)
+			for (int32_t base = top; base >= 0; base -= 256)
 			{
-				int32_t const i = base - (int32_t) lane;
-				uint32_t const c = (i >= 0) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
-				uint32_t const v = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
-				bool const nz = c > 0;
-				bool const rec = nz && v >= thr;
-				uint32_t const inc = wave_incl_add(c);
-				uint64_t const rmask = __ballot(rec);       // values descend with the lane: a prefix of the non-zero lanes
-				uint32_t const r_inc = rmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(rmask)) : 0u;
-				uint32_t const excN = cumN + (inc - r_inc) - c;
-				bool const take = nz && !rec && excN <= X;
-				uint64_t const omask = __ballot(nz && !rec);
-				uint32_t const pos = nent + (uint32_t) __popcll(omask & ((1ull << lane) - 1ull));
-				if (take) out[pos] = make_uint2(v, c);
-				uint64_t const tmask = __ballot(take);
-				nent += (uint32_t) __popcll(tmask);
-				uint32_t const t_inc = tmask ? shfl_u32(inc, 63 - (int) __builtin_clzll(tmask)) : r_inc;
-				cumN += t_inc - r_inc;
-				R += r_inc;
-				if (tmask != omask || cumN > X) break;
+				// lane l holds the ids base - 4l - q, q = 0..3: descending ids = descending values, lane-major
+				uint32_t c[4], v[4];
+				uint32_t lane_c = 0, lane_o = 0, lane_rc = 0;
+				bool cand[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					int32_t const i = base - 4 * (int32_t) lane - q;
+					c[q] = (i >= 0) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
+					v[q] = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
+					bool const nz = c[q] > 0;
+					bool const rec = nz && v[q] >= thr;       // the values >= thr are a prefix of the non-zero entries
+					cand[q] = nz && !rec;
+					lane_c += c[q];
+					lane_o += cand[q] ? 1u : 0u;
+					lane_rc += rec ? c[q] : 0u;
+				}
+				// one scan for the counts (< 2^16 in all: m <= 65535) and the candidate numbers, one for the lump
+				uint32_t const inc = wave_incl_add(lane_c | (lane_o << 16));
+				uint32_t const r_tot = readlane_u32(wave_incl_add(lane_rc), 63);
+				uint32_t const tot_o = readlane_u32(inc, 63) >> 16;
+				uint32_t run_c = (inc & 0xFFFFu) - lane_c;   // counts in front of this lane's entries
+				uint32_t run_o = (inc >> 16) - lane_o;       // candidates in front of them
+				uint32_t lastP = 0;
+				bool tk[4];
+#pragma unroll
+				for (int q = 0; q < 4; ++q)
+				{
+					// a candidate is taken while the below-thr counts in front of it do not exceed X
+					uint32_t const excN = cumN + run_c - r_tot;
+					tk[q] = cand[q] && excN <= X;
+					if (tk[q]) { out[nent + run_o] = make_uint2(v[q], c[q]); lastP = excN + c[q]; }
+					run_o += cand[q] ? 1u : 0u;
+					run_c += c[q];
+				}
+				uint32_t const taken = (uint32_t) (__popcll(__ballot(tk[0])) + __popcll(__ballot(tk[1])) + __popcll(__ballot(tk[2])) + __popcll(__ballot(tk[3])));
+				// the taken entries are a prefix of the candidates: the largest inclusive count among them is the new cumN
+				uint32_t mx = lastP;
+				mx = max(mx, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, mx));
+				mx = max(mx, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, mx));
+				mx = max(mx, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, mx));
+				mx = max(mx, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, mx));
+				mx = max(mx, dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, mx));
+				mx = max(mx, dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, mx));
+				nent += taken;
+				if (taken) cumN = readlane_u32(mx, 63);
+				R += r_tot;
+				if (taken != tot_o || cumN > X) break;
 			}
 			uint32_t const cum = R + cumN;
 			if (lane == 0)
@@ -850,6 +890,7 @@ __global__ __launch_bounds__(T) void k_columns(
 				out[0] = make_uint2((uint32_t) (k + 1), R);
 				hdr[k] = make_uint4(nent, zero_present ? cnt_get<PK>(cnt_l, 0u) : 0u, cum == m ? 1u : 0u, cum);
 			}
+			__builtin_amdgcn_s_setprio(0);
 		}
 	}
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
