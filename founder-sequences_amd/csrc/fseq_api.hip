@@ -259,7 +259,9 @@ struct fseq_ctx {
 	// results
 	bool have_result = false;
 	fseq_result res{};
-	std::vector<uint32_t> h_LB, h_M, h_SZ;
+	std::vector<uint32_t> h_LBv;             // the lb chain the traceback walk follows (pageable on purpose, see run_long_path)
+	uint32_t *h_LB = nullptr;                // pinned: the walk's index / result lists
+	size_t h_LB_cap = 0;
 	std::vector<fseq_dp_arg> traceback;
 	std::vector<fseq_segment> segments;
 	std::vector<uint32_t> sp_first, sp_len;
@@ -452,7 +454,7 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_columns_stream, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
 		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
-		c->bk_cap_words = 18432;
+		c->bk_cap_words = 12288;                               // two bitmaps + 32-bit prefix counts: 12 B per word
 		if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) c->bk_cap_words = (uint32_t) std::max(2048, atoi(e));
 		c->bk_lds = blockkeys_stream_lds_bytes(c->bk_cap_words, 1024);
 		if (c->bk_lds <= LDS_LIMIT) HIP_TRY(c, allow_lds(k_blockkeys_stream, c->bk_lds));
@@ -470,7 +472,7 @@ int prepare_geometry(fseq_ctx *c)
 			size_t const arrays = blockkeys_lds_bytes(p.m, 0, (int) c->ks.T, c->ld, c->bsh);
 			size_t budget = 76 * 1024;
 			if (arrays + 6 * 4096 > budget) budget = LDS_LIMIT - 1024;
-			size_t cap = (budget - arrays) / 6;
+			size_t cap = (budget - arrays) / 10;                  // two bitmaps (4 B) + a 16-bit prefix count per word
 			cap = std::min<size_t>(cap & ~size_t(63), 32768);
 			if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) cap = (size_t) std::max(2048, atoi(e));     // tests: force the fallback
 			c->bk_cap_words = (uint32_t) cap;
@@ -697,24 +699,42 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	return FSEQ_OK;
 }
 
-// host-side traceback walk: segmentation_lp_context.cc:191-224
-void follow_traceback(fseq_ctx *c)
+// host-side traceback walk: segmentation_lp_context.cc:191-224.  Only the lb chain comes to the host (pinned
+// memory); the keys and sizes of the visited entries are gathered on the device afterwards.
+int follow_traceback(fseq_ctx *c, hipStream_t st)
 {
 	uint64_t const L = c->p.segment_length;
 	c->traceback.clear();
 	uint64_t arg_idx = c->dp_size - 1;
+	double const t0 = now_ms();
 	while (true)
 	{
 		fseq_dp_arg e;
-		e.lb = c->h_LB[arg_idx];
+		e.lb = c->h_LBv[arg_idx];
 		e.rb = arg_idx + L;
-		e.segment_max_size = c->h_M[arg_idx];
-		e.segment_size = c->h_SZ[arg_idx];
+		e.segment_max_size = e.segment_size = 0;
 		c->traceback.push_back(e);
 		if (0 == e.lb) break;
+		if (e.lb < L || e.lb - L >= arg_idx) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend");
 		arg_idx = e.lb - L;
 	}
 	std::reverse(c->traceback.begin(), c->traceback.end());
+	if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: lb chain walked in %.3f ms\n", now_ms() - t0);
+	size_t const S = c->traceback.size();
+	int rc;
+	if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
+	if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
+	// indices up, (key, size) pairs down: through the pinned words behind the lb chain (3 S <= 3 (n / L + 1))
+	uint32_t *const idx = c->h_LB;
+	uint2 *const ms = reinterpret_cast<uint2 *>(idx + ((S + 1) & ~size_t(1)));
+	for (size_t j = 0; j < S; ++j) idx[j] = (uint32_t) (c->traceback[j].rb - L);
+	uint32_t *d_idx = reinterpret_cast<uint32_t *>(c->d_cols);
+	HIP_TRY(c, hipMemcpyAsync(d_idx, idx, S * 4, hipMemcpyHostToDevice, st));
+	hipLaunchKernelGGL(k_gather_pairs, dim3((uint32_t) ((S + 255) / 256)), dim3(256), 0, st, d_idx, (uint32_t) S, c->dp.M, c->dp.SZ, c->d_tau);
+	HIP_TRY(c, hipMemcpyAsync(ms, c->d_tau, S * 8, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	for (size_t j = 0; j < S; ++j) { c->traceback[j].segment_max_size = ms[j].x; c->traceback[j].segment_size = ms[j].y; }
+	return FSEQ_OK;
 }
 
 // ---- launches: LDS-resident kernels, or their HBM-streamed counterparts for large m
@@ -1339,11 +1359,20 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
 		HIP_TRY(c, hipGetLastError());
 
-		c->h_LB.resize(c->dp_size); c->h_M.resize(c->dp_size); c->h_SZ.resize(c->dp_size);
+		if (c->h_LB_cap < c->dp_size)
+		{
+			if (c->h_LB) (void) hipHostFree(c->h_LB);
+			c->h_LB = nullptr; c->h_LB_cap = 0;
+			size_t const extra = 3 * (size_t) (n / L + 2) + 8;    // the walk's index and (key, size) lists
+			HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_LB), extra * 4, hipHostMallocDefault));
+			c->h_LB_cap = c->dp_size;
+			c->h_LBv.resize(c->dp_size);
+		}
 		uint32_t h_flags[4] = {0, 0, 0, 0};
-		HIP_TRY(c, hipMemcpyAsync(c->h_LB.data(), c->dp.LB, c->dp_size * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(c, hipMemcpyAsync(c->h_M.data(), c->dp.M, c->dp_size * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(c, hipMemcpyAsync(c->h_SZ.data(), c->dp.SZ, c->dp_size * 4, hipMemcpyDeviceToHost, st));
+		// The lb chain goes to PAGEABLE memory on purpose: the runtime's staged copy leaves it in the host's caches,
+		// and the walk is a chain of dependent random reads (measured on C3, 6156 hops: 1.4 ms on DMA-written pinned
+		// memory against 0.1 ms here; the staged copy of 4 MB costs 0.25 ms more than the pinned one).
+		HIP_TRY(c, hipMemcpyAsync(c->h_LBv.data(), c->dp.LB, c->dp_size * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
 		if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipStreamSynchronize(st));
@@ -1386,7 +1415,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 
 		if (!overflow)
 		{
-			follow_traceback(c);
+			if ((rc = follow_traceback(c, st))) return rc;
+			if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: traceback walk + gather %.3f ms\n", now_ms() - th0);
 			uint32_t const max_seg = c->traceback.back().segment_max_size;
 			c->res.max_segment_size = max_seg;
 			c->res.dp_segment_count = c->traceback.size();
@@ -1476,6 +1506,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			}
 		}
 		ms_host += now_ms() - th0;
+		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: traceback + merge %.3f ms\n", now_ms() - th0);
 		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
 		if (!overflow) break;
 		if (X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
@@ -1737,6 +1768,7 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
 	if (c->h_done) (void) hipHostFree(c->h_done);
+	if (c->h_LB) (void) hipHostFree(c->h_LB);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;
@@ -2022,9 +2054,10 @@ int fseq_short_path_runs(fseq_ctx *c, uint32_t *first_idx, uint32_t *run_len)
 int fseq_debug_dp(fseq_ctx *c, uint32_t *lb, uint32_t *max_size, uint32_t *size)
 {
 	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	if (lb) std::copy(c->h_LB.begin(), c->h_LB.end(), lb);
-	if (max_size) std::copy(c->h_M.begin(), c->h_M.end(), max_size);
-	if (size) std::copy(c->h_SZ.begin(), c->h_SZ.end(), size);
+	(void) hipSetDevice(c->p.device);
+	if (lb) HIP_TRY(c, hipMemcpy(lb, c->dp.LB, c->dp_size * 4, hipMemcpyDeviceToHost));
+	if (max_size) HIP_TRY(c, hipMemcpy(max_size, c->dp.M, c->dp_size * 4, hipMemcpyDeviceToHost));
+	if (size) HIP_TRY(c, hipMemcpy(size, c->dp.SZ, c->dp_size * 4, hipMemcpyDeviceToHost));
 	return FSEQ_OK;
 }
 

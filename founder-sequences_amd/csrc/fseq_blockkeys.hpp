@@ -29,17 +29,17 @@ namespace fseq {
 constexpr uint32_t BK_GL = 3;                 // 2^3 leaves per group (64 columns at 2 bits per symbol)
 constexpr uint32_t BK_LEAF_BITS = 65536;      // one bit per 16-bit leaf word
 
-// LDS of the LDS-resident tree: prefix ids + (GL + 1) stack arrays of m u16, bitmap words + one u16 prefix count per
+// LDS of the LDS-resident tree: prefix ids + (GL + 1) stack arrays of m u16, two bitmaps + one u16 prefix count per
 // word, the block scan scratch, the staged columns of one leaf (8 >> (2 - bsh) columns of ld bytes)
 __host__ __device__ inline size_t blockkeys_lds_bytes(uint32_t m, uint32_t cap_words, int T, size_t ld = 0, uint32_t bsh = 2)
 {
-	return carve_bytes(m, 2) * (BK_GL + 2) + carve_bytes(cap_words, 4) + carve_bytes(cap_words, 2) + carve_bytes((size_t) T / WAVE + 1, 4)
+	return carve_bytes(m, 2) * (BK_GL + 2) + 2 * carve_bytes(cap_words, 4) + carve_bytes(cap_words, 2) + carve_bytes(2 * ((size_t) T / WAVE + 1), 4)
 	     + carve_bytes((size_t) (8u >> (2u - bsh)) * ld + 16, 1);
 }
 // ... of the streamed tree: bitmap + 32-bit prefix counts + scan scratch
 __host__ __device__ inline size_t blockkeys_stream_lds_bytes(uint32_t cap_words, int T)
 {
-	return carve_bytes(cap_words, 4) * 2 + carve_bytes((size_t) T / WAVE + 1, 4);
+	return carve_bytes(cap_words, 4) * 3 + carve_bytes(2 * ((size_t) T / WAVE + 1), 4);
 }
 
 // halfwords per block of the HBM scratch of the LDS-resident tree: leaf words [nleaf][m] and group ids [ngrp][m], u16
@@ -59,42 +59,35 @@ __host__ __device__ inline size_t blockkeys_stream_ws_words(uint32_t m, uint32_t
 
 template <typename IdT, typename PrefT>
 struct BkState {
+	// (no arrays in here: a dynamically indexed member would move the whole struct to scratch memory)
 	IdT *acc;                      // ids over the columns merged so far
-	IdT *stk[BK_GL + 1];           // DFS stack of id arrays inside a group
-	uint32_t *bm;
+	IdT *stk0;                     // DFS stack of id arrays inside a group: level i at stk0 + i * stk_stride
+	size_t stk_stride;
+	uint32_t *bm0;                 // two bitmaps of cap_words, used alternately: the idle one is cleared while the other is summed
 	PrefT *pref;
-	uint32_t *sscr;
+	uint32_t *sscr;                // two scan scratch areas of T / 64 + 1 words, alternating as well
 	uint32_t cap_words;
+	uint32_t turn;                 // rank operations done so far (selects the bitmap)
+	uint32_t used_a, used_b;       // words of bitmap 0 / 1 that may be non-zero
+	__device__ __forceinline__ IdT *stk(uint32_t i) const { return stk0 + (size_t) i * stk_stride; }
 };
-
-// prefix popcounts of the bitmap words [0, W): pref[w] = number of set bits in front of word w; returns the total
-template <int T, typename PrefT>
-__device__ __forceinline__ uint32_t bk_prefix(uint32_t const *bm, PrefT *pref, uint32_t W, uint32_t *sscr)
-{
-	uint32_t const tid = threadIdx.x;
-	uint32_t const per = (W + T - 1) / T, w0 = tid * per;
-	uint32_t s = 0;
-	for (uint32_t q = 0; q < per; ++q)
-		if (w0 + q < W) s += (uint32_t) __popc(bm[w0 + q]);
-	uint32_t total;
-	uint32_t run = block_excl_add<T>(s, sscr, &total);
-	for (uint32_t q = 0; q < per; ++q)
-		if (w0 + q < W) { pref[w0 + q] = (PrefT) run; run += (uint32_t) __popc(bm[w0 + q]); }
-	__syncthreads();
-	return total;
-}
 
 // Dense rank of (hi[r], lo[r]) over the rows, hi the more significant (later columns); hi == nullptr: of lo[r] alone
 // (a leaf: Dlo = 65536 possible words).  The Dhi x Dlo bitmap is processed in slices of whole hi values when it
 // exceeds the LDS budget (very diverse blocks): a slice ranks the rows whose hi falls into it, earlier slices hold
 // the smaller keys.  out may alias lo.  Every row is read and written by the same thread in every pass.
+// Three barriers per slice: [set bits] | [popcount my words; clear the OTHER bitmap for the next rank] | [prefix
+// over the threads -> per-word prefix counts] | [look the rows up].  The bitmap of this call was cleared during the
+// call before (both are cleared once at kernel start); nothing here waits for the look-ups of the call before --
+// they only read the other bitmap and the prefix counts, which are rewritten behind this call's second barrier.
 template <int T, typename IdT, typename PrefT>
-__device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> const &S, uint32_t m, uint32_t Dlo, uint32_t Dhi, IdT const *lo, IdT const *hi,
+__device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m, uint32_t Dlo, uint32_t Dhi, IdT const *lo, IdT const *hi,
                                              IdT *out, uint32_t *sliced)
 {
 	// rows per thread and step: the 32-bit ids of the streamed regime live in HBM / L2 -- eight independent loads in
 	// flight per thread instead of one round trip per row
-	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 1u;
+	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 4u;
+	constexpr uint32_t NW = T / WAVE;
 	uint32_t const tid = threadIdx.x;
 	uint32_t const cap_bits = S.cap_words * 32u;
 	uint32_t const hps = ((uint64_t) Dlo * Dhi <= cap_bits) ? Dhi : max(1u, cap_bits / Dlo);     // hi values per slice (Dlo <= cap_bits)
@@ -104,8 +97,12 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> const &S, uint3
 	{
 		uint32_t const h1 = min(Dhi, h0 + hps);
 		uint32_t const W = ((h1 - h0) * Dlo + 31u) >> 5;
-		for (uint32_t w = tid; w < W; w += T) S.bm[w] = 0u;
-		__syncthreads();
+		uint32_t const par = S.turn & 1u;
+		uint32_t *const bm = S.bm0 + par * S.cap_words, *const other = S.bm0 + (par ^ 1u) * S.cap_words;
+		uint32_t *const scr = S.sscr + par * (NW + 1u);
+		uint32_t const other_used = par ? S.used_a : S.used_b;
+		if (par) { S.used_a = 0u; S.used_b = W; } else { S.used_b = 0u; S.used_a = W; }
+		++S.turn;
 		for (uint32_t r0 = tid; r0 < m; r0 += T * U)
 		{
 			uint32_t lv[U], hv[U];
@@ -122,11 +119,33 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> const &S, uint3
 				{
 					uint32_t const k = (hv[u] - h0) * Dlo + lv[u];
 					uint32_t const bit = 1u << (k & 31u);
-					if (!(S.bm[k >> 5] & bit)) atomicOr(&S.bm[k >> 5], bit);   // rows of one founder share keys: most find their bit set
+					if (!(bm[k >> 5] & bit)) atomicOr(&bm[k >> 5], bit);   // rows of one founder share keys: most find their bit set
 				}
 		}
 		__syncthreads();
-		uint32_t const total = bk_prefix<T, PrefT>(S.bm, S.pref, W, S.sscr);
+		// my words' popcounts; the wave totals go to the scan scratch
+		uint32_t const per = (W + T - 1) / T, w0 = tid * per;
+		uint32_t s = 0;
+		for (uint32_t q = 0; q < per; ++q)
+			if (w0 + q < W) s += (uint32_t) __popc(bm[w0 + q]);
+		uint32_t const inc = wave_incl_add(s);
+		if (lane_id() == 63) scr[wave_id()] = inc;
+		// the other bitmap has been read for the last time before this call's first barrier: clear what its last use
+		// may have set, for the next rank operation
+		for (uint32_t w = tid; w < other_used; w += T) other[w] = 0u;
+		__syncthreads();
+		uint32_t pre = 0, total = 0;
+#pragma unroll
+		for (uint32_t w = 0; w < NW; ++w)
+		{
+			uint32_t const x = scr[w];
+			if (w < wave_id()) pre += x;
+			total += x;
+		}
+		uint32_t run = pre + inc - s;
+		for (uint32_t q = 0; q < per; ++q)
+			if (w0 + q < W) { S.pref[w0 + q] = (PrefT) run; run += (uint32_t) __popc(bm[w0 + q]); }
+		__syncthreads();
 		for (uint32_t r0 = tid; r0 < m; r0 += T * U)
 		{
 			uint32_t lv[U], hv[U];
@@ -142,10 +161,9 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> const &S, uint3
 				if (hv[u] >= h0 && hv[u] < h1)
 				{
 					uint32_t const k = (hv[u] - h0) * Dlo + lv[u];
-					out[r0 + u * T] = (IdT) (base + (uint32_t) S.pref[k >> 5] + (uint32_t) __popc(S.bm[k >> 5] & ((1u << (k & 31u)) - 1u)));
+					out[r0 + u * T] = (IdT) (base + (uint32_t) S.pref[k >> 5] + (uint32_t) __popc(bm[k >> 5] & ((1u << (k & 31u)) - 1u)));
 				}
 		}
-		__syncthreads();
 		base += total;
 	}
 	return base;
@@ -155,7 +173,7 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> const &S, uint3
 template <int T, typename IdT>
 __device__ __forceinline__ void bk_copy(uint32_t m, IdT const *__restrict__ src, IdT *__restrict__ dst, IdT *__restrict__ dst2 = nullptr)
 {
-	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 1u;
+	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 4u;
 	for (uint32_t r0 = threadIdx.x; r0 < m; r0 += T * U)
 	{
 		IdT v[U];
@@ -195,25 +213,30 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 	if (!STREAM)
 	{
 		S.acc = cv.take<IdT>(m);
-		for (uint32_t i = 0; i <= BK_GL; ++i) S.stk[i] = cv.take<IdT>(m);
-		S.bm = cv.take<uint32_t>(cap_words);
+		S.stk_stride = carve_bytes(m, sizeof(IdT)) / sizeof(IdT);
+		S.stk0 = cv.take<IdT>(S.stk_stride * (BK_GL + 1));
+		S.bm0 = cv.take<uint32_t>(2 * (size_t) cap_words);
 		S.pref = cv.take<PrefT>(cap_words);
-		S.sscr = cv.take<uint32_t>(T / WAVE + 1);
+		S.sscr = cv.take<uint32_t>(2 * (T / WAVE + 1));
 		sym = cv.take<uint8_t>((size_t) cl * ld + 16);
 		leafw = static_cast<uint16_t *>(scratch_or_ws);
 		grpid = reinterpret_cast<IdT *>(leafw + (size_t) nleaf * m);
 	}
 	else
 	{
-		S.bm = cv.take<uint32_t>(cap_words);
+		S.bm0 = cv.take<uint32_t>(2 * (size_t) cap_words);
 		S.pref = cv.take<PrefT>(cap_words);
-		S.sscr = cv.take<uint32_t>(T / WAVE + 1);
+		S.sscr = cv.take<uint32_t>(2 * (T / WAVE + 1));
 		IdT *w = static_cast<IdT *>(scratch_or_ws);
 		S.acc = w; w += m;
-		for (uint32_t i = 0; i <= BK_GL; ++i) { S.stk[i] = w; w += m; }
+		S.stk0 = w; S.stk_stride = m; w += (size_t) m * (BK_GL + 1);
 		grpid = w;
 	}
 	S.cap_words = cap_words;
+	S.turn = 0;
+	S.used_a = S.used_b = 0;
+	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.bm0[w] = 0u;
+	__syncthreads();
 	uint32_t Dacc = 0, sliced = 0;
 
 	// !STREAM: the columns of a leaf are one contiguous piece of the column-major alignment (cl * ld bytes): 16 bytes
@@ -257,7 +280,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 		{
 			uint64_t const kc = k0 + (uint64_t) l * cl;
 			uint32_t const nc = (uint32_t) min<uint64_t>(cl, kend - kc);
-			IdT *const top = S.stk[sp];
+			IdT *const top = S.stk(sp);
 			if (!STREAM)
 			{
 				fetch(l + 1);
@@ -302,19 +325,20 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 					}
 				}
 			}
+			__syncthreads();                                      // the words were written by row groups, the rank reads them by rows
 			D[sp] = bk_merge<T, IdT, PrefT>(S, m, BK_LEAF_BITS, 1u, top, nullptr, top, &sliced);
 			if (!STREAM) land();                                  // every thread is past the word build (barriers in bk_merge)
 			sz[sp] = 1;
 			++sp;
 			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
 			{
-				D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk[sp - 2], S.stk[sp - 1], S.stk[sp - 2], &sliced);
+				D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced);
 				sz[sp - 2] += sz[sp - 1];
 				--sp;
 			}
 		}
 		// ---- the group joins the prefix
-		IdT *const gi = S.stk[0];
+		IdT *const gi = S.stk(0);
 		if (g == 0)
 		{
 			bk_copy<T, IdT>(m, gi, grpid, S.acc);
@@ -329,7 +353,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 	}
 
 	// ---- outputs: rank of every row, one representative row per distinct key, the divergence in front of each key
-	IdT *const rep = S.stk[1];
+	IdT *const rep = S.stk(1);
 	{
 		constexpr uint32_t U = STREAM ? 8u : 1u;
 		for (uint32_t r0 = tid; r0 < m; r0 += T * U)

@@ -930,6 +930,15 @@ __global__ __launch_bounds__(64) void k_gather_lists(
 		out_ent[(size_t) blockIdx.x * stride + i] = ent[k * (size_t) stride + i];
 }
 
+// out[j] = {a[idx[j]], b[idx[j]]}: the DP entries on the traceback path (the host walks the lb chain, the keys and
+// sizes of the visited entries follow in one small copy)
+__global__ __launch_bounds__(256) void k_gather_pairs(uint32_t const *__restrict__ idx, uint32_t count, uint32_t const *__restrict__ a,
+                                                      uint32_t const *__restrict__ b, uint2 *__restrict__ out)
+{
+	uint32_t const j = blockIdx.x * 256u + threadIdx.x;
+	if (j < count) out[j] = make_uint2(a[idx[j]], b[idx[j]]);
+}
+
 // find_segments_greedy (segmentation_lp_context.cc:335-390) asks, traceback boundary after boundary, whether
 // unique_substring_count_lhs(current_lb) = #{d_rb > current_lb} <= max_segment_size (:363-364).  That holds exactly
 // for current_lb >= tau, tau = the value of the first list entry at which the cumulative count exceeds
