@@ -326,8 +326,10 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 				}
 			}
 			__syncthreads();                                      // the words were written by row groups, the rank reads them by rows
+			// every thread is past this leaf's word build: the next leaf's columns may land in the staging buffer (the
+			// barriers of the rank below stand between this and the next word build)
+			if (!STREAM) land();
 			D[sp] = bk_merge<T, IdT, PrefT>(S, m, BK_LEAF_BITS, 1u, top, nullptr, top, &sliced);
-			if (!STREAM) land();                                  // every thread is past the word build (barriers in bk_merge)
 			sz[sp] = 1;
 			++sp;
 			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))

@@ -658,6 +658,25 @@ def test_phase_a_in_key_space_matches_the_column_sweep(pkg, monkeypatch, mode):
         assert fallbacks == 0
 
 
+def test_repeated_runs_are_bit_identical(pkg):
+    """The same context run again and again (phase A's staged leaf columns, the emitter wave, the speculative DP and
+    the benign races they allow must never show in a result): traceback, segments and a boundary state each time."""
+    for (m, n, L, K, Brec, mu, seed, kind) in [(10000, 1200, 100, 32, 5000, 1e-4, 0x5EED0005, 1), (2500, 20000, 50, 16, 2000, 1e-4, 0x5EED0002, 0)]:
+        ctx = pkg.SegmentationContext(m, n, L)
+        ctx.generate_synthetic(seed, K, Brec, mu, kind)
+        ctx.run()
+        tb0, red0 = ctx.traceback().copy(), ctx.reduced_traceback().copy()
+        a0, d0 = ctx.boundary_state(len(red0) // 2)
+        b0 = ctx.debug_block_state(ctx.timings()["n_blocks"] // 2)
+        for _ in range(12):
+            ctx.run()
+            assert np.array_equal(ctx.traceback(), tb0) and np.array_equal(ctx.reduced_traceback(), red0)
+            a, d = ctx.boundary_state(len(red0) // 2)
+            assert np.array_equal(a, a0) and np.array_equal(d, d0)
+            b = ctx.debug_block_state(ctx.timings()["n_blocks"] // 2)
+            assert np.array_equal(b[0], b0[0]) and np.array_equal(b[1], b0[1])
+
+
 def test_speculative_dp_with_short_lists_retries(pkg, monkeypatch):
     """A list too short to prove a cell is reported per chunk by the sweep that last ran the chunk; the run
     retries with longer lists and stays exact."""
