@@ -259,9 +259,9 @@ struct fseq_ctx {
 	// results
 	bool have_result = false;
 	fseq_result res{};
-	std::vector<uint32_t> h_LBv;             // the lb chain the traceback walk follows (pageable on purpose, see run_long_path)
-	uint32_t *h_LB = nullptr;                // pinned: the walk's index / result lists
-	size_t h_LB_cap = 0;
+	uint4 *d_tb = nullptr;                   // the traceback kernels' output {entry, lb, key, size} per segment, window heads, counts
+	size_t tb_cap = 0;
+	uint32_t tb_win = 0;
 	std::vector<fseq_dp_arg> traceback;
 	std::vector<fseq_segment> segments;
 	std::vector<uint32_t> sp_first, sp_len;
@@ -588,6 +588,7 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
 	dev_free(&c->d_bk); c->bk_blocks = 0; dev_free(&c->d_bkws); c->bkws_words = 0;
+	dev_free(&c->d_tb); c->tb_cap = 0; c->tb_win = 0;
 	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
 	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
 	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
@@ -699,41 +700,41 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	return FSEQ_OK;
 }
 
-// host-side traceback walk: segmentation_lp_context.cc:191-224.  Only the lb chain comes to the host (pinned
-// memory); the keys and sizes of the visited entries are gathered on the device afterwards.
+// follow_traceback (segmentation_lp_context.cc:191-224): the lb chain is followed on the device, window by window
+// (k_tb_windows / k_tb_chain / k_tb_emit, fseq_kernels.hpp); the S visited entries come back in one small copy.
+// Scratch: Mprev (exit pointers) and the first words of K (hop counts) -- both are free once the DP is done.
 int follow_traceback(fseq_ctx *c, hipStream_t st)
 {
-	uint64_t const L = c->p.segment_length;
-	c->traceback.clear();
-	uint64_t arg_idx = c->dp_size - 1;
-	double const t0 = now_ms();
-	while (true)
-	{
-		fseq_dp_arg e;
-		e.lb = c->h_LBv[arg_idx];
-		e.rb = arg_idx + L;
-		e.segment_max_size = e.segment_size = 0;
-		c->traceback.push_back(e);
-		if (0 == e.lb) break;
-		if (e.lb < L || e.lb - L >= arg_idx) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend");
-		arg_idx = e.lb - L;
-	}
-	std::reverse(c->traceback.begin(), c->traceback.end());
-	if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: lb chain walked in %.3f ms\n", now_ms() - t0);
-	size_t const S = c->traceback.size();
+	uint32_t const L = (uint32_t) c->p.segment_length, dp_size = (uint32_t) c->dp_size;
+	size_t const cap = (size_t) (c->p.n / L + 2);           // a segment is at least L columns long
+	uint32_t const nwin = (dp_size + TB_WIN - 1u) / TB_WIN;
 	int rc;
-	if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
-	if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
-	// indices up, (key, size) pairs down: through the pinned words behind the lb chain (3 S <= 3 (n / L + 1))
-	uint32_t *const idx = c->h_LB;
-	uint2 *const ms = reinterpret_cast<uint2 *>(idx + ((S + 1) & ~size_t(1)));
-	for (size_t j = 0; j < S; ++j) idx[j] = (uint32_t) (c->traceback[j].rb - L);
-	uint32_t *d_idx = reinterpret_cast<uint32_t *>(c->d_cols);
-	HIP_TRY(c, hipMemcpyAsync(d_idx, idx, S * 4, hipMemcpyHostToDevice, st));
-	hipLaunchKernelGGL(k_gather_pairs, dim3((uint32_t) ((S + 255) / 256)), dim3(256), 0, st, d_idx, (uint32_t) S, c->dp.M, c->dp.SZ, c->d_tau);
-	HIP_TRY(c, hipMemcpyAsync(ms, c->d_tau, S * 8, hipMemcpyDeviceToHost, st));
+	if (c->tb_cap < cap || c->tb_win < nwin)
+	{
+		if ((rc = dev_alloc(c, &c->d_tb, cap + nwin / 2 + 2))) return rc;   // out[cap] | head[nwin] (uint2) | count[4]
+		c->tb_cap = cap; c->tb_win = nwin;
+	}
+	uint2 *d_head = reinterpret_cast<uint2 *>(c->d_tb + cap);
+	uint32_t *d_count = reinterpret_cast<uint32_t *>(d_head + nwin);
+	uint32_t *d_exit_next = c->d_Mprev, *d_exit_cnt = reinterpret_cast<uint32_t *>(c->dp.K);
+	HIP_TRY(c, hipMemsetAsync(d_count, 0, 16, st));
+	hipLaunchKernelGGL(k_tb_windows, dim3(nwin), dim3(256), 0, st, c->dp.LB, dp_size, L, d_exit_next, d_exit_cnt);
+	hipLaunchKernelGGL(k_tb_chain, dim3(1), dim3(64), 0, st, d_exit_next, d_exit_cnt, dp_size, d_head, nwin, d_count);
+	hipLaunchKernelGGL(k_tb_emit, dim3(nwin), dim3(256), 0, st, c->dp.LB, c->dp.M, c->dp.SZ, dp_size, L, d_head, d_count, c->d_tb, (uint32_t) cap);
+	uint32_t cnt[4] = {0, 0, 0, 0};
+	HIP_TRY(c, hipMemcpyAsync(cnt, d_count, 16, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
-	for (size_t j = 0; j < S; ++j) { c->traceback[j].segment_max_size = ms[j].x; c->traceback[j].segment_size = ms[j].y; }
+	HIP_TRY(c, hipGetLastError());
+	if (cnt[1] != 1u || cnt[0] == 0 || cnt[0] > cap) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend to lb == 0");
+	size_t const S = cnt[0];
+	std::vector<uint4> h(S);
+	HIP_TRY(c, hipMemcpy(h.data(), c->d_tb, S * sizeof(uint4), hipMemcpyDeviceToHost));
+	c->traceback.resize(S);
+	for (size_t j = 0; j < S; ++j)
+	{
+		uint4 const e = h[S - 1 - j];                        // the kernels list the last segment first
+		c->traceback[j] = fseq_dp_arg{e.y, (uint64_t) e.x + L, e.z, e.w};
+	}
 	return FSEQ_OK;
 }
 
@@ -1359,20 +1360,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipEventRecord(c->ev[5], st));
 		HIP_TRY(c, hipGetLastError());
 
-		if (c->h_LB_cap < c->dp_size)
-		{
-			if (c->h_LB) (void) hipHostFree(c->h_LB);
-			c->h_LB = nullptr; c->h_LB_cap = 0;
-			size_t const extra = 3 * (size_t) (n / L + 2) + 8;    // the walk's index and (key, size) lists
-			HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_LB), extra * 4, hipHostMallocDefault));
-			c->h_LB_cap = c->dp_size;
-			c->h_LBv.resize(c->dp_size);
-		}
 		uint32_t h_flags[4] = {0, 0, 0, 0};
-		// The lb chain goes to PAGEABLE memory on purpose: the runtime's staged copy leaves it in the host's caches,
-		// and the walk is a chain of dependent random reads (measured on C3, 6156 hops: 1.4 ms on DMA-written pinned
-		// memory against 0.1 ms here; the staged copy of 4 MB costs 0.25 ms more than the pinned one).
-		HIP_TRY(c, hipMemcpyAsync(c->h_LBv.data(), c->dp.LB, c->dp_size * 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
 		if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipStreamSynchronize(st));
@@ -1768,7 +1756,6 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
 	if (c->h_done) (void) hipHostFree(c->h_done);
-	if (c->h_LB) (void) hipHostFree(c->h_LB);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;

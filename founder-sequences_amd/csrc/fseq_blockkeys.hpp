@@ -281,6 +281,10 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 			uint64_t const kc = k0 + (uint64_t) l * cl;
 			uint32_t const nc = (uint32_t) min<uint64_t>(cl, kend - kc);
 			IdT *const top = S.stk(sp);
+			// The word build writes `top` by row GROUPS (the rows that share a byte / word of the packed column), the rank
+			// operations read and write their arrays by single rows: a thread that is done with the last look-up must not
+			// overwrite a row another thread has still to read there (bk_merge does not end with a barrier).
+			__syncthreads();
 			if (!STREAM)
 			{
 				fetch(l + 1);

@@ -930,6 +930,110 @@ __global__ __launch_bounds__(64) void k_gather_lists(
 		out_ent[(size_t) blockIdx.x * stride + i] = ent[k * (size_t) stride + i];
 }
 
+// ------------------------------------------------------------------------------------------------
+// follow_traceback (segmentation_lp_context.cc:191-224) on the device: from DP[n - L] follow arg_idx = lb - L
+// until lb == 0.  A chain of S dependent reads (6156 on BASELINE C3: 0.75 ms as host cache misses after a 4 MB
+// copy, no better as one device thread), so it is cut into windows of TB_WIN entries:
+//   k_tb_windows  every window: pointer doubling inside LDS -> for EVERY entry the first entry below the window
+//                 its chain reaches and the number of entries visited on the way (the chain only descends)
+//   k_tb_chain    one thread hops from window to window along the real chain (one dependent read per window
+//                 instead of one per segment) and hands every visited window its entry point and output offset
+//   k_tb_emit     every visited window walks its few hops in LDS and writes {entry, lb, key, size}
+// out[] lists the last segment first; count[0] = S, count[1] = 1 iff the chain ended in an entry with lb == 0.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TB_WIN = 8192;
+constexpr uint32_t TB_TERM = 0xFFFFFFFFu;
+
+// successor of entry t, or TB_TERM when the chain ends at t (lb == 0) or t does not hold a valid lb (entries no cell
+// writes; they are never on the chain from n - L)
+__device__ __forceinline__ uint32_t tb_next(uint32_t lb, uint32_t t, uint32_t L) { return (lb >= L && lb - L < t) ? lb - L : TB_TERM; }
+
+__global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__ LB, uint32_t dp_size, uint32_t L,
+                                                    uint32_t *__restrict__ exit_next, uint32_t *__restrict__ exit_cnt)
+{
+	__shared__ uint32_t nx[2][TB_WIN];
+	__shared__ uint16_t cn[2][TB_WIN];
+	uint32_t const base = blockIdx.x * TB_WIN;
+	for (uint32_t i = threadIdx.x; i < TB_WIN; i += 256u)
+	{
+		uint32_t const t = base + i;
+		nx[0][i] = t < dp_size ? tb_next(LB[t], t, L) : TB_TERM;
+		cn[0][i] = 1;
+	}
+	__syncthreads();
+	// after round k an entry has jumped over 2^k entries of its chain inside the window (at most TB_WIN / max(L, 1) + 1 of them)
+	uint32_t const hops = TB_WIN / (L ? L : 1u) + 2u;
+	uint32_t cur = 0;
+	for (uint32_t span = 1; span < hops; span <<= 1)
+	{
+		for (uint32_t i = threadIdx.x; i < TB_WIN; i += 256u)
+		{
+			uint32_t j = nx[cur][i];
+			uint32_t c = cn[cur][i];
+			if (j != TB_TERM && j >= base) { c += cn[cur][j - base]; j = nx[cur][j - base]; }
+			nx[cur ^ 1u][i] = j;
+			cn[cur ^ 1u][i] = (uint16_t) c;
+		}
+		cur ^= 1u;
+		__syncthreads();
+	}
+	for (uint32_t i = threadIdx.x; i < TB_WIN; i += 256u)
+		if (base + i < dp_size) { exit_next[base + i] = nx[cur][i]; exit_cnt[base + i] = cn[cur][i]; }
+}
+
+// head[w] = {entry point, output offset} of the w-th visited window; count[0] = segments, count[1] = ok, count[2] = windows
+__global__ __launch_bounds__(64) void k_tb_chain(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t dp_size,
+                                                 uint2 *__restrict__ head, uint32_t max_windows, uint32_t *__restrict__ count)
+{
+	if (threadIdx.x != 0) return;
+	uint32_t cur = dp_size - 1u, off = 0, nw = 0;
+	while (nw < max_windows)
+	{
+		head[nw++] = make_uint2(cur, off);
+		off += exit_cnt[cur];
+		uint32_t const e = exit_next[cur];
+		if (e == TB_TERM) break;
+		cur = e;
+	}
+	count[0] = off; count[2] = nw;
+}
+
+__global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB, uint32_t const *__restrict__ M, uint32_t const *__restrict__ SZ,
+                                                 uint32_t dp_size, uint32_t L, uint2 const *__restrict__ head, uint32_t *__restrict__ count,
+                                                 uint4 *__restrict__ out, uint32_t cap)
+{
+	if (blockIdx.x >= count[2]) return;
+	__shared__ uint32_t lbw[TB_WIN];
+	__shared__ uint32_t s_n;
+	uint2 const h = head[blockIdx.x];
+	uint32_t const base = (h.x / TB_WIN) * TB_WIN;
+	for (uint32_t i = threadIdx.x; i < TB_WIN; i += 256u) lbw[i] = base + i < dp_size ? LB[base + i] : 0u;
+	__syncthreads();
+	if (threadIdx.x == 0)
+	{
+		uint32_t cur = h.x, n = 0;
+		while (true)
+		{
+			uint32_t const lb = lbw[cur - base];
+			if (h.y + n < cap) { out[h.y + n].x = cur; out[h.y + n].y = lb; }
+			++n;
+			uint32_t const nx = tb_next(lb, cur, L);
+			if (nx == TB_TERM) { if (lb == 0u) count[1] = 1u; break; }       // (only the last window of the chain ends like this)
+			if (nx < base) break;
+			cur = nx;
+		}
+		s_n = n;
+	}
+	__syncthreads();
+	for (uint32_t j = threadIdx.x; j < s_n; j += 256u)
+		if (h.y + j < cap)
+		{
+			uint32_t const t = out[h.y + j].x;
+			out[h.y + j].z = M[t];
+			out[h.y + j].w = SZ[t];
+		}
+}
+
 // out[j] = {a[idx[j]], b[idx[j]]}: the DP entries on the traceback path (the host walks the lb chain, the keys and
 // sizes of the visited entries follow in one small copy)
 __global__ __launch_bounds__(256) void k_gather_pairs(uint32_t const *__restrict__ idx, uint32_t count, uint32_t const *__restrict__ a,
