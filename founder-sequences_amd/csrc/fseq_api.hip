@@ -34,9 +34,6 @@ struct KernelSet {
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
 	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
-	void (*blockkeys)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t bsh,
-	                  uint32_t *, uint32_t *, uint32_t *, uint64_t col0, uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced);
-	hipError_t (*prepare_blockkeys)(size_t lds);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
@@ -73,14 +70,6 @@ struct Launch {
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0);
 	}
-	static void blockkeys(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                      uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
-	                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced)
-	{
-		hipLaunchKernelGGL((k_blockkeys<T>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0,
-		                   scratch, scratch_per_block, cap_words, sliced);
-	}
-	static hipError_t prepare_blockkeys(size_t lds) { return allow_lds(k_blockkeys<T>, lds); }
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
@@ -117,13 +106,51 @@ struct Launch {
 		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
 		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
 		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
-		k.blockkeys = &blockkeys; k.prepare_blockkeys = &prepare_blockkeys;
 		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
 		k.lds_chain = chain_lds_bytes<T, E, PK>();
 		k.chain = &chain; k.prepare = &prepare;
 		return k;
 	}
 };
+
+// phase A in key space, LDS-resident rows (fseq_blockkeys.hpp): the kernel has its own workgroup size, one thread
+// per 8 rows where that fits (blockkeys_threads)
+#define FSEQ_BK_SIZES(X) X(256) X(320) X(512) X(768) X(1024)
+void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+                      uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
+                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced)
+{
+	switch (T)
+	{
+#define X(T_) case T_: hipLaunchKernelGGL((k_blockkeys<T_>), dim3(grid), dim3(T_), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0, \
+	                                          scratch, scratch_per_block, cap_words, sliced); break;
+		FSEQ_BK_SIZES(X)
+#undef X
+		default: break;
+	}
+}
+hipError_t prepare_blockkeys(uint32_t T, size_t lds)
+{
+	if (getenv("FSEQ_DEBUG"))
+	{
+		int nb = -1;
+		switch (T)
+		{
+#define X(T_) case T_: (void) allow_lds(k_blockkeys<T_>, lds); (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_blockkeys<T_>, T_, lds); break;
+			FSEQ_BK_SIZES(X)
+#undef X
+			default: break;
+		}
+		fprintf(stderr, "fseq: k_blockkeys<%u> with %zu bytes of LDS: %d workgroups per CU\n", T, lds, nb);
+	}
+	switch (T)
+	{
+#define X(T_) case T_: return allow_lds(k_blockkeys<T_>, lds);
+		FSEQ_BK_SIZES(X)
+#undef X
+		default: return hipErrorInvalidValue;
+	}
+}
 
 bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 {
@@ -198,6 +225,7 @@ struct fseq_ctx {
 	uint16_t *d_bk = nullptr;                // phase A in key space (fseq_blockkeys.hpp): per-block scratch (leaf words, group ids)
 	size_t bk_per_block = 0, bk_blocks = 0;
 	uint32_t bk_cap_words = 0;
+	uint32_t bk_T = 0;                       // threads of k_blockkeys (LDS-resident rows)
 	size_t bk_lds = 0;
 	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
 	uint32_t chunk_cap = 0;
@@ -466,19 +494,20 @@ int prepare_geometry(fseq_ctx *c)
 		if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
 			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
-		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the bitmap takes what is left of ~76 KiB
-		// (two workgroups per CU) when that is worth at least the leaf bitmap twice over, else of the whole CU
+		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the two maps take what is left of ~76 KiB
+		// (two workgroups per CU) when that holds the leaf map with a quarter to spare, else of the whole CU
 		{
-			size_t const arrays = blockkeys_lds_bytes(p.m, 0, (int) c->ks.T, c->ld, c->bsh);
+			c->bk_T = blockkeys_threads(p.m);
+			size_t const arrays = blockkeys_lds_bytes(p.m, 0, (int) c->bk_T, c->ld, c->bsh);
 			size_t budget = 76 * 1024;
-			if (arrays + 6 * 4096 > budget) budget = LDS_LIMIT - 1024;
-			size_t cap = (budget - arrays) / 10;                  // two bitmaps (4 B) + a 16-bit prefix count per word
+			if (arrays + 16 * 2560 > budget) budget = LDS_LIMIT - 1024;
+			size_t cap = budget > arrays ? (budget - arrays) / 16 : 0;     // two maps of 8-byte {bits, prefix} entries
 			cap = std::min<size_t>(cap & ~size_t(63), 32768);
-			if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) cap = (size_t) std::max(2048, atoi(e));     // tests: force the fallback
+			if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) cap = (size_t) std::max(2048, atoi(e));     // tests: force the sliced merges
 			c->bk_cap_words = (uint32_t) cap;
-			c->bk_lds = blockkeys_lds_bytes(p.m, c->bk_cap_words, (int) c->ks.T, c->ld, c->bsh);
+			c->bk_lds = blockkeys_lds_bytes(p.m, c->bk_cap_words, (int) c->bk_T, c->ld, c->bsh);
 			// (a leaf's columns are staged with two 16-byte pieces per thread)
-			if (cap >= 2048 && c->bk_lds <= LDS_LIMIT && (size_t) (8u >> (2u - c->bsh)) * c->ld <= (size_t) c->ks.T * 32) HIP_TRY(c, c->ks.prepare_blockkeys(c->bk_lds));
+			if (cap >= 2048 && c->bk_lds <= LDS_LIMIT && (size_t) (8u >> (2u - c->bsh)) * c->ld <= (size_t) c->bk_T * 32) HIP_TRY(c, prepare_blockkeys(c->bk_T, c->bk_lds));
 			else c->bk_cap_words = 0;
 		}
 	}
@@ -1072,8 +1101,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			c->bk_per_block = per; c->bk_blocks = my_blocks;
 		}
 		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
-		ks.blockkeys(st, my_blocks, c->bk_lds, c->d_msa, c->ld, m, n, c->B, c->bsh, c->d_rank + (size_t) b_lo * m,
-		             c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64);
+		launch_blockkeys(c->bk_T, st, my_blocks, c->bk_lds, c->d_msa, c->ld, m, n, c->B, c->bsh, c->d_rank + (size_t) b_lo * m,
+		                 c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64);
 	}
 	else
 		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
@@ -1654,7 +1683,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				if ((rc = dev_alloc(c, &c->d_bk, per))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
 				c->bk_per_block = per; c->bk_blocks = 1;
 			}
-			c->ks.blockkeys(st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr);
+			launch_blockkeys(c->bk_T, st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr);
 		}
 	}
 	else

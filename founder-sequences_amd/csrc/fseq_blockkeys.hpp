@@ -18,8 +18,19 @@
 //            differ (group ids are kept in an HBM scratch), then the last leaf word / column in which they differ
 // Exact whatever the data; a merge whose bitmap would not fit the LDS budget (very diverse blocks: D_prefix x
 // D_group > cap) is done in slices of whole hi values.
-// Two instantiations: the id arrays in LDS as 16-bit words (m <= 11,264, the LDS-resident kernel configurations),
-// or in a per-workgroup HBM / L2 workspace as 32-bit words (the streamed regime: BASELINE C4's m = 100,000).
+// Two forms: the id arrays in LDS as 16-bit words (m <= 11,264, the LDS-resident kernel configurations; bk_rank8 /
+// blockkeys_tree_lds), or in a per-workgroup HBM / L2 workspace as 32-bit words (the streamed regime: BASELINE
+// C4's m = 100,000; bk_merge / blockkeys_tree_stream).
+//
+// LDS-resident form, shaped by what the stamps of the first version showed (245 rank operations of ~5,900 cycles and
+// 123 word builds of ~5,500 per C3 block: LDS instruction issue and barriers, not arithmetic):
+//   * a thread owns 8 CONSECUTIVE rows: one 16-byte LDS access per id array and step instead of eight 2-byte ones,
+//     and -- the same thread builds, ranks and rewrites a row throughout -- no barrier around the word build
+//   * the presence map is {bits, prefix} pairs: one 8-byte read per look-up
+//   * the prefix over the map words is wave-local; the look-up adds the offset of the word's wave with a
+//     ds_bpermute from the scanned wave totals -> two barriers per rank operation: [set bits] | [popcount, local
+//     prefix, clear the other map] | [look-up]
+//   * the leaf's word build sets the bits itself (the set phase of a leaf rank is the build)
 #pragma once
 
 #include "fseq_kernels.hpp"
@@ -29,11 +40,27 @@ namespace fseq {
 constexpr uint32_t BK_GL = 3;                 // 2^3 leaves per group (64 columns at 2 bits per symbol)
 constexpr uint32_t BK_LEAF_BITS = 65536;      // one bit per 16-bit leaf word
 
-// LDS of the LDS-resident tree: prefix ids + (GL + 1) stack arrays of m u16, two bitmaps + one u16 prefix count per
-// word, the block scan scratch, the staged columns of one leaf (8 >> (2 - bsh) columns of ld bytes)
+#ifdef FSEQ_BK_STAMPS
+#define BK_T(S, i) do { long long const t_ = clock64(); (S).acc_t[i] += t_ - (S).last_t; (S).last_t = t_; } while (0)
+#else
+#define BK_T(S, i) do {} while (0)
+#endif
+
+// rows of a u16 array in the HBM scratch: whole 8-row pieces (16-byte stores)
+__host__ __device__ inline size_t bk_m8(uint32_t m) { return ((size_t) m + 7) & ~size_t(7); }
+
+// threads of the LDS-resident kernel: one thread per 8 rows where that fits
+__host__ __device__ inline uint32_t blockkeys_threads(uint32_t m)
+{
+	uint32_t const t = (m + 7u) / 8u;
+	return t <= 256u ? 256u : t <= 320u ? 320u : t <= 512u ? 512u : t <= 768u ? 768u : 1024u;
+}
+
+// LDS of the LDS-resident tree: prefix ids + (GL + 1) stack arrays of m u16, two maps of cap_words {bits, prefix}
+// pairs, the wave totals, the staged columns of one leaf (8 >> (2 - bsh) columns of ld bytes)
 __host__ __device__ inline size_t blockkeys_lds_bytes(uint32_t m, uint32_t cap_words, int T, size_t ld = 0, uint32_t bsh = 2)
 {
-	return carve_bytes(m, 2) * (BK_GL + 2) + 2 * carve_bytes(cap_words, 4) + carve_bytes(cap_words, 2) + carve_bytes(2 * ((size_t) T / WAVE + 1), 4)
+	return carve_bytes(m, 2) * (BK_GL + 2) + carve_bytes(2 * (size_t) cap_words, 8) + carve_bytes((size_t) T / WAVE + 1, 4)
 	     + carve_bytes((size_t) (8u >> (2u - bsh)) * ld + 16, 1);
 }
 // ... of the streamed tree: bitmap + 32-bit prefix counts + scan scratch
@@ -42,12 +69,12 @@ __host__ __device__ inline size_t blockkeys_stream_lds_bytes(uint32_t cap_words,
 	return carve_bytes(cap_words, 4) * 3 + carve_bytes(2 * ((size_t) T / WAVE + 1), 4);
 }
 
-// halfwords per block of the HBM scratch of the LDS-resident tree: leaf words [nleaf][m] and group ids [ngrp][m], u16
+// halfwords per block of the HBM scratch of the LDS-resident tree: leaf words [nleaf][m8] and group ids [ngrp][m8], u16
 __host__ __device__ inline size_t blockkeys_scratch_halfwords(uint32_t m, uint32_t B, uint32_t bsh)
 {
 	uint32_t const cl = 8u >> (2u - bsh);                     // columns per leaf
 	uint32_t const nleaf = (B + cl - 1) / cl, ngrp = (nleaf + (1u << BK_GL) - 1) >> BK_GL;
-	return ((size_t) nleaf + ngrp) * m;
+	return ((size_t) nleaf + ngrp) * bk_m8(m);
 }
 // words per WORKGROUP of the streamed tree's workspace: the id arrays (GL + 2) x m and the group ids [ngrp][m], u32
 __host__ __device__ inline size_t blockkeys_stream_ws_words(uint32_t m, uint32_t B, uint32_t bsh)
@@ -57,6 +84,412 @@ __host__ __device__ inline size_t blockkeys_stream_ws_words(uint32_t m, uint32_t
 	return ((size_t) (BK_GL + 2) + ngrp) * m + 64;
 }
 
+// =================================================================================================================
+// LDS-resident form
+// =================================================================================================================
+struct BkLds {
+	// (no arrays in here: a dynamically indexed member would move the whole struct to scratch memory)
+	uint16_t *acc;                 // ids over the columns merged so far
+	uint16_t *stk0;                // DFS stack of id arrays inside a group: level i at stk0 + i * stk_stride
+	uint32_t stk_stride;           // halfwords, a multiple of 8
+	uint2 *map0;                   // two maps of cap_words {bits, wave-local prefix}, used alternately: the idle one is cleared while the other is summed
+	uint32_t *scr;                 // popcount totals of the waves
+	uint32_t cap_words;
+	uint32_t turn;                 // rank operations done so far (selects the map)
+	uint32_t used_a, used_b;       // entries of map 0 / 1 that may be non-zero
+#ifdef FSEQ_BK_STAMPS
+	long long acc_t[8], last_t;
+#endif
+	__device__ __forceinline__ uint16_t *stk(uint32_t i) const { return stk0 + (size_t) i * stk_stride; }
+	__device__ __forceinline__ uint2 *cur() const { return map0 + (size_t) (turn & 1u) * cap_words; }
+};
+
+// Barrier over the LDS traffic only: __syncthreads() also waits for the wave's outstanding HBM accesses (vmcnt(0)) --
+// here that would be the prefetch of the next leaf's columns and the stores of the leaf words, both of which have
+// all the time in the world.
+__device__ __forceinline__ void bk_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// halfword u (0 .. 7) of a 16-byte piece
+__device__ __forceinline__ uint32_t bk_half(uint4 const &q, uint32_t u)
+{
+	uint32_t const w = u < 2 ? q.x : u < 4 ? q.y : u < 6 ? q.z : q.w;
+	return (u & 1u) ? w >> 16 : w & 0xFFFFu;
+}
+__device__ __forceinline__ uint4 bk_pack(uint32_t const (&v)[8])
+{
+	return make_uint4(v[0] | v[1] << 16, v[2] | v[3] << 16, v[4] | v[5] << 16, v[6] | v[7] << 16);
+}
+
+// Dense rank of (hi[r], lo[r]) over the rows, hi the more significant (later columns); hi == nullptr: of lo[r] alone
+// (a leaf: Dlo = 65536 possible words, its bits already set by the word build: PRESET).  The Dhi x Dlo map is
+// processed in slices of whole hi values when it exceeds the LDS budget (very diverse blocks): a slice ranks the
+// rows whose hi falls into it, earlier slices hold the smaller keys.  out may alias lo.  A row is read and written
+// by the thread that owns it in every pass (rows 8 t .. 8 t + 7, then + 8 T), so consecutive rank operations need
+// no barrier between them.  mid() runs between the two barriers of the first slice.
+template <int T, bool PRESET, typename F>
+__device__ __forceinline__ uint32_t bk_rank8(BkLds &S, uint32_t m, uint32_t Dlo, uint32_t Dhi, uint16_t const *lo, uint16_t const *hi,
+                                             uint16_t *out, uint32_t *sliced, F &&mid)
+{
+	constexpr uint32_t NW = T / WAVE;
+	uint32_t const tid = threadIdx.x;
+	uint32_t const cap_bits = S.cap_words * 32u;
+	uint32_t const hps = ((uint64_t) Dlo * Dhi <= cap_bits) ? Dhi : max(1u, cap_bits / Dlo);     // hi values per slice (Dlo <= cap_bits)
+	if (hps < Dhi) ++*sliced;
+	uint32_t base = 0;
+	for (uint32_t h0 = 0; h0 < Dhi; h0 += hps)
+	{
+		uint32_t const h1 = min(Dhi, h0 + hps);
+		bool const whole = (h0 == 0u && h1 == Dhi);
+		uint32_t const W = ((h1 - h0) * Dlo + 31u) >> 5;
+		uint32_t const par = S.turn & 1u;
+		uint2 *const map = S.map0 + (size_t) par * S.cap_words, *const other = S.map0 + (size_t) (par ^ 1u) * S.cap_words;
+		uint32_t const other_used = par ? S.used_a : S.used_b;
+		if (par) { S.used_a = 0u; S.used_b = W; } else { S.used_b = 0u; S.used_a = W; }
+		++S.turn;
+		if (!PRESET)
+		{
+			if (whole)
+				// (the common case: no slice test, nothing between the eight atomics of a thread)
+				for (uint32_t r0 = tid * 8u; r0 < m; r0 += T * 8u)
+				{
+					uint4 const lq = *reinterpret_cast<uint4 const *>(lo + r0);
+					uint4 const hq = *reinterpret_cast<uint4 const *>(hi + r0);
+					uint32_t k[8];
+#pragma unroll
+					for (uint32_t u = 0; u < 8; ++u) k[u] = __umul24(bk_half(hq, u), Dlo) + bk_half(lq, u);
+#pragma unroll
+					for (uint32_t u = 0; u < 8; ++u)
+					{
+						uint32_t const kk = r0 + u < m ? k[u] : k[0];   // (a row behind m sets the bit of row r0 once more)
+						atomicOr(&map[kk >> 5].x, 1u << (kk & 31u));
+					}
+				}
+			else
+				for (uint32_t r0 = tid * 8u; r0 < m; r0 += T * 8u)
+				{
+					uint4 const lq = *reinterpret_cast<uint4 const *>(lo + r0);
+					uint4 const hq = *reinterpret_cast<uint4 const *>(hi + r0);
+#pragma unroll
+					for (uint32_t u = 0; u < 8; ++u)
+					{
+						uint32_t const h = bk_half(hq, u);
+						if (r0 + u < m && h >= h0 && h < h1)
+						{
+							uint32_t const k = __umul24(h - h0, Dlo) + bk_half(lq, u);
+							atomicOr(&map[k >> 5].x, 1u << (k & 31u));
+						}
+					}
+				}
+		}
+#ifdef FSEQ_BK_STAMPS
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		BK_T(S, 0);
+		bk_barrier();
+		BK_T(S, 1);
+#else
+		bk_barrier();
+#endif
+		if (h0 == 0u) mid();
+#ifdef FSEQ_BK_STAMPS
+		asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+		BK_T(S, 2);
+#endif
+		// Popcounts of the map words and their wave-local prefix; the wave totals go to the scratch.  A wave takes the
+		// 64 << lp entries [wave << (6 + lp), ...): rows of 128, lane i the entries 2 i and 2 i + 1 of every row -- the
+		// 16-byte accesses of consecutive lanes are consecutive (no bank conflicts; 64-byte pieces per lane ran at a
+		// quarter of the LDS rate), one wave scan per row.
+		uint32_t lp = 0;
+		while (((uint32_t) T << lp) < W) ++lp;
+		if (lp == 0)
+		{
+			uint32_t const s = tid < W ? (uint32_t) __popc(map[tid].x) : 0u;
+			uint32_t const inc = wave_incl_add(s);
+			if (lane_id() == 63) S.scr[wave_id()] = inc;
+			if (tid < W) map[tid].y = inc - s;
+		}
+		else
+		{
+			uint32_t const cb = wave_id() << (6u + lp);
+			uint32_t carry = 0;
+			for (uint32_t j = 0; j < (1u << (lp - 1u)); ++j)
+			{
+				uint32_t const w = cb + (j << 7) + 2u * lane_id();
+				uint4 e = make_uint4(0, 0, 0, 0);
+				if (w < W) e = *reinterpret_cast<uint4 const *>(map + w);       // (entry W of an odd W is zero and inside the map)
+				uint32_t const c0 = (uint32_t) __popc(e.x), s = c0 + (uint32_t) __popc(e.z);
+				uint32_t const inc = wave_incl_add(s);
+				e.y = carry + inc - s;
+				e.w = e.y + c0;
+				if (w < W) *reinterpret_cast<uint4 *>(map + w) = e;
+				carry += readlane_u32(inc, 63);
+			}
+			if (lane_id() == 63) S.scr[wave_id()] = carry;
+		}
+		// the other map has been read for the last time before this call's first barrier: clear what its last use
+		// may have set, for the next rank operation
+#ifdef FSEQ_BK_STAMPS
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		BK_T(S, 5);
+#endif
+		for (uint32_t w = tid * 2u; w < other_used; w += T * 2u) *reinterpret_cast<uint4 *>(other + w) = make_uint4(0u, 0u, 0u, 0u);
+#ifdef FSEQ_BK_STAMPS
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+		BK_T(S, 6);
+#endif
+		bk_barrier();
+		BK_T(S, 7);
+		// exclusive scan of the wave totals, one per lane; the look-up fetches the entry of its word's wave with a
+		// ds_bpermute -- which reads 0 from an inactive lane: the loop runs with every lane of the wave, rows or not
+		uint32_t const wt = lane_id() < NW ? S.scr[lane_id()] : 0u;
+		uint32_t const wi = wave_incl_add(wt);
+		uint32_t const total = readlane_u32(wi, 63);
+		int const wex = (int) (wi - wt);
+		uint32_t const wsh = 6u + lp;
+		uint32_t const rlast = (m - 1u) & ~7u;
+		if (whole)
+			// (the common case: the eight map reads and permutes of a thread in flight together, one 16-byte store)
+			for (uint32_t rb = 0; rb < m; rb += T * 8u)
+			{
+				uint32_t const r0 = rb + tid * 8u, rl = min(r0, rlast);
+				uint4 const lq = *reinterpret_cast<uint4 const *>(lo + rl);
+				uint4 hq = make_uint4(0, 0, 0, 0);
+				if (!PRESET) hq = *reinterpret_cast<uint4 const *>(hi + rl);
+				uint32_t k[8], id[8];
+				uint2 e[8];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) k[u] = PRESET ? bk_half(lq, u) : __umul24(bk_half(hq, u), Dlo) + bk_half(lq, u);
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) e[u] = map[k[u] >> 5];
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) id[u] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((k[u] >> 5 >> wsh) << 2), wex);
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u) id[u] += base + e[u].y + (uint32_t) __popc(e[u].x & ((1u << (k[u] & 31u)) - 1u));
+				if (r0 < m) *reinterpret_cast<uint4 *>(out + r0) = bk_pack(id);
+			}
+		else
+			for (uint32_t rb = 0; rb < m; rb += T * 8u)
+			{
+				uint32_t const r0 = rb + tid * 8u, rl = min(r0, rlast);
+				uint4 const lq = *reinterpret_cast<uint4 const *>(lo + rl);
+				uint4 const hq = *reinterpret_cast<uint4 const *>(hi + rl);
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u)
+				{
+					uint32_t const h = bk_half(hq, u);
+					bool const in = r0 + u < m && h >= h0 && h < h1;
+					uint32_t const k = in ? __umul24(h - h0, Dlo) + bk_half(lq, u) : 0u;
+					uint2 const e = map[k >> 5];
+					uint32_t const wpre = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((k >> 5 >> wsh) << 2), wex);
+					if (in) out[r0 + u] = (uint16_t) (base + wpre + e.y + (uint32_t) __popc(e.x & ((1u << (k & 31u)) - 1u)));
+				}
+			}
+		base += total;
+		BK_T(S, 3);
+	}
+	return base;
+}
+
+// dst[r] = src[r] (and dst2[r], if given) for the rows this thread owns; dst in HBM, rows padded to 8
+template <int T>
+__device__ __forceinline__ void bk_copy8(uint32_t m, uint16_t const *src, uint16_t *__restrict__ dst, uint16_t *dst2 = nullptr)
+{
+	for (uint32_t r0 = threadIdx.x * 8u; r0 < m; r0 += T * 8u)
+	{
+		uint4 const v = *reinterpret_cast<uint4 const *>(src + r0);
+		*reinterpret_cast<uint4 *>(dst + r0) = v;
+		if (dst2) *reinterpret_cast<uint4 *>(dst2 + r0) = v;
+	}
+}
+
+// The 16-bit words of one leaf (nc <= 16 / bits columns staged at sym, ld bytes apart) for the rows this thread owns:
+// to `top` (LDS), to `leafw` (HBM) and as set bits of `map`.  BSH: log2 of the rows per byte (2 / 1 / 0).
+template <int T, int BSH>
+__device__ __forceinline__ void bk_build_leaf(uint8_t const *sym, size_t ld, uint32_t nc, uint32_t m, uint16_t *top, uint16_t *__restrict__ leafw, uint2 *map)
+{
+	constexpr uint32_t BITS = 8u >> BSH, CL = 16u / BITS, SMASK = (1u << BITS) - 1u;
+	for (uint32_t r0 = threadIdx.x * 8u; r0 < m; r0 += T * 8u)
+	{
+		// the 8 rows' symbols of every column: 2 / 4 / 8 bytes each, all loads in flight together (a column behind
+		// the leaf's last reads as column 0 and counts as zeros)
+		uint32_t x0[CL], x1[CL];
+#pragma unroll
+		for (uint32_t c = 0; c < CL; ++c)
+		{
+			uint8_t const *const at = sym + (size_t) (c < nc ? c : 0u) * ld + (r0 >> BSH);
+			x1[c] = 0;
+			if (BSH == 2) x0[c] = *reinterpret_cast<uint16_t const *>(at);
+			else if (BSH == 1) x0[c] = *reinterpret_cast<uint32_t const *>(at);
+			else { uint2 const t = *reinterpret_cast<uint2 const *>(at); x0[c] = t.x; x1[c] = t.y; }
+		}
+		uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+		for (uint32_t c = 0; c < CL; ++c)
+		{
+			uint32_t const a = c < nc ? x0[c] : 0u, b = c < nc ? x1[c] : 0u;
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u)
+			{
+				uint32_t const sh = u * BITS;
+				uint32_t const v = (sh < 32u ? a >> sh : b >> (sh - 32u)) & SMASK;
+				w[u] |= v << (BITS * c);
+			}
+		}
+		uint4 const q = bk_pack(w);
+		*reinterpret_cast<uint4 *>(top + r0) = q;
+		*reinterpret_cast<uint4 *>(leafw + r0) = q;
+		// (a row behind m sets the bit of row r0 once more)
+#pragma unroll
+		for (uint32_t u = 0; u < 8; ++u)
+		{
+			uint32_t const k = r0 + u < m ? w[u] : w[0];
+			atomicOr(&map[k >> 5].x, 1u << (k & 31u));
+		}
+	}
+}
+
+// The tree over the block [k0, kend): smem holds everything, scratch = this block's leaf words and group ids (u16).
+// Returns the number of merges that had to be sliced (diagnostic only).
+template <int T>
+__device__ __forceinline__ uint32_t blockkeys_tree_lds(
+	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
+	uint16_t *__restrict__ scratch, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
+{
+	uint32_t const tid = threadIdx.x;
+	uint32_t const bits = 8u >> bsh, cl = 16u / bits;
+	uint32_t const nb = (uint32_t) (kend - k0);
+	uint32_t const nleaf = (nb + cl - 1) / cl, ngrp = (nleaf + (1u << BK_GL) - 1) >> BK_GL;
+	size_t const m8 = bk_m8(m);
+	Carver cv{smem};
+	BkLds S;
+	S.acc = cv.take<uint16_t>(m);
+	S.stk_stride = (uint32_t) (carve_bytes(m, 2) / 2);
+	S.stk0 = cv.take<uint16_t>((size_t) S.stk_stride * (BK_GL + 1));
+	S.map0 = cv.take<uint2>(2 * (size_t) cap_words);
+	S.scr = cv.take<uint32_t>(T / WAVE + 1);
+	uint8_t *const sym = cv.take<uint8_t>((size_t) cl * ld + 16);     // the columns of the current leaf, staged
+	uint16_t *const leafw = scratch;                          // [nleaf][m8]
+	uint16_t *const grpid = leafw + (size_t) nleaf * m8;      // [ngrp][m8]
+	S.cap_words = cap_words;
+	S.turn = 0;
+	S.used_a = S.used_b = 0;
+	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.map0[w] = make_uint2(0u, 0u);
+	uint32_t Dacc = 0, sliced = 0;
+#ifdef FSEQ_BK_STAMPS
+	for (int i = 0; i < 8; ++i) S.acc_t[i] = 0;
+	S.last_t = clock64();
+#endif
+
+	// The columns of a leaf are one contiguous piece of the column-major alignment (cl * ld bytes): 16 bytes per
+	// thread and piece; the next leaf's columns are fetched into registers before this leaf's word build and land in
+	// the staging buffer behind the first barrier of its rank (every thread is done reading the buffer there, and the
+	// second barrier stands before the next build).
+	constexpr uint32_t NPF = 2;                               // 16-byte pieces per thread: cl * ld <= T * 32 (host checks)
+	uint4 pf[NPF];
+	auto fetch = [&](uint32_t l) {
+		uint64_t const kc = k0 + (uint64_t) l * cl;
+		uint32_t const bytes = (l < nleaf) ? (uint32_t) (min<uint64_t>(cl, kend - kc) * ld) : 0u;
+#pragma unroll
+		for (uint32_t q = 0; q < NPF; ++q)
+		{
+			uint32_t const off = (tid + q * T) * 16u;
+			pf[q] = (off < bytes) ? *reinterpret_cast<uint4 const *>(msa + kc * ld + off) : make_uint4(0, 0, 0, 0);
+		}
+	};
+	auto land = [&]() {
+#pragma unroll
+		for (uint32_t q = 0; q < NPF; ++q)
+		{
+			uint32_t const off = (tid + q * T) * 16u;
+			if (off < cl * (uint32_t) ld) *reinterpret_cast<uint4 *>(sym + off) = pf[q];
+		}
+	};
+	auto nothing = []() {};
+	fetch(0);
+	land();
+	__syncthreads();                                          // maps cleared, leaf 0 staged
+
+	for (uint32_t g = 0; g < ngrp; ++g)
+	{
+		// ---- one group: leaves left to right, equal-sized neighbours merged at once (a balanced tree, left child
+		// = the largest power of two below the size), the rest merged at the end of the group
+		uint32_t const l0 = g << BK_GL, l1 = min(nleaf, l0 + (1u << BK_GL));
+		uint32_t sp = 0, sz[BK_GL + 1], D[BK_GL + 1];
+		for (uint32_t l = l0; l < l1; ++l)
+		{
+			uint64_t const kc = k0 + (uint64_t) l * cl;
+			uint32_t const nc = (uint32_t) min<uint64_t>(cl, kend - kc);
+			uint16_t *const top = S.stk(sp);
+			fetch(l + 1);
+			if (bsh == 2) bk_build_leaf<T, 2>(sym, ld, nc, m, top, leafw + (size_t) l * m8, S.cur());
+			else if (bsh == 1) bk_build_leaf<T, 1>(sym, ld, nc, m, top, leafw + (size_t) l * m8, S.cur());
+			else bk_build_leaf<T, 0>(sym, ld, nc, m, top, leafw + (size_t) l * m8, S.cur());
+			BK_T(S, 4);
+			D[sp] = bk_rank8<T, true>(S, m, BK_LEAF_BITS, 1u, top, nullptr, top, &sliced, land);
+			sz[sp] = 1;
+			++sp;
+			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
+			{
+				D[sp - 2] = bk_rank8<T, false>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced, nothing);
+				sz[sp - 2] += sz[sp - 1];
+				--sp;
+			}
+		}
+		// ---- the group joins the prefix
+		uint16_t *const gi = S.stk(0);
+		if (g == 0)
+		{
+			bk_copy8<T>(m, gi, grpid, S.acc);
+			Dacc = D[0];
+		}
+		else
+		{
+			bk_copy8<T>(m, gi, grpid + (size_t) g * m8);
+			Dacc = bk_rank8<T, false>(S, m, Dacc, D[0], S.acc, gi, S.acc, &sliced, nothing);
+		}
+	}
+
+	// ---- outputs: rank of every row, one representative row per distinct key, the divergence in front of each key
+	uint16_t *const rep = S.stk(1);
+	__syncthreads();                                          // rep is written by key, not by row
+	for (uint32_t r0 = tid * 8u; r0 < m; r0 += T * 8u)
+	{
+		uint4 const q = *reinterpret_cast<uint4 const *>(S.acc + r0);
+#pragma unroll
+		for (uint32_t u = 0; u < 8; ++u)
+			if (r0 + u < m) { uint32_t const v = bk_half(q, u); rank_out[r0 + u] = v; rep[v] = (uint16_t) (r0 + u); }
+	}
+	__syncthreads();
+	for (uint32_t j = tid; j < Dacc; j += T)
+	{
+		uint32_t d = (uint32_t) kend;                        // key 0: first of its bucket in every column
+		if (j > 0)
+		{
+			uint32_t const ra = rep[j - 1], rb = rep[j];
+			uint32_t g = ngrp - 1;
+			while (g > 0 && grpid[(size_t) g * m8 + ra] == grpid[(size_t) g * m8 + rb]) --g;
+			uint32_t const l0 = g << BK_GL, l1 = min(nleaf, l0 + (1u << BK_GL));
+			uint32_t l = l1 - 1u;
+			uint32_t x = (uint32_t) leafw[(size_t) l * m8 + ra] ^ (uint32_t) leafw[(size_t) l * m8 + rb];
+			while (x == 0u && l > l0) { --l; x = (uint32_t) leafw[(size_t) l * m8 + ra] ^ (uint32_t) leafw[(size_t) l * m8 + rb]; }
+			// highest differing symbol of the word = the last column in which the two keys differ; the common
+			// suffix starts one column behind it
+			uint32_t const p = (31u - (uint32_t) __builtin_clz(x | 1u)) / bits;
+			d = (uint32_t) (k0 + (uint64_t) l * cl + p + 1u);
+		}
+		keyd_out[j] = d;
+	}
+	if (tid == 0) *nkeys_out = Dacc;
+#ifdef FSEQ_BK_STAMPS
+	if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 700))
+		printf("bk stamps block %u: set %lld B1 %lld mid %lld count+scan %lld clear %lld B2 %lld lookup %lld build %lld | Dacc %u turns %u\n", blockIdx.x,
+		       S.acc_t[0], S.acc_t[1], S.acc_t[2], S.acc_t[5], S.acc_t[6], S.acc_t[7], S.acc_t[3], S.acc_t[4], Dacc, S.turn);
+#endif
+	return sliced;
+}
+
+// =================================================================================================================
+// streamed form
+// =================================================================================================================
 template <typename IdT, typename PrefT>
 struct BkState {
 	// (no arrays in here: a dynamically indexed member would move the whole struct to scratch memory)
@@ -191,43 +624,27 @@ __device__ __forceinline__ uint32_t bk_symbol(uint8_t const *msa, size_t ld, uin
 	return ((uint32_t) msa[k * ld + (r >> bsh)] >> ((r & ((1u << bsh) - 1u)) * bits)) & ((1u << bits) - 1u);
 }
 
-// The tree over the block [k0, kend).  STREAM = false: smem holds everything, scratch = this block's leaf words and
-// group ids (u16).  STREAM = true: smem holds the bitmap, ws = this workgroup's id arrays and group ids (u32).
-// Returns the number of merges that had to be sliced (diagnostic only).
-template <int T, bool STREAM>
-__device__ __forceinline__ uint32_t blockkeys_tree(
+// The tree over the block [k0, kend), streamed rows: smem holds the bitmaps, ws = this workgroup's id arrays and
+// group ids (u32).  Returns the number of merges that had to be sliced (diagnostic only).
+__device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
-	void *__restrict__ scratch_or_ws, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
+	uint32_t *__restrict__ ws, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
 {
-	using IdT = std::conditional_t<STREAM, uint32_t, uint16_t>;
-	using PrefT = std::conditional_t<STREAM, uint32_t, uint16_t>;
+	constexpr int T = 1024;
+	using IdT = uint32_t;
+	using PrefT = uint32_t;
 	uint32_t const tid = threadIdx.x;
 	uint32_t const bits = 8u >> bsh, cl = 16u / bits, smask = (1u << bits) - 1u;
 	uint32_t const nb = (uint32_t) (kend - k0);
 	uint32_t const nleaf = (nb + cl - 1) / cl, ngrp = (nleaf + (1u << BK_GL) - 1) >> BK_GL;
 	Carver cv{smem};
 	BkState<IdT, PrefT> S;
-	uint8_t *sym = nullptr;                                   // !STREAM: the columns of the current leaf, staged
-	uint16_t *leafw = nullptr;                                // !STREAM: [nleaf][m]
+	S.bm0 = cv.take<uint32_t>(2 * (size_t) cap_words);
+	S.pref = cv.take<PrefT>(cap_words);
+	S.sscr = cv.take<uint32_t>(2 * (T / WAVE + 1));
 	IdT *grpid;                                               // [ngrp][m]
-	if (!STREAM)
 	{
-		S.acc = cv.take<IdT>(m);
-		S.stk_stride = carve_bytes(m, sizeof(IdT)) / sizeof(IdT);
-		S.stk0 = cv.take<IdT>(S.stk_stride * (BK_GL + 1));
-		S.bm0 = cv.take<uint32_t>(2 * (size_t) cap_words);
-		S.pref = cv.take<PrefT>(cap_words);
-		S.sscr = cv.take<uint32_t>(2 * (T / WAVE + 1));
-		sym = cv.take<uint8_t>((size_t) cl * ld + 16);
-		leafw = static_cast<uint16_t *>(scratch_or_ws);
-		grpid = reinterpret_cast<IdT *>(leafw + (size_t) nleaf * m);
-	}
-	else
-	{
-		S.bm0 = cv.take<uint32_t>(2 * (size_t) cap_words);
-		S.pref = cv.take<PrefT>(cap_words);
-		S.sscr = cv.take<uint32_t>(2 * (T / WAVE + 1));
-		IdT *w = static_cast<IdT *>(scratch_or_ws);
+		IdT *w = ws;
 		S.acc = w; w += m;
 		S.stk0 = w; S.stk_stride = m; w += (size_t) m * (BK_GL + 1);
 		grpid = w;
@@ -238,37 +655,6 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.bm0[w] = 0u;
 	__syncthreads();
 	uint32_t Dacc = 0, sliced = 0;
-
-	// !STREAM: the columns of a leaf are one contiguous piece of the column-major alignment (cl * ld bytes): 16 bytes
-	// per thread and piece; the next leaf's columns are fetched into registers while this leaf is ranked (the HBM
-	// latency hides behind the ~10 barriers of a leaf and its merges).
-	constexpr uint32_t NPF = 2;                               // 16-byte pieces per thread: cl * ld <= T * 32 (host checks)
-	uint4 pf[NPF];
-	auto fetch = [&](uint32_t l) {
-		uint64_t const kc = k0 + (uint64_t) l * cl;
-		uint32_t const bytes = (l < nleaf) ? (uint32_t) (min<uint64_t>(cl, kend - kc) * ld) : 0u;
-#pragma unroll
-		for (uint32_t q = 0; q < NPF; ++q)
-		{
-			uint32_t const off = (tid + q * T) * 16u;
-			pf[q] = (off < bytes) ? *reinterpret_cast<uint4 const *>(msa + kc * ld + off) : make_uint4(0, 0, 0, 0);
-		}
-	};
-	auto land = [&]() {
-#pragma unroll
-		for (uint32_t q = 0; q < NPF; ++q)
-		{
-			uint32_t const off = (tid + q * T) * 16u;
-			if (off < cl * (uint32_t) ld) *reinterpret_cast<uint4 *>(sym + off) = pf[q];
-		}
-	};
-	if (!STREAM)
-	{
-		fetch(0);
-		land();
-		__syncthreads();
-	}
-	uint32_t const rpb = 1u << bsh, ngr = (m + rpb - 1u) >> bsh;    // rows per byte; row groups = bytes per column
 
 	for (uint32_t g = 0; g < ngrp; ++g)
 	{
@@ -281,33 +667,10 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 			uint64_t const kc = k0 + (uint64_t) l * cl;
 			uint32_t const nc = (uint32_t) min<uint64_t>(cl, kend - kc);
 			IdT *const top = S.stk(sp);
-			// The word build writes `top` by row GROUPS (the rows that share a byte / word of the packed column), the rank
+			// The word build writes `top` by row GROUPS (the rows that share a word of the packed column), the rank
 			// operations read and write their arrays by single rows: a thread that is done with the last look-up must not
 			// overwrite a row another thread has still to read there (bk_merge does not end with a barrier).
 			__syncthreads();
-			if (!STREAM)
-			{
-				fetch(l + 1);
-				// a thread takes the rows that share a byte: one LDS byte per column gives all of their symbols
-				for (uint32_t q = tid; q < ngr; q += T)
-				{
-					uint32_t w[4] = {0, 0, 0, 0};
-					for (uint32_t c = 0; c < nc; ++c)
-					{
-						uint32_t const b = sym[(size_t) c * ld + q];
-#pragma unroll
-						for (uint32_t j = 0; j < 4; ++j)
-							if (j < rpb) w[j] |= ((b >> (j * bits)) & smask) << (bits * c);
-					}
-#pragma unroll
-					for (uint32_t j = 0; j < 4; ++j)
-					{
-						uint32_t const r = q * rpb + j;
-						if (j < rpb && r < m) { top[r] = (IdT) w[j]; leafw[(size_t) l * m + r] = (uint16_t) w[j]; }
-					}
-				}
-			}
-			else
 			{
 				// a thread takes the rows that share a 32-bit word of the packed column (16 / 8 / 4 rows): one coalesced
 				// word per column, all of a leaf's columns in flight together
@@ -330,9 +693,6 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 				}
 			}
 			__syncthreads();                                      // the words were written by row groups, the rank reads them by rows
-			// every thread is past this leaf's word build: the next leaf's columns may land in the staging buffer (the
-			// barriers of the rank below stand between this and the next word build)
-			if (!STREAM) land();
 			D[sp] = bk_merge<T, IdT, PrefT>(S, m, BK_LEAF_BITS, 1u, top, nullptr, top, &sliced);
 			sz[sp] = 1;
 			++sp;
@@ -361,7 +721,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 	// ---- outputs: rank of every row, one representative row per distinct key, the divergence in front of each key
 	IdT *const rep = S.stk(1);
 	{
-		constexpr uint32_t U = STREAM ? 8u : 1u;
+		constexpr uint32_t U = 8u;
 		for (uint32_t r0 = tid; r0 < m; r0 += T * U)
 		{
 			uint32_t v[U];
@@ -382,29 +742,16 @@ __device__ __forceinline__ uint32_t blockkeys_tree(
 			uint32_t g = ngrp - 1;
 			while (g > 0 && grpid[(size_t) g * m + ra] == grpid[(size_t) g * m + rb]) --g;
 			uint32_t const l0 = g << BK_GL, l1 = min(nleaf, l0 + (1u << BK_GL));
-			if (!STREAM)
-			{
-				uint32_t l = l1 - 1u;
-				uint32_t x = (uint32_t) leafw[(size_t) l * m + ra] ^ (uint32_t) leafw[(size_t) l * m + rb];
-				while (x == 0u && l > l0) { --l; x = (uint32_t) leafw[(size_t) l * m + ra] ^ (uint32_t) leafw[(size_t) l * m + rb]; }
-				// highest differing symbol of the word = the last column in which the two keys differ; the common
-				// suffix starts one column behind it
-				uint32_t const p = (31u - (uint32_t) __builtin_clz(x | 1u)) / bits;
-				d = (uint32_t) (k0 + (uint64_t) l * cl + p + 1u);
-			}
-			else
-			{
-				// the keys differ inside group g: the last column of the group in which the two rows differ
-				uint64_t k = min<uint64_t>(kend, k0 + (uint64_t) l1 * cl);
-				uint64_t const klo = k0 + (uint64_t) l0 * cl;
-				while (k > klo + 1u && bk_symbol(msa, ld, k - 1u, ra, bsh) == bk_symbol(msa, ld, k - 1u, rb, bsh)) --k;
-				d = (uint32_t) k;
-			}
+			// the keys differ inside group g: the last column of the group in which the two rows differ
+			uint64_t k = min<uint64_t>(kend, k0 + (uint64_t) l1 * cl);
+			uint64_t const klo = k0 + (uint64_t) l0 * cl;
+			while (k > klo + 1u && bk_symbol(msa, ld, k - 1u, ra, bsh) == bk_symbol(msa, ld, k - 1u, rb, bsh)) --k;
+			d = (uint32_t) k;
 		}
 		keyd_out[j] = d;
 	}
 	if (tid == 0) *nkeys_out = Dacc;
-	__syncthreads();                                          // (STREAM: the workspace is reused for the next block)
+	__syncthreads();                                          // the workspace is reused for the next block
 	return sliced;
 }
 
@@ -420,8 +767,8 @@ __global__ __launch_bounds__(T) void k_blockkeys(
 	uint64_t const k0 = col0 + (uint64_t) blockIdx.x * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	size_t const ob = (size_t) blockIdx.x * m;
-	uint32_t const ns = blockkeys_tree<T, false>(smem, msa, ld, m, k0, kend, bsh, cap_words, scratch + (size_t) blockIdx.x * scratch_per_block,
-	                                             rank + ob, keyd + ob, nkeys + blockIdx.x);
+	uint32_t const ns = blockkeys_tree_lds<T>(smem, msa, ld, m, k0, kend, bsh, cap_words, scratch + (size_t) blockIdx.x * scratch_per_block,
+	                                          rank + ob, keyd + ob, nkeys + blockIdx.x);
 	if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 }
 
@@ -438,8 +785,8 @@ __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 		uint64_t const k0 = col0 + (uint64_t) b * B;
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		size_t const ob = (size_t) b * m;
-		uint32_t const ns = blockkeys_tree<1024, true>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-		                                               rank + ob, keyd + ob, nkeys + b);
+		uint32_t const ns = blockkeys_tree_stream(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
+		                                          rank + ob, keyd + ob, nkeys + b);
 		if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 	}
 }
