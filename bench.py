@@ -108,6 +108,77 @@ def cpu_baseline(ctx, w, threads):
     }
 
 
+def rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehearsal):
+    """The north-star partition (positions of the pBWT order sharded over the ranks, two all-reduces per column) on a
+    column prefix of the workload; prints one JSON line on rank 0."""
+    import threading
+    import numpy as np
+    m, cols = w["m"], args.rowshard_cols
+    sigma, bits = (16, 4) if w["kind"] else (4, 2)
+    gen = pkg.SegmentationContext(m, cols, max(1, cols // 4), device=local_rank)
+    gen.generate_synthetic(w["seed"], w["K"], w["B"], w["mu"], w["kind"])
+    msa = gen.get_sequences(0, cols)
+    gen.close()
+    alphabet = np.sort(np.frombuffer(b"ACGTRYSWKMBDHVN-" if w["kind"] else b"ACGT", dtype=np.uint8))
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[alphabet] = np.arange(len(alphabet), dtype=np.uint8)      # consecutive codes in byte order, as the library assigns them
+    packed, ld = pkg.pack_columns(lut[msa], bits)
+    dev = torch.device("cuda", local_rank)
+    nthreads = args.rowshard_threads if world == 1 else 0
+    W = nthreads or world
+    words = pkg.rowshard_xbuf_words(m, bits, W)
+    per = 8 // bits
+
+    def my_columns(r):
+        lo, hi = pkg.rowshard_rows(m, bits, r, W)
+        mine = np.zeros_like(packed)
+        mine[:, lo // per:(hi + per - 1) // per] = packed[:, lo // per:(hi + per - 1) // per]      # this rank's rows only
+        return torch.from_numpy(mine).to(dev)
+
+    results = {}
+    if nthreads:
+        tw = fdist.ThreadWorld(W)
+
+        def work(r):
+            colsd = my_columns(r)
+            tr, ar = tw.transport(words, r, dev)
+            for _ in range(2):                                     # once to warm up, once timed
+                tw.barrier.wait()
+                t0 = time.perf_counter()
+                out = pkg.rowshard_pbwt(colsd.data_ptr(), ld, m, sigma, bits, cols, r, W, tr.ptr, tr.words, ar if W > 1 else None, device=local_rank)
+                tw.barrier.wait()
+                results[r] = (time.perf_counter() - t0, out[5])
+        ths = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+        dt = max(v[0] for v in results.values())
+        nex = results[0][1]
+        transport_name = "ranks as threads of one process on one GPU: barrier + device reduction"
+    else:
+        colsd = my_columns(rank)
+        tr = fdist.ShardTransport(words, dev, dist if world > 1 else None, via_host=rehearsal)
+        nex = 0
+
+        def step():
+            nonlocal nex
+            nex = pkg.rowshard_pbwt(colsd.data_ptr(), ld, m, sigma, bits, cols, rank, world, tr.ptr, tr.words,
+                                    tr.allreduce if world > 1 else None, device=local_rank)[5]
+        dt = fdist.timed_steps(step, 1, 1, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
+                               tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cpu" if rehearsal else "cuda"))
+        transport_name = "1 GPU, no exchange" if world == 1 else ("gloo via host (rehearsal: ranks share a GPU)" if rehearsal else "RCCL")
+    if rank == 0:
+        print(json.dumps({
+            "metric": "row-sharded pBWT sweep, columns/s (north-star partition; conformance path)",
+            "value": cols / dt, "unit": "columns/s", "n_gpus": world, "ranks": W, "higher_is_better": True,
+            "us_per_column": dt / cols * 1e6, "cells_per_s": m * cols / dt, "exchanges": int(nex),
+            "exchanges_per_column": nex / cols, "scaling": "strong", "data": "synthetic", "dtype": "u32",
+            "config": {"workload": "%s prefix: m=%d x %d columns, sigma=%d; positions of the order and rows of the alignment sharded over %d ranks"
+                                   % (args.workload, m, cols, sigma, W),
+                       "transport": transport_name}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +193,12 @@ def main():
     ap.add_argument("--batched", action="store_true", help="also measure 8 alignments in flight on the one GPU (secondary figure)")
     ap.add_argument("--concurrent", type=int, default=1,
                     help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
+    ap.add_argument("--rowshard-cols", type=int, default=0,
+                    help="instead of the headline step: the north-star row split (fseq_rowshard_pbwt) over this many columns of the "
+                         "workload, one JSON line of its own (columns/s; latency-bound by design, DESIGN.md section 6)")
+    ap.add_argument("--rowshard-threads", type=int, default=0,
+                    help="with --rowshard-cols on ONE GPU: this many ranks as threads of the process (all-reduce = barrier + "
+                         "device reduction) instead of torch.distributed ranks")
     args = ap.parse_args()
 
     import torch
@@ -153,6 +230,11 @@ def main():
         args.workload = "C3" if world == 1 else "C4"
     w = dict(WORKLOADS[args.workload])
     m, n, L = w["m"], w["n"], w["L"]
+    if args.rowshard_cols:
+        rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehearsal)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
     transport = None
     if world > 1:

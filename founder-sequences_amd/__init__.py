@@ -70,6 +70,7 @@ EXPORTS = [
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
     "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+    "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
 ]
@@ -131,6 +132,10 @@ def load_library():
     L.fseq_set_shard.argtypes = [vp, C.c_uint32, C.c_uint32, vp, u64, ALLREDUCE_FN, vp]
     L.fseq_shard_columns.argtypes = [vp, C.POINTER(u64), C.POINTER(u64)]
     L.fseq_shard_owner.argtypes = [vp, u64, C.POINTER(C.c_uint32)]
+    L.fseq_rowshard_xbuf_words.restype = u64
+    L.fseq_rowshard_xbuf_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+    L.fseq_rowshard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.fseq_rowshard_pbwt.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(u64)]
     _lib = L
     return L
 
@@ -170,6 +175,61 @@ def debug_rmq(keys, beg, end, device=0):
     if rc != FSEQ_OK:
         raise FseqError(rc, L.fseq_strerror(rc).decode())
     return a, b
+
+
+class RowShard(C.Structure):
+    _fields_ = [("device", C.c_int32), ("rank", C.c_uint32), ("world", C.c_uint32), ("m", C.c_uint32), ("sigma", C.c_uint32),
+                ("bits", C.c_uint32), ("ncols", C.c_uint64), ("d_cols", C.c_void_p), ("ld", C.c_size_t), ("xbuf", C.c_void_p),
+                ("xbuf_words", C.c_uint64), ("fn", ALLREDUCE_FN), ("user", C.c_void_p)]
+
+
+def pack_columns(msa_codes, bits):
+    """Row-major codes (m x n, values < 2**bits) -> column-major packed bytes (n x ld, ld a multiple of 16): the layout
+    fseq_set_device_columns_packed and fseq_rowshard_pbwt read (row r of a column in byte r * bits / 8)."""
+    m, n = msa_codes.shape
+    per = 8 // bits
+    ld = ((m + per - 1) // per + 15) // 16 * 16
+    cols = np.zeros((n, ld * per), dtype=np.uint8)
+    cols[:, :m] = msa_codes.T
+    out = np.zeros((n, ld), dtype=np.uint8)
+    for j in range(per):
+        out |= (cols[:, j::per] << (bits * j)).astype(np.uint8)
+    return out, ld
+
+
+def rowshard_xbuf_words(m, bits, world):
+    return int(load_library().fseq_rowshard_xbuf_words(m, bits, world))
+
+
+def rowshard_rows(m, bits, rank, world):
+    lo, hi = C.c_uint32(), C.c_uint32()
+    rc = load_library().fseq_rowshard_rows(m, bits, rank, world, C.byref(lo), C.byref(hi))
+    if rc != FSEQ_OK:
+        raise FseqError(rc, load_library().fseq_strerror(rc).decode())
+    return lo.value, hi.value
+
+
+def rowshard_pbwt(d_cols_ptr, ld, m, sigma, bits, ncols, rank, world, xbuf_ptr, xbuf_words, allreduce=None, device=0):
+    """fseq_rowshard_pbwt (the north-star row split, include/fseq.h): returns (a, d, pos_lo, pos_hi, ms, exchanges);
+    a / d are m long with this rank's positions [pos_lo, pos_hi) filled in.  allreduce(offset, count, op) -> 0."""
+    L = load_library()
+
+    def _cb(_user, off, cnt, op):
+        try:
+            return int(allreduce(int(off), int(cnt), int(op)) or 0)
+        except Exception:                           # an exception must not unwind through the C frame
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = ALLREDUCE_FN(_cb) if allreduce is not None else ALLREDUCE_FN()
+    args = RowShard(device, rank, world, m, sigma, bits, ncols, d_cols_ptr, ld, xbuf_ptr, xbuf_words, cb, None)
+    a = np.zeros(m, dtype=np.uint32)
+    d = np.zeros(m, dtype=np.uint32)
+    lo, hi, ms, nex = C.c_uint32(), C.c_uint32(), C.c_double(), C.c_uint64()
+    rc = L.fseq_rowshard_pbwt(C.byref(args), a.ctypes.data, d.ctypes.data, C.byref(lo), C.byref(hi), C.byref(ms), C.byref(nex))
+    if rc != FSEQ_OK:
+        raise FseqError(rc, L.fseq_strerror(rc).decode())
+    return a, d, lo.value, hi.value, ms.value, nex.value
 
 
 def dp_schedule(segment_length, n, col_hi):

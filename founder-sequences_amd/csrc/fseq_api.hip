@@ -11,6 +11,7 @@
 #include "fseq_dpspec.hpp"
 #include "fseq_stream.hpp"
 #include "fseq_blockkeys.hpp"
+#include "fseq_rowshard.hpp"
 #include "fseq_join.hpp"
 
 #include <algorithm>
@@ -2283,6 +2284,111 @@ int fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi,
 	if (rounds_within) *rounds_within = dp_rounds_within(S, col_hi);
 	if (pipelined) *pipelined = S.pipe ? 1 : 0;
 	return FSEQ_OK;
+}
+
+// ---- row-sharded pBWT sweep: the north-star partition as a conformance path (fseq_rowshard.hpp) ------------------
+uint64_t fseq_rowshard_xbuf_words(uint32_t m, uint32_t bits, uint32_t world)
+{
+	if (!m || !world || (bits != 2 && bits != 4 && bits != 8)) return 0;
+	uint32_t const bsh = bits == 2 ? 2u : bits == 4 ? 1u : 0u;
+	uint64_t const cw = (sym_bytes(m, bsh) + 3u) / 4u;
+	return 2 * (cw + 2ull * m) + (uint64_t) RS_SLOT * world + 64;
+}
+
+int fseq_rowshard_rows(uint32_t m, uint32_t bits, uint32_t rank, uint32_t world, uint32_t *row_lo, uint32_t *row_hi)
+{
+	if (!m || !world || rank >= world || !row_lo || !row_hi || (bits != 2 && bits != 4 && bits != 8)) return FSEQ_E_ARG;
+	uint32_t const bsh = bits == 2 ? 2u : bits == 4 ? 1u : 0u;
+	uint64_t const cw = (sym_bytes(m, bsh) + 3u) / 4u, rpw = 32u / bits;
+	*row_lo = (uint32_t) std::min<uint64_t>(m, cw * rank / world * rpw);
+	*row_hi = (uint32_t) std::min<uint64_t>(m, cw * (rank + 1) / world * rpw);
+	return FSEQ_OK;
+}
+
+int fseq_rowshard_pbwt(fseq_rowshard const *A, uint32_t *a_out, uint32_t *d_out, uint32_t *pos_lo, uint32_t *pos_hi,
+                       double *ms, uint64_t *n_exchanges)
+{
+	if (!A || !A->m || !A->world || A->rank >= A->world || !A->d_cols || !a_out || !d_out) return FSEQ_E_ARG;
+	if ((A->bits != 2 && A->bits != 4 && A->bits != 8) || A->sigma < 1 || A->sigma > (1u << A->bits)) return FSEQ_E_ARG;
+	uint32_t const m = A->m, G = A->world, g = A->rank;
+	uint32_t const bsh = A->bits == 2 ? 2u : A->bits == 4 ? 1u : 0u;
+	uint64_t const cw = (sym_bytes(m, bsh) + 3u) / 4u;
+	if (A->ld % 4 || A->ld < cw * 4) return FSEQ_E_ARG;
+	if (A->ncols > 0xFFFFFFFEull) return FSEQ_E_ARG;
+	if (G > 1 && (!A->xbuf || !A->fn)) return FSEQ_E_ARG;
+	if (!A->xbuf || A->xbuf_words < fseq_rowshard_xbuf_words(m, A->bits, G)) return FSEQ_E_ARG;
+	if (hipSetDevice(A->device) != hipSuccess) return FSEQ_E_HIP;
+	uint32_t nbits = 1;
+	while ((1u << nbits) < A->sigma) ++nbits;
+	uint32_t const npass = (nbits + 1) / 2;
+	uint64_t const reg = cw + 2ull * m;
+	uint32_t *const xb = static_cast<uint32_t *>(A->xbuf);
+	uint32_t *const slots = xb + 2 * reg;
+	auto C_ = [&](uint32_t r) { return xb + r * reg; };
+	auto A_ = [&](uint32_t r) { return xb + r * reg + cw; };
+	auto D_ = [&](uint32_t r) { return xb + r * reg + cw + m; };
+	uint32_t const p_lo = (uint32_t) ((uint64_t) m * g / G), p_hi = (uint32_t) ((uint64_t) m * (g + 1) / G), ml = p_hi - p_lo;
+	uint32_t const w_lo = (uint32_t) (cw * g / G), w_hi = (uint32_t) (cw * (g + 1) / G);
+	hipStream_t st = nullptr;
+	if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return FSEQ_E_HIP;
+	uint64_t nex = 0;
+	bool ok = true;
+	auto H = [&](hipError_t e) { if (e != hipSuccess) ok = false; return e == hipSuccess; };
+	auto xch = [&](uint64_t off, uint64_t count) {
+		++nex;
+		if (G == 1 || !ok) return;
+		if (!H(hipStreamSynchronize(st))) return;
+		if (A->fn(A->user, off, count, 0) != 0) ok = false;
+	};
+	auto contrib = [&](uint64_t k, uint32_t r) {
+		H(hipMemsetAsync(C_(r), 0, cw * 4, st));
+		if (w_hi > w_lo)
+			hipLaunchKernelGGL(k_rs_contrib, dim3((w_hi - w_lo + 255u) / 256u), dim3(256), 0, st,
+			                   reinterpret_cast<uint32_t const *>(static_cast<uint8_t const *>(A->d_cols) + k * A->ld), w_lo, w_hi, C_(r));
+	};
+	double const t0 = now_ms();
+	hipLaunchKernelGGL(k_rs_init, dim3((m + 255u) / 256u), dim3(256), 0, st, A_(0), D_(0), m);
+	uint32_t colreg = 0, adreg = 0;
+	if (A->ncols)
+	{
+		contrib(0, 0);
+		xch(0, cw);                                              // X0 of column 0
+	}
+	for (uint64_t k = 0; k < A->ncols && ok; ++k)
+		for (uint32_t pass = 0; pass < npass && ok; ++pass)
+		{
+			uint8_t const *col = reinterpret_cast<uint8_t const *>(C_(colreg));
+			H(hipMemsetAsync(slots, 0, (size_t) RS_SLOT * G * 4, st));
+			hipLaunchKernelGGL(k_rs_sweep<false>, dim3(1), dim3(ST), 0, st, col, A_(adreg) + p_lo, D_(adreg) + p_lo, ml, bsh, pass,
+			                   (uint32_t) (k + 1), slots, g, G, (uint32_t *) nullptr, (uint32_t *) nullptr);
+			xch(2 * reg, (uint64_t) RS_SLOT * G);                   // X1 + X2
+			uint32_t const r2 = 1u - adreg;
+			H(hipMemsetAsync(A_(r2), 0, (size_t) 2 * m * 4, st));
+			hipLaunchKernelGGL(k_rs_sweep<true>, dim3(1), dim3(ST), 0, st, col, A_(adreg) + p_lo, D_(adreg) + p_lo, ml, bsh, pass,
+			                   (uint32_t) (k + 1), slots, g, G, A_(r2), D_(r2));
+			if (pass + 1 == npass && k + 1 < A->ncols)
+			{
+				contrib(k + 1, r2);
+				xch(r2 * reg, reg);                                  // X3 + X0 of the next column
+				colreg = r2;
+			}
+			else
+				xch(r2 * reg + cw, 2ull * m);                        // X3
+			adreg = r2;
+		}
+	if (ok) H(hipStreamSynchronize(st));
+	double const t1 = now_ms();
+	if (ok && ml)
+	{
+		H(hipMemcpy(a_out + p_lo, A_(adreg) + p_lo, (size_t) ml * 4, hipMemcpyDeviceToHost));
+		H(hipMemcpy(d_out + p_lo, D_(adreg) + p_lo, (size_t) ml * 4, hipMemcpyDeviceToHost));
+	}
+	(void) hipStreamDestroy(st);
+	if (pos_lo) *pos_lo = p_lo;
+	if (pos_hi) *pos_hi = p_hi;
+	if (ms) *ms = t1 - t0;
+	if (n_exchanges) *n_exchanges = nex;
+	return ok ? FSEQ_OK : FSEQ_E_HIP;
 }
 
 int fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,

@@ -57,8 +57,9 @@ class ThreadWorld:
         self.barrier = threading.Barrier(world)
         self.bufs = [None] * world
 
-    def attach(self, ctx, rank, device):
-        tr = ShardTransport(ctx.shard_xbuf_words(self.world), device, None)
+    def transport(self, words, rank, device):
+        """(ShardTransport, allreduce(offset, count, op)) of one rank: a buffer of `words` words on `device`."""
+        tr = ShardTransport(words, device, None)
         self.bufs[rank] = tr.buf
         torch = tr.torch
 
@@ -77,6 +78,10 @@ class ThreadWorld:
             self.barrier.wait()
             return 0
 
+        return tr, allreduce
+
+    def attach(self, ctx, rank, device):
+        tr, allreduce = self.transport(ctx.shard_xbuf_words(self.world), rank, device)
         ctx.set_shard(rank, self.world, tr.ptr, tr.words, allreduce)
         ctx._transport = tr
         return tr

@@ -155,6 +155,36 @@ int  fseq_shard_columns(fseq_ctx const *ctx, uint64_t *first, uint64_t *last);
 /* rank that owns the boundary state at column rb */
 int  fseq_shard_owner(fseq_ctx const *ctx, uint64_t rb, uint32_t *rank);
 
+/* ---- Row-sharded pBWT sweep: BASELINE.json north_star's partition, as a conformance path ----------------------
+ * "Rows shard across the GPUs with a per-column sigma-bucket-histogram all-reduce and a boundary exchange for the
+ * divergence scan": rank g of `world` owns the positions [m g / world, m (g + 1) / world) of the order (a_k, d_k)
+ * and supplies the symbols of the rows fseq_rowshard_rows reports; every column (and 2-bit digit of a wider
+ * alphabet) costs two all-reduces through the same fseq_allreduce_fn as above -- the column itself plus the scattered
+ * (a, d), and one 12-word summary per rank (bucket counts, running maxima, symbols seen).  The sweep therefore runs
+ * at the latency of the collective (DESIGN.md section 6 has the measured curve); the production split of one
+ * alignment over GPUs is fseq_set_shard's column blocks, which exchange per phase, not per column.
+ * Computes what the per-column update of libbio::pbwt_context computes when founder_sequences.hh:56-65 drives it
+ *  over the columns [0, ncols) from the identity order: bit-identical to the single-GPU path.
+ * d_cols: device, column-major packed codes < sigma (the layout of fseq_set_device_columns_packed: `bits` per row,
+ * row r of a column in byte r * bits / 8, ld bytes from column to column, ld a multiple of 4); only this rank's rows
+ * are read.  a_out / d_out: host, m entries each; the entries [*pos_lo, *pos_hi) are written. */
+typedef struct fseq_rowshard {
+	int32_t  device;
+	uint32_t rank, world;
+	uint32_t m, sigma, bits;
+	uint64_t ncols;
+	void const *d_cols;
+	size_t   ld;
+	void    *xbuf;                 /* device, fseq_rowshard_xbuf_words uint32 words; every rank its own */
+	uint64_t xbuf_words;
+	fseq_allreduce_fn fn;          /* may be NULL when world == 1 */
+	void    *user;
+} fseq_rowshard;
+uint64_t fseq_rowshard_xbuf_words(uint32_t m, uint32_t bits, uint32_t world);
+int  fseq_rowshard_rows(uint32_t m, uint32_t bits, uint32_t rank, uint32_t world, uint32_t *row_lo, uint32_t *row_hi);
+int  fseq_rowshard_pbwt(fseq_rowshard const *args, uint32_t *a_out, uint32_t *d_out, uint32_t *pos_lo, uint32_t *pos_hi,
+                        double *ms, uint64_t *n_exchanges);
+
 /* replaces: generate_traceback + update_samples_to_traceback_positions + find_segments_greedy
  * (segmentation_lp_context.cc:26-390) or segmentation_sp_context::process
  * (segmentation_sp_context.cc:21-28) when n < 2L.  Returns FSEQ_E_NO_REDUCTION exactly when the

@@ -362,3 +362,85 @@ def segment_sharded(codes, L, B, X, rank, world, allreduce, forced_rounds=0, sta
             sa, sd = pb.colstep(sa, sd, codes[sa, k], k + 1)
         snaps[i] = (sa, sd)
     return dict(M=M, LB=LB, SZ=SZ, traceback=tb, max_segment_size=max_seg, reduced=red, snaps=snaps, geometry=G, X=X)
+
+
+# ---- the north-star row split (csrc/fseq_rowshard.hpp, fseq_rowshard_pbwt): a model of its exchange arithmetic -------
+def rowshard_pbwt(codes, ncols, rank, world, allreduce, sigma=4):
+    """pBWT over the columns [0, ncols) with the positions of the order split over `world` ranks and the symbols of
+    the rows split likewise; per column (and 2-bit digit) X0 the column (zero elsewhere + sum), X1 + X2 one summary
+    per rank (bucket counts, running maximum since the last occurrence of every digit, digits seen), X3 the scatter
+    (zero elsewhere + sum, together with X0 of the next column).  allreduce(array, op) -> summed array on every rank.
+    Returns (a, d, exchanges): the whole order as every rank holds it after the last scatter."""
+    m = codes.shape[0]
+    p_lo, p_hi = m * rank // world, m * (rank + 1) // world
+    r_lo, r_hi = m * rank // world, m * (rank + 1) // world
+    nbits = max(1, int(np.ceil(np.log2(max(2, sigma)))))
+    npass = (nbits + 1) // 2
+    a = np.arange(m, dtype=np.int64)
+    d = np.zeros(m, dtype=np.int64)
+    calls = 0
+
+    def mine(k):
+        c = np.zeros(m, dtype=np.int64)
+        c[r_lo:r_hi] = codes[r_lo:r_hi, k]
+        return c
+
+    if ncols == 0:
+        return a, d, 0
+    col = allreduce(mine(0), 0)
+    calls += 1
+    for k in range(ncols):
+        for ps in range(npass):
+            dig = (col >> (2 * ps)) & 3
+            # ---- summary of my positions
+            cnt = np.zeros(4, dtype=np.int64)
+            val = np.zeros(4, dtype=np.int64)
+            has = 0
+            for p in range(p_lo, p_hi):
+                s = int(dig[a[p]])
+                val = np.maximum(val, d[p])
+                val[s] = 0
+                cnt[s] += 1
+                has |= 1 << s
+            slots = np.zeros((world, 9), dtype=np.int64)
+            slots[rank, 0:4] = cnt
+            slots[rank, 4:8] = val
+            slots[rank, 8] = has
+            slots = allreduce(slots.ravel(), 0).reshape(world, 9)
+            calls += 1
+            # ---- carry of the ranks to my left, bucket starts
+            cval = np.zeros(4, dtype=np.int64)
+            chas = 0
+            ccnt = np.zeros(4, dtype=np.int64)
+            for h in range(rank):
+                hh = int(slots[h, 8])
+                for x in range(4):
+                    cval[x] = slots[h, 4 + x] if (hh >> x) & 1 else max(cval[x], slots[h, 4 + x])
+                chas |= hh
+                ccnt += slots[h, 0:4]
+            tot = slots[:, 0:4].sum(axis=0)
+            start = np.concatenate([[0], np.cumsum(tot)[:-1]])
+            # ---- my rows to their destinations
+            xa = np.zeros(m, dtype=np.int64)
+            xd = np.zeros(m, dtype=np.int64)
+            run = cval.copy()
+            seen = chas
+            nxt = start + ccnt
+            for p in range(p_lo, p_hi):
+                s = int(dig[a[p]])
+                run = np.maximum(run, d[p])
+                dn = int(run[s]) if (seen >> s) & 1 else k + 1
+                run[s] = 0
+                seen |= 1 << s
+                xa[nxt[s]] = a[p]
+                xd[nxt[s]] = dn
+                nxt[s] += 1
+            last = ps + 1 == npass
+            if last and k + 1 < ncols:
+                buf = allreduce(np.concatenate([mine(k + 1), xa, xd]), 0)
+                col, a, d = buf[:m], buf[m:2 * m], buf[2 * m:]
+            else:
+                buf = allreduce(np.concatenate([xa, xd]), 0)
+                a, d = buf[:m], buf[m:]
+            calls += 1
+    return a, d, calls

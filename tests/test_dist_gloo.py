@@ -95,6 +95,55 @@ def test_two_ranks_shard_one_alignment_over_gloo():
     assert x0 == x1 and x0 > 2                              # the retry with longer lists happened on both
 
 
+def _rowshard_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    for p in (HERE, os.path.dirname(HERE), os.path.join(os.path.dirname(HERE), "oracle")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import fso
+    import proto_shard as ps
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        def allreduce(arr, op):
+            t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int64).copy())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
+            return t.numpy()
+
+        ok = True
+        calls = []
+        for (m, n, K, B, mu, seed, kind) in [(41, 60, 4, 20, 2e-2, 71, 0), (30, 25, 5, 10, 3e-2, 72, 1)]:
+            msa = fso.synth_msa(fso.synth_spec(seed, K, B, mu, kind), m, n)
+            al = np.unique(msa)
+            codes = np.searchsorted(al, msa).astype(np.int64)
+            a, d, c = ps.rowshard_pbwt(codes, n, rank, world, allreduce, sigma=len(al))
+            p = fso.Pbwt(msa)
+            while p.idx < n:
+                p.step()
+            ok = ok and np.array_equal(a, p.a) and np.array_equal(d, p.d)
+            calls.append(c)
+        q.put((rank, bool(ok), calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_row_shard_the_pbwt_over_gloo():
+    """The north-star partition (positions of the order over the ranks; per column the column, one summary per rank,
+    the scatter -- csrc/fseq_rowshard.hpp) as its Python model in two processes joined by gloo all-reduces only."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rowshard_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert out[0][1] and out[1][1]
+    assert out[0][2] == out[1][2] == [1 + 2 * 60, 1 + 2 * 2 * 25]      # two exchanges per column and 2-bit digit
+
+
 def test_assignment_covers_everything_once():
     d = importlib.import_module("founder-sequences_amd.dist")
     for n in (0, 1, 7, 22, 64):
