@@ -19,7 +19,17 @@ constexpr uint32_t STREAM_MAX_COLBYTES = 147456;   // column staging: one packed
 struct StreamLds {
 	StepScratch<ST, 4> scr;
 	uint32_t red[4 * (ST / WAVE) + 8];
+	uint32_t sink[WAVE];                             // where stream_touch's loads land (never read)
 };
+
+// One dword per lane from `g` into LDS at lds_addr + 4 * lane (LDS-DMA: no destination register, so nothing waits for
+// it and nothing can be clobbered by it): used to pull the NEXT tile's lines into L2 while this tile is computed.
+__device__ __forceinline__ void stream_touch(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
 
 // staged: plus the 2 x SCAP words in which stream_pass lays a tile out in output order
 __host__ __device__ inline size_t stream_lds_bytes(uint32_t colbytes, bool staged)
@@ -128,6 +138,7 @@ __device__ __forceinline__ void stream_pass(
 	// first laid out in LDS in output order -- its four bucket runs back to back -- and written out with
 	// consecutive lanes on consecutive words: the direct scatter writes every 32-byte sector in several
 	// partial pieces (measured: 2x the write traffic, 1.4x the time of phase A at m = 100,000).
+	uint32_t const sink = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) L.sink);
 	for (uint32_t base = 0; base < m; base += SCAP)
 	{
 		uint32_t a[SE], d[SE], s[SE], dst[SE], dnew[SE];
@@ -139,6 +150,15 @@ __device__ __forceinline__ void stream_pass(
 			a[e] = in ? a_src[pos] : 0u;
 			d[e] = (in && !KEYS) ? d_src[pos] : 0u;
 			s[e] = in ? digit(a[e]) : 4u;
+		}
+		// The next tile's rows on their way from HBM into L2 while this tile is partitioned (one workgroup per CU: no
+		// other wave would hide that latency): one touch per 64 bytes, the first half of the workgroup for a, the
+		// second for d.
+		{
+			uint32_t const w = base + SCAP + (tid & (ST / 2 - 1)) * 16u;
+			bool const second = tid >= ST / 2;
+			if (w < m && (tid & (ST / 2 - 1)) < SCAP / 16u && !(second && KEYS))
+				stream_touch((second ? d_src : a_src) + w, sink);
 		}
 		uint32_t gs[4];
 #pragma unroll
