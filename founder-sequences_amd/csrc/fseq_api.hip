@@ -494,6 +494,8 @@ int prepare_geometry(fseq_ctx *c)
 		c->lds_columns = c->ks.columns_lds(c->B);
 		if (c->lds_columns > LDS_LIMIT || c->ks.lds_chain > LDS_LIMIT || c->ks.lds_colblock > LDS_LIMIT || c->ks.lds_snap > LDS_LIMIT)
 			return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
+		// phase C works on value ids < m + B in 16-bit keys (partition_step<.., KEY16>); the LDS check above implies it
+		if ((uint64_t) p.m + c->B > 65535u) return fail(c, FSEQ_E_UNSUPPORTED, "block length too large for the 16-bit value ids of phase C");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
 		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the two maps take what is left of ~76 KiB
 		// (two workgroups per CU) when that holds the leaf map with a quarter to spare, else of the whole CU

@@ -53,6 +53,18 @@ __device__ __forceinline__ uint32_t wave_incl_add(uint32_t v)
 	return v;
 }
 
+// inclusive max-scan over the 64 lanes of a wave (identity 0)
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v)
+{
+	v = max(v, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, v));
+	v = max(v, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, v));
+	v = max(v, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, v));
+	v = max(v, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, v));
+	v = max(v, dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, v));
+	v = max(v, dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, v));
+	return v;
+}
+
 // minimum over the 64 lanes of a wave (returned in every lane)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
@@ -201,7 +213,14 @@ struct TileCarry {
 // before it (and is advanced past this tile), bucket starts come from tc->start.
 // IDLE0: wave 0 owns no rows (phase C keeps it free for the per-column list, fseq_kernels.hpp): it contributes the
 // identity summary and skips the arithmetic, but meets the step's barrier.
-template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false>
+// KEY16: every d and first_val is below 65536 (value ids of phase C, block-relative divergences of a rank block).
+// The scan of the running maxima -- combine(L, R).val[x] = R.has[x] ? R.val[x] : max(L.val[x], R.val[x]), four
+// instructions per symbol and step -- then becomes a plain max-scan of keys (occurrences of x so far) << 16 | val[x]:
+// the bucket counts are scanned first (they are needed anyway), a thread's key carries its INCLUSIVE count of x, so
+// the maximum over the threads to the left picks the threads behind the last x (equal counts) and among them the
+// largest value; a thread that holds x itself restarts with its own tail maximum.  The key's upper half is at the
+// same time the exclusive bucket count and the "seen before" test.  ~250 -> ~100 instructions per step.
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, bool KEY16 = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
 	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr)
@@ -258,6 +277,121 @@ __device__ __forceinline__ void partition_step(
 		pend |= (act && !((has >> (c & 15u)) & 1u)) ? (1u << e) : 0u;
 		lcp += act ? (1ull << sh) : 0ull;
 		has |= act ? (1u << (c & 15u)) : 0u;
+	}
+
+	if constexpr (KEY16)
+	{
+		static_assert(!TILE, "the keyed scan is for orders that fit one workgroup");
+		// ---- bucket counts: inclusive over the lanes (two 16-bit counts per word: at most T * E <= 65535 rows)
+		uint32_t ic[NC];
+#pragma unroll
+		for (int i = 0; i < NC; ++i)
+		{
+			uint32_t const lo = (uint32_t) (lcp >> (8 * i)) & 15u;
+			uint32_t const hi = (uint32_t) (lcp >> (8 * i + 4)) & 15u;
+			ic[i] = wave_incl_add(lo | (hi << 16));
+		}
+		// ---- keys, inclusive max-scan
+		uint32_t key[SIGMA];
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x)
+		{
+			uint32_t const occ16 = (x & 1) ? (ic[x >> 1] & 0xFFFF0000u) : (ic[x >> 1] << 16);
+			key[x] = wave_incl_max(occ16 | run[x]);
+		}
+		if (NW > 1 && lane == 63)
+		{
+#pragma unroll
+			for (int i = 0; i < NC; ++i) scr.cnt[wave][i] = ic[i];
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) scr.val[wave][x] = key[x] & 0xFFFFu;
+		}
+		// exclusive within the wave (lane 0: the identity)
+		uint32_t ek[SIGMA];
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) ek[x] = dpp_mov<DPP_WAVE_SHR1, 0xF>(0u, key[x]);
+		uint32_t totc[NC], pc[NC], pk[SIGMA];
+#pragma unroll
+		for (int i = 0; i < NC; ++i) pc[i] = 0;
+#pragma unroll
+		for (int x = 0; x < SIGMA; ++x) pk[x] = 0;
+		__syncthreads();
+		if (NW == 1)
+		{
+#pragma unroll
+			for (int i = 0; i < NC; ++i) totc[i] = readlane_u32(ic[i], 63);
+		}
+		else
+		{
+			// second level over the NW <= 16 wave totals (lanes 0 .. NW-1 of DPP row 0), every wave for itself
+			static_assert(NW <= 16, "wave totals fit one DPP row");
+			uint32_t wc[NC], wk[SIGMA];
+#pragma unroll
+			for (int i = 0; i < NC; ++i) wc[i] = lane < (uint32_t) NW ? scr.cnt[lane][i] : 0u;
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) wk[x] = lane < (uint32_t) NW ? scr.val[lane][x] : 0u;
+#pragma unroll
+			for (int i = 0; i < NC; ++i)
+			{
+				wc[i] += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, wc[i]);
+				if (NW > 2) wc[i] += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, wc[i]);
+				if (NW > 4) wc[i] += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, wc[i]);
+				if (NW > 8) wc[i] += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, wc[i]);
+			}
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x)
+			{
+				uint32_t const occ16 = (x & 1) ? (wc[x >> 1] & 0xFFFF0000u) : (wc[x >> 1] << 16);
+				uint32_t k = occ16 | wk[x];
+				k = max(k, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, k));
+				if (NW > 2) k = max(k, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, k));
+				if (NW > 4) k = max(k, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, k));
+				if (NW > 8) k = max(k, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, k));
+				wk[x] = k;
+			}
+#pragma unroll
+			for (int i = 0; i < NC; ++i) totc[i] = readlane_u32(wc[i], NW - 1);
+			if (wave > 0)
+			{
+				int const src = (int) __builtin_amdgcn_readfirstlane(wave) - 1;
+#pragma unroll
+				for (int i = 0; i < NC; ++i) pc[i] = readlane_u32(wc[i], src);
+#pragma unroll
+				for (int x = 0; x < SIGMA; ++x) pk[x] = readlane_u32(wk[x], src);
+			}
+		}
+		// ---- this thread's prefix: key of the waves to the left against the lanes to the left (whose counts are
+		// wave-local: lifted by the count of the waves to the left); its upper half = rows of bucket x in front
+		uint32_t base[SIGMA], cval[SIGMA];
+		{
+			uint32_t acc = 0;
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x)
+			{
+				uint32_t const pocc16 = (x & 1) ? (pc[x >> 1] & 0xFFFF0000u) : (pc[x >> 1] << 16);
+				uint32_t const k = max(pk[x], ek[x] + pocc16);
+				base[x] = acc + (k >> 16);
+				cval[x] = k;                                       // (upper half != 0: x was seen before)
+				acc += (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+			}
+		}
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			uint32_t const c = s[e];
+			uint32_t b = 0, cv = 0;
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x)
+			{
+				bool const is = (c == (uint32_t) x);
+				b = is ? base[x] : b;
+				cv = is ? cval[x] : cv;
+			}
+			if ((pend >> e) & 1u)
+				dnew[e] = (cv >> 16) ? max(cv & 0xFFFFu, dnew[e]) : first_val;
+			dst[e] = b + lidx[e];
+		}
+		return;
 	}
 
 	Summary<SIGMA> S;
