@@ -480,7 +480,8 @@ int prepare_geometry(fseq_ctx *c)
 		size_t const lds = stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged);
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK>, lds));
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
-		HIP_TRY(c, allow_lds(k_columns_stream, lds));
+		HIP_TRY(c, allow_lds(k_columns_stream<19>, lds));
+		HIP_TRY(c, allow_lds(k_columns_stream<0>, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
 		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
 		c->bk_cap_words = 12288;                               // two bitmaps + 32-bit prefix counts: 12 B per word
@@ -1273,8 +1274,11 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
-			if (c->use_stream)
-				hipLaunchKernelGGL(k_columns_stream, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+			if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !getenv("FSEQ_STREAM_PLAIN_SCAN"))
+				hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+			else if (c->use_stream)
+				hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
 				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 			else
 				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,

@@ -213,14 +213,15 @@ struct TileCarry {
 // before it (and is advanced past this tile), bucket starts come from tc->start.
 // IDLE0: wave 0 owns no rows (phase C keeps it free for the per-column list, fseq_kernels.hpp): it contributes the
 // identity summary and skips the arithmetic, but meets the step's barrier.
-// KEY16: every d and first_val is below 65536 (value ids of phase C, block-relative divergences of a rank block).
+// KS (key shift, 16 .. 19; 0 = off): every d and first_val is below 2^KS (value ids of phase C, block-relative
+// divergences) and one step holds fewer than 2^(32 - KS) rows.
 // The scan of the running maxima -- combine(L, R).val[x] = R.has[x] ? R.val[x] : max(L.val[x], R.val[x]), four
-// instructions per symbol and step -- then becomes a plain max-scan of keys (occurrences of x so far) << 16 | val[x]:
+// instructions per symbol and step -- then becomes a plain max-scan of keys (occurrences of x so far) << KS | val[x]:
 // the bucket counts are scanned first (they are needed anyway), a thread's key carries its INCLUSIVE count of x, so
 // the maximum over the threads to the left picks the threads behind the last x (equal counts) and among them the
 // largest value; a thread that holds x itself restarts with its own tail maximum.  The key's upper half is at the
 // same time the exclusive bucket count and the "seen before" test.  ~250 -> ~100 instructions per step.
-template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, bool KEY16 = false>
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
 	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr)
@@ -279,9 +280,11 @@ __device__ __forceinline__ void partition_step(
 		has |= act ? (1u << (c & 15u)) : 0u;
 	}
 
-	if constexpr (KEY16)
+	if constexpr (KS != 0)
 	{
-		static_assert(!TILE, "the keyed scan is for orders that fit one workgroup");
+		constexpr uint32_t VMASK = (1u << KS) - 1u;
+		static_assert(KS >= 16 && KS <= 19, "key = count << KS | value: counts of one step below 2^(32 - KS)");
+		static_assert((uint64_t) T * E < (1ull << (32 - KS)), "counts of one step must fit the key");
 		// ---- bucket counts: inclusive over the lanes (two 16-bit counts per word: at most T * E <= 65535 rows)
 		uint32_t ic[NC];
 #pragma unroll
@@ -291,26 +294,25 @@ __device__ __forceinline__ void partition_step(
 			uint32_t const hi = (uint32_t) (lcp >> (8 * i + 4)) & 15u;
 			ic[i] = wave_incl_add(lo | (hi << 16));
 		}
+		auto occ_key = [](uint32_t const (&c)[NC], int x) -> uint32_t {        // count of x, in key position
+			return (x & 1) ? ((c[x >> 1] >> 16) << KS) : ((c[x >> 1] & 0xFFFFu) << KS);
+		};
 		// ---- keys, inclusive max-scan
 		uint32_t key[SIGMA];
 #pragma unroll
-		for (int x = 0; x < SIGMA; ++x)
-		{
-			uint32_t const occ16 = (x & 1) ? (ic[x >> 1] & 0xFFFF0000u) : (ic[x >> 1] << 16);
-			key[x] = wave_incl_max(occ16 | run[x]);
-		}
+		for (int x = 0; x < SIGMA; ++x) key[x] = wave_incl_max(occ_key(ic, x) | run[x]);
 		if (NW > 1 && lane == 63)
 		{
 #pragma unroll
 			for (int i = 0; i < NC; ++i) scr.cnt[wave][i] = ic[i];
 #pragma unroll
-			for (int x = 0; x < SIGMA; ++x) scr.val[wave][x] = key[x] & 0xFFFFu;
+			for (int x = 0; x < SIGMA; ++x) scr.val[wave][x] = key[x] & VMASK;
 		}
 		// exclusive within the wave (lane 0: the identity)
 		uint32_t ek[SIGMA];
 #pragma unroll
 		for (int x = 0; x < SIGMA; ++x) ek[x] = dpp_mov<DPP_WAVE_SHR1, 0xF>(0u, key[x]);
-		uint32_t totc[NC], pc[NC], pk[SIGMA];
+		uint32_t totc[NC], pc[NC], pk[SIGMA], totk[SIGMA];
 #pragma unroll
 		for (int i = 0; i < NC; ++i) pc[i] = 0;
 #pragma unroll
@@ -320,6 +322,8 @@ __device__ __forceinline__ void partition_step(
 		{
 #pragma unroll
 			for (int i = 0; i < NC; ++i) totc[i] = readlane_u32(ic[i], 63);
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) totk[x] = TILE ? readlane_u32(key[x], 63) : 0u;
 		}
 		else
 		{
@@ -341,8 +345,7 @@ __device__ __forceinline__ void partition_step(
 #pragma unroll
 			for (int x = 0; x < SIGMA; ++x)
 			{
-				uint32_t const occ16 = (x & 1) ? (wc[x >> 1] & 0xFFFF0000u) : (wc[x >> 1] << 16);
-				uint32_t k = occ16 | wk[x];
+				uint32_t k = occ_key(wc, x) | wk[x];
 				k = max(k, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, k));
 				if (NW > 2) k = max(k, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, k));
 				if (NW > 4) k = max(k, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, k));
@@ -351,6 +354,8 @@ __device__ __forceinline__ void partition_step(
 			}
 #pragma unroll
 			for (int i = 0; i < NC; ++i) totc[i] = readlane_u32(wc[i], NW - 1);
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) totk[x] = TILE ? readlane_u32(wk[x], NW - 1) : 0u;
 			if (wave > 0)
 			{
 				int const src = (int) __builtin_amdgcn_readfirstlane(wave) - 1;
@@ -361,18 +366,40 @@ __device__ __forceinline__ void partition_step(
 			}
 		}
 		// ---- this thread's prefix: key of the waves to the left against the lanes to the left (whose counts are
-		// wave-local: lifted by the count of the waves to the left); its upper half = rows of bucket x in front
-		uint32_t base[SIGMA], cval[SIGMA];
+		// wave-local: lifted by the count of the waves to the left); its upper part = rows of bucket x in front
+		uint32_t base[SIGMA], cval[SIGMA], seen = 0;
 		{
 			uint32_t acc = 0;
 #pragma unroll
 			for (int x = 0; x < SIGMA; ++x)
 			{
-				uint32_t const pocc16 = (x & 1) ? (pc[x >> 1] & 0xFFFF0000u) : (pc[x >> 1] << 16);
-				uint32_t const k = max(pk[x], ek[x] + pocc16);
-				base[x] = acc + (k >> 16);
-				cval[x] = k;                                       // (upper half != 0: x was seen before)
-				acc += (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+				uint32_t const k = max(pk[x], ek[x] + occ_key(pc, x));
+				uint32_t const tot = (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+				if (TILE)
+				{
+					// (tiles to the left) (+) (threads to the left in this tile); then the carry moves past this tile
+					base[x] = tc->start[x & 3] + tc->cnt[x & 3] + (k >> KS);
+					cval[x] = (k >> KS) ? (k & VMASK) : max(tc->val[x & 3], k & VMASK);
+					seen |= ((k >> KS) || ((tc->has >> x) & 1u)) ? (1u << x) : 0u;
+				}
+				else
+				{
+					base[x] = acc + (k >> KS);
+					cval[x] = k & VMASK;
+					seen |= (k >> KS) ? (1u << x) : 0u;
+					acc += tot;
+				}
+			}
+			if (TILE)
+			{
+#pragma unroll
+				for (int x = 0; x < SIGMA; ++x)
+				{
+					uint32_t const tot = (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+					tc->cnt[x & 3] += tot;
+					tc->val[x & 3] = (totk[x] >> KS) ? (totk[x] & VMASK) : max(tc->val[x & 3], totk[x] & VMASK);
+					tc->has |= (totk[x] >> KS) ? (1u << x) : 0u;
+				}
 			}
 		}
 #pragma unroll
@@ -388,7 +415,7 @@ __device__ __forceinline__ void partition_step(
 				cv = is ? cval[x] : cv;
 			}
 			if ((pend >> e) & 1u)
-				dnew[e] = (cv >> 16) ? max(cv & 0xFFFFu, dnew[e]) : first_val;
+				dnew[e] = ((seen >> (c & 15u)) & 1u) ? max(cv, dnew[e]) : first_val;
 			dst[e] = b + lidx[e];
 		}
 		return;

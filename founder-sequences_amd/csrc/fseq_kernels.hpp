@@ -777,7 +777,7 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
 			// (value ids: D0 + nb <= m + B < 65536 -- the LDS of the id histogram bounds B long before -- so the keyed scan)
-			partition_step<T, E, SIGMA, false, EW, true>(d, s, D0 + j, scr, dst, dnew);
+			partition_step<T, E, SIGMA, false, EW, 16>(d, s, D0 + j, scr, dst, dnew);
 
 #pragma unroll
 			for (int e = 0; e < E; ++e)

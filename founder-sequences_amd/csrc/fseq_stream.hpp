@@ -96,7 +96,7 @@ __device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t
 // One stable 4-bucket partition pass over an order of m rows held in global memory:
 // (a_src, d_src) -> (a_dst, d_dst).  KEYS: sort keys only (no divergences).  pre_cnt: bucket sizes if the
 // caller already knows them (column passes), else a counting sweep comes first.  Ends with a barrier.
-template <bool KEYS, typename DF, typename HOOK>
+template <bool KEYS, int KS = 0, typename DF, typename HOOK>
 __device__ __forceinline__ void stream_pass(
 	uint32_t m, uint32_t const *a_src, uint32_t const *d_src, uint32_t *a_dst, uint32_t *d_dst,
 	uint32_t first_val, DF const digit, HOOK const hook, StreamLds &L, uint32_t const *pre_cnt = nullptr, uint32_t *stage = nullptr)
@@ -163,7 +163,7 @@ __device__ __forceinline__ void stream_pass(
 		uint32_t gs[4];
 #pragma unroll
 		for (int x = 0; x < 4; ++x) gs[x] = tc.start[x] + tc.cnt[x];       // where this tile's rows of bucket x go
-		partition_step<ST, SE, 4, true>(d, s, first_val, L.scr, dst, dnew, &tc);
+		partition_step<ST, SE, 4, true, false, KS>(d, s, first_val, L.scr, dst, dnew, &tc);
 		if (stage)
 		{
 			uint32_t lofs[4];                                              // tile-local start of every bucket run
@@ -409,6 +409,9 @@ struct HistHook {
 	}
 };
 
+// KS: key shift of the partition step's keyed scan (fseq_core.hpp): 19 when every value id is below 2^19
+// (m + B < 524,288; a tile holds 7,168 < 2^13 rows), else 0 (the has-based scan)
+template <int KS>
 __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 		{
 			uint32_t cnt4[4];
 			column_digit_counts(sym, m, bsh, pass, cnt4, L.red);
-			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, bsh, pass}, HistHook{cnt}, L, cnt4, stage);
+			stream_pass<false, KS>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], D0 + j, DigitColumn{sym, bsh, pass}, HistHook{cnt}, L, cnt4, stage);
 			cur ^= 1u;
 		}
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
