@@ -402,6 +402,26 @@ __device__ __forceinline__ void partition_step(
 				}
 			}
 		}
+		if constexpr (SIGMA == 4 && KS == 16 && !TILE)
+		{
+			// bucket start (< 65536 rows) and prefix maximum (< 65536) of a symbol share a word: one 4-way select per row,
+			// as a tree over the two bits of the symbol (an unused position, s = 4, reads entry 0; nothing uses it)
+			uint32_t pv[4];
+#pragma unroll
+			for (int x = 0; x < 4; ++x) pv[x] = (base[x] << 16) | cval[x];
+#pragma unroll
+			for (int e = 0; e < E; ++e)
+			{
+				uint32_t const c = s[e];
+				bool const b0 = c & 1u, b1 = c & 2u;
+				uint32_t const lo2 = b0 ? pv[1] : pv[0], hi2 = b0 ? pv[3] : pv[2];
+				uint32_t const sel = b1 ? hi2 : lo2;
+				if ((pend >> e) & 1u)
+					dnew[e] = ((seen >> (c & 15u)) & 1u) ? max(sel & 0xFFFFu, dnew[e]) : first_val;
+				dst[e] = (sel >> 16) + lidx[e];
+			}
+			return;
+		}
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{

@@ -80,7 +80,7 @@ __host__ __device__ inline uint32_t sym_bytes(uint32_t m, uint32_t bsh) { return
 __device__ __forceinline__ uint32_t sym_digit(uint8_t const *col, uint32_t a, uint32_t bsh, uint32_t pass)
 {
 	uint32_t const byte = col[a >> bsh];
-	uint32_t const sh = (a & ((1u << bsh) - 1u)) * (8u >> bsh) + 2u * pass;
+	uint32_t const sh = ((a & ((1u << bsh) - 1u)) << (3u - bsh)) + 2u * pass;     // (8 >> bsh) bits per row
 	return (byte >> sh) & 3u;
 }
 
