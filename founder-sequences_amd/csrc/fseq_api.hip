@@ -45,6 +45,7 @@ struct KernelSet {
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
 	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0);
 	hipError_t (*prepare)(size_t lds_columns);
+	hipError_t (*prepare_columns)(size_t lds_columns);
 };
 
 template <typename K>
@@ -97,10 +98,11 @@ struct Launch {
 		hipError_t e;
 		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>())) != hipSuccess) return e;
 		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_columns<T, E, SIGMA, PK, EW>, lds_columns)) != hipSuccess) return e;
 		if ((e = allow_lds(k_chain<T, E, PK>, chain_lds_bytes<T, E, PK>())) != hipSuccess) return e;
+		(void) lds_columns;
 		return hipSuccess;
 	}
+	static hipError_t prepare_columns(size_t lds_columns) { return allow_lds(k_columns<T, E, SIGMA, PK, EW>, lds_columns); }
 	static KernelSet make()
 	{
 		KernelSet k;
@@ -109,7 +111,7 @@ struct Launch {
 		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
 		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
 		k.lds_chain = chain_lds_bytes<T, E, PK>();
-		k.chain = &chain; k.prepare = &prepare;
+		k.chain = &chain; k.prepare = &prepare; k.prepare_columns = &prepare_columns;
 		return k;
 	}
 };
@@ -153,6 +155,16 @@ hipError_t prepare_blockkeys(uint32_t T, size_t lds)
 	}
 }
 
+// phase C from another configuration than phases A, B and pass 2 (the emitter-wave kernels give their threads one
+// row more; the latency-bound chain and snapshot kernels are better off without it)
+template <typename Base, typename Col>
+KernelSet compose_kernels()
+{
+	KernelSet k = Base::make();
+	k.columns_lds = &Col::columns_lds; k.columns = &Col::columns; k.columns_resident = &Col::columns_resident; k.prepare_columns = &Col::prepare_columns;
+	return k;
+}
+
 bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 {
 	if (sigma > 256) return false;
@@ -174,6 +186,19 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 	FSEQ_TRY(64, 1, false)
 	FSEQ_TRY(64, 7, false)
 	FSEQ_TRY(256, 5, false)
+	// 512 threads: the list wave pays since the partition step's scan became cheap (BASELINE C3: phase C 8.2 -> 7.7 ms
+	// with six rows on seven waves and the list on the eighth; 576 threads would keep five rows per thread, but nine
+	// waves per workgroup place three on one SIMD and only one workgroup fits a CU)
+	if (ew_ok && m > 448u * 5u && m <= 448u * 6u && m <= 512u * 5u)
+	{
+		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 6, 4, false, true>>();
+		return true;
+	}
+	if (ew_ok && m > 256u * 5u && m <= 448u * 5u)
+	{
+		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 5, 4, false, true>>();
+		return true;
+	}
 	FSEQ_TRY(512, 5, false)
 	FSEQ_TRY(512, 7, false)
 	FSEQ_TRY_EW(1024, 7, false)
@@ -498,6 +523,7 @@ int prepare_geometry(fseq_ctx *c)
 		// phase C works on value ids < m + B in 16-bit keys (partition_step<.., KEY16>); the LDS check above implies it
 		if ((uint64_t) p.m + c->B > 65535u) return fail(c, FSEQ_E_UNSUPPORTED, "block length too large for the 16-bit value ids of phase C");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
+		HIP_TRY(c, c->ks.prepare_columns(c->lds_columns));
 		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the two maps take what is left of ~76 KiB
 		// (two workgroups per CU) when that holds the leaf map with a quarter to spare, else of the whole CU
 		{
