@@ -41,13 +41,15 @@ def phase_of(name):
     mo = re.search(r"k_colblock<[^>]*?,\s*(\d),\s*(true|false)>", name) or re.search(r"k_colblock_stream<(\d)>", name)
     if mo:
         return "phase_a" if mo.group(1) == "0" else "pass_2"
+    if "k_blockkeys" in name:
+        return "phase_a"
     if "k_chain" in name or "k_boundary_recent" in name:
         return "phase_b"
     if "k_columns" in name:
         return "phase_c"
     if "k_dp<" in name or "k_spec_" in name:
         return "phase_d"
-    if "k_gather" in name or "k_seg_" in name or "copyBuffer" in name or "fillBuffer" in name:
+    if "k_gather" in name or "k_seg_" in name or "k_tb_" in name or "copyBuffer" in name or "fillBuffer" in name:
         return "host"
     return None
 

@@ -104,9 +104,10 @@ def test_wide_and_odd_alphabets(pkg, sigma, m, n, L):
     compare_long(pkg, msa, L, block_len=48)
 
 
-@pytest.mark.parametrize("m", [2, 63, 64, 65, 448, 449, 1280, 1281, 2560, 2561, 3584, 3585, 7168, 7169])
+@pytest.mark.parametrize("m", [2, 63, 64, 65, 448, 449, 1280, 1281, 2240, 2241, 2560, 2561, 3584, 3585, 6720, 6721, 7168, 7169])
 def test_kernel_configuration_boundaries(pkg, m):
-    """Row counts on both sides of every <T,E> capacity (64, 448, 1280, 2560, 3584, 7168 | packed)."""
+    """Row counts on both sides of every <T,E> capacity (64, 448, 1280, 2560, 3584, 7168 | packed) and of the
+    configurations that keep a wave free for the per-column lists (448 x 5 = 2240, 448 x 6 > 2560, 960 x 7 = 6720)."""
     n, L = 160, 8
     msa = fso.synth_msa(fso.synth_spec(1000 + m, 7, 40, 4e-3), m, n)
     compare_long(pkg, msa, L, check_dp=True, block_len=33)
