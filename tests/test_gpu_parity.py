@@ -121,11 +121,21 @@ def test_kernel_configuration_boundaries(pkg, m):
     (200001, 48, 8, 30, 16, 5e-5, 44, 0, 0),             # 2-bit packed columns: 50,001 bytes staged per column
     (11300, 2400, 4, 3, 40, 2e-3, 45, 0, 1200),          # two blocks, many segments: pass 2 in several launches
     (12000, 3000, 10, 12, 200, 3e-4, 46, 0, 12),         # 250 blocks: three-level phase B on the streamed kernels
+    (540000, 40, 6, 40, 10, 2e-5, 47, 0, 0),             # value ids beyond 2^19: the keyed scan of the tiles does not apply
 ])
 def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     """m > 11,264: the block order streams through HBM/L2 in tiles (fseq_stream.hpp)."""
     msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
     compare_long(pkg, msa, L, block_len=B)
+
+
+def test_streamed_phase_c_with_the_plain_scan(pkg, monkeypatch):
+    """The streamed tiles scan their running maxima as keys (count << 19 | value id) when the ids allow it; the
+    has-based scan they fall back to otherwise must give the same results."""
+    monkeypatch.setenv("FSEQ_STREAM_PLAIN_SCAN", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(12000, 500, 20, 12, 120, 3e-4, 41, 0, 64), (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, block_len=B)
 
 
 def test_unsupported_shape_fails_loudly(pkg):
