@@ -139,14 +139,16 @@ __device__ __forceinline__ void stream_pass(
 	// consecutive lanes on consecutive words: the direct scatter writes every 32-byte sector in several
 	// partial pieces (measured: 2x the write traffic, 1.4x the time of phase A at m = 100,000).
 	uint32_t const sink = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) L.sink);
-	for (uint32_t base = 0; base < m; base += SCAP)
-	{
+	// One tile.  FULL: all SCAP positions hold rows (every tile but the last): no bounds in the loads, the staging and
+	// the write-out -- the seven "position < m" predicates alone were seven SGPR pairs in a kernel that spills them.
+	auto tile = [&](uint32_t base, auto full_tag) {
+		constexpr bool FULL = decltype(full_tag)::value;
 		uint32_t a[SE], d[SE], s[SE], dst[SE], dnew[SE];
 #pragma unroll
 		for (int e = 0; e < SE; ++e)
 		{
 			uint32_t const pos = base + tid * SE + e;
-			bool const in = pos < m;
+			bool const in = FULL || pos < m;
 			a[e] = in ? a_src[pos] : 0u;
 			d[e] = (in && !KEYS) ? d_src[pos] : 0u;
 			s[e] = in ? digit(a[e]) : 4u;
@@ -154,6 +156,7 @@ __device__ __forceinline__ void stream_pass(
 		// The next tile's rows on their way from HBM into L2 while this tile is partitioned (one workgroup per CU: no
 		// other wave would hide that latency): one touch per 64 bytes, the first half of the workgroup for a, the
 		// second for d.
+		if (FULL)
 		{
 			uint32_t const w = base + SCAP + (tid & (ST / 2 - 1)) * 16u;
 			bool const second = tid >= ST / 2;
@@ -166,40 +169,41 @@ __device__ __forceinline__ void stream_pass(
 		partition_step<ST, SE, 4, true, false, KS>(d, s, first_val, L.scr, dst, dnew, &tc);
 		if (stage)
 		{
-			uint32_t lofs[4];                                              // tile-local start of every bucket run
+			// tile-local start of every bucket run, and what turns a global destination into a tile-local one
+			uint32_t lofs[4], shift[4];
 			{
 				uint32_t acc = 0;
 #pragma unroll
-				for (int x = 0; x < 4; ++x) { lofs[x] = acc; acc += tc.start[x] + tc.cnt[x] - gs[x]; }
+				for (int x = 0; x < 4; ++x) { lofs[x] = acc; shift[x] = gs[x] - acc; acc += tc.start[x] + tc.cnt[x] - gs[x]; }
 			}
 #pragma unroll
 			for (int e = 0; e < SE; ++e)
 			{
-				if (base + tid * SE + e < m)
+				if (FULL || base + tid * SE + e < m)
 				{
-					uint32_t g = 0, lo = 0;
-#pragma unroll
-					for (int x = 0; x < 4; ++x) { bool const is = s[e] == (uint32_t) x; g = is ? gs[x] : g; lo = is ? lofs[x] : lo; }
-					uint32_t const lp = dst[e] - g + lo;
+					// (a 4-way select as a tree over the two bits of the symbol)
+					bool const b0 = s[e] & 1u, b1 = s[e] & 2u;
+					uint32_t const lo2 = b0 ? shift[1] : shift[0], hi2 = b0 ? shift[3] : shift[2];
+					uint32_t const lp = dst[e] - (b1 ? hi2 : lo2);
 					stage[lp] = a[e];
 					if (!KEYS) { stage[SCAP + lp] = dnew[e]; hook(d[e], dnew[e]); }
 				}
 			}
 			__syncthreads();
-			uint32_t const tile_n = min(SCAP, m - base);
+			uint32_t const tile_n = FULL ? SCAP : m - base;
 #pragma unroll
 			for (int e = 0; e < SE; ++e)
 			{
 				uint32_t const j = (uint32_t) e * ST + tid;
-				if (j < tile_n)
+				if (FULL || j < tile_n)
 				{
-					uint32_t const x = (j >= lofs[1] ? 1u : 0u) + (j >= lofs[2] ? 1u : 0u) + (j >= lofs[3] ? 1u : 0u);
-					uint32_t g = gs[0], lo = 0;
-					g = x == 1u ? gs[1] : g; lo = x == 1u ? lofs[1] : lo;
-					g = x == 2u ? gs[2] : g; lo = x == 2u ? lofs[2] : lo;
-					g = x == 3u ? gs[3] : g; lo = x == 3u ? lofs[3] : lo;
-					a_dst[g + (j - lo)] = stage[j];
-					if (!KEYS) d_dst[g + (j - lo)] = stage[SCAP + j];
+					// bucket of output slot j: the runs lie back to back
+					uint32_t sh = shift[0];
+					sh = j >= lofs[1] ? shift[1] : sh;
+					sh = j >= lofs[2] ? shift[2] : sh;
+					sh = j >= lofs[3] ? shift[3] : sh;
+					a_dst[j + sh] = stage[j];
+					if (!KEYS) d_dst[j + sh] = stage[SCAP + j];
 				}
 			}
 		}
@@ -208,7 +212,7 @@ __device__ __forceinline__ void stream_pass(
 #pragma unroll
 			for (int e = 0; e < SE; ++e)
 			{
-				if (base + tid * SE + e < m)
+				if (FULL || base + tid * SE + e < m)
 				{
 					a_dst[dst[e]] = a[e];
 					if (!KEYS) { d_dst[dst[e]] = dnew[e]; hook(d[e], dnew[e]); }
@@ -216,7 +220,10 @@ __device__ __forceinline__ void stream_pass(
 			}
 		}
 		__syncthreads();
-	}
+	};
+	uint32_t base = 0;
+	for (; base + SCAP <= m; base += SCAP) tile(base, std::true_type{});
+	if (base < m) tile(base, std::false_type{});
 }
 
 __device__ __forceinline__ void stage_column(uint8_t *sym, uint8_t const *col, uint32_t colbytes)
