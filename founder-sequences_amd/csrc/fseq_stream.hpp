@@ -71,24 +71,27 @@ __device__ __forceinline__ void block_sum4(uint32_t (&c)[4], uint32_t *red)
 		for (int x = 0; x < 4; ++x) c[x] += red[w * 4 + x];
 }
 
-// Bucket sizes of a column pass do not depend on the order: count the digit straight off the staged column.
+// Bucket sizes of a column pass do not depend on the order: count the digit straight off the staged column -- a
+// word of 16 / 8 / 4 packed symbols at a time: the two bits of the digit of every symbol as two masks, four popcounts.
 __device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t m, uint32_t bsh, uint32_t pass, uint32_t (&cnt)[4], uint32_t *red)
 {
 #pragma unroll
 	for (int x = 0; x < 4; ++x) cnt[x] = 0;
 	uint32_t const spw = 4u << bsh, bits = 8u >> bsh;          // symbols per 32-bit word, bits per symbol
 	uint32_t const nwords = (sym_bytes(m, bsh) + 3u) / 4u;
+	uint32_t const ones = bsh == 2 ? 0x55555555u : bsh == 1 ? 0x11111111u : 0x01010101u;      // bit 0 of every symbol
 	for (uint32_t wi = threadIdx.x; wi < nwords; wi += ST)
 	{
 		uint32_t const w = *reinterpret_cast<uint32_t const *>(sym + wi * 4u);
 		uint32_t const r0 = wi * spw;
-		for (uint32_t q = 0; q < spw; ++q)
-		{
-			uint32_t const g = (w >> (bits * q + 2u * pass)) & 3u;
-			bool const in = r0 + q < m;
-#pragma unroll
-			for (int x = 0; x < 4; ++x) cnt[x] += (in && g == (uint32_t) x) ? 1u : 0u;
-		}
+		// symbols of rows behind m (the last word only) do not count
+		uint32_t const nv = min(spw, m - r0);
+		uint32_t const valid = nv == spw ? ones : (ones & ((1u << (nv * bits)) - 1u));
+		uint32_t const lo = (w >> (2u * pass)) & valid, hi = (w >> (2u * pass + 1u)) & valid;
+		cnt[0] += (uint32_t) __popc(valid & ~lo & ~hi);
+		cnt[1] += (uint32_t) __popc(lo & ~hi);
+		cnt[2] += (uint32_t) __popc(hi & ~lo);
+		cnt[3] += (uint32_t) __popc(lo & hi);
 	}
 	block_sum4(cnt, red);
 }
