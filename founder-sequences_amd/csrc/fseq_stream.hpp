@@ -1,7 +1,7 @@
 // fseq_stream.hpp -- the column kernels for orders that do not fit LDS (m > 11,264 rows; BASELINE
 // config C4 has m = 100,000).  Same algorithm and the same partition_step as fseq_kernels.hpp, but
 // the order (a, d) of a block lives in a per-block HBM/L2 workspace (two buffers, ping-pong) and a
-// partition pass streams it through the workgroup tile by tile (T*E = 7168 rows) with a running
+// partition pass streams it through the workgroup tile by tile (ST * SE = 4096 rows) with a running
 // TileCarry.  A column pass = the bucket sizes counted off the staged column + one partition sweep (one
 // read and one write of a and d: SURVEY.md's 17 B/cell as real HBM traffic); a rank-digit or key pass
 // has a counting sweep over the order first.
@@ -12,7 +12,7 @@
 
 namespace fseq {
 
-constexpr int ST = 1024, SE = 7;                   // measured on m = 100,000: SE = 7 beats 4..9 (odd: conflict-free LDS staging; SE = 8 is 25 % slower)
+constexpr int ST = 1024, SE = 4;                   // measured on m = 100,000 with the keyed scan and the full-tile path: phase C 32.7 / 25.5 / 29.1 / 28.3 / 30.6 ms for SE = 3 / 4 / 5 / 6 / 7 (no spills at 4)
 constexpr uint32_t SCAP = ST * SE;
 constexpr uint32_t STREAM_MAX_COLBYTES = 147456;   // column staging: one packed column (sym_bytes(m, bsh)) in LDS
 
@@ -420,7 +420,7 @@ struct HistHook {
 };
 
 // KS: key shift of the partition step's keyed scan (fseq_core.hpp): 19 when every value id is below 2^19
-// (m + B < 524,288; a tile holds 7,168 < 2^13 rows), else 0 (the has-based scan)
+// (m + B < 524,288; a tile holds 4,096 < 2^13 rows), else 0 (the has-based scan)
 template <int KS>
 __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,

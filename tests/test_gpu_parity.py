@@ -114,8 +114,8 @@ def test_kernel_configuration_boundaries(pkg, m):
 
 
 @pytest.mark.parametrize("m,n,L,K,Brec,mu,seed,kind,B", [
-    (12000, 500, 20, 12, 120, 3e-4, 41, 0, 64),          # two tiles of 7168 rows
-    (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50),          # three tiles, sigma = 16 (two digit passes per column)
+    (12000, 500, 20, 12, 120, 3e-4, 41, 0, 64),          # three tiles of 4096 rows
+    (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50),          # five tiles, sigma = 16 (two digit passes per column)
     (70000, 200, 12, 20, 64, 1e-4, 43, 0, 40),           # more than 65535 rows: 32-bit tile carry
     (100000, 160, 10, 64, 50, 5e-5, 0x5EED0004, 0, 0),   # BASELINE config C4 rows, shortened columns
     (200001, 48, 8, 30, 16, 5e-5, 44, 0, 0),             # 2-bit packed columns: 50,001 bytes staged per column
