@@ -1119,7 +1119,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
 		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
 		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64);
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, getenv("FSEQ_BLOCKKEYS_WIDE") ? 1u : 0u);
 	}
 	else if (keyspace)
 	{
@@ -1706,7 +1706,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				c->bkws_words = per;
 			}
 			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
-			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr);
+			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, getenv("FSEQ_BLOCKKEYS_WIDE") ? 1u : 0u);
 		}
 		else
 		{

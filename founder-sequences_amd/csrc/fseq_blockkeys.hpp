@@ -519,7 +519,7 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m,
 {
 	// rows per thread and step: the 32-bit ids of the streamed regime live in HBM / L2 -- eight independent loads in
 	// flight per thread instead of one round trip per row
-	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 4u;
+	constexpr uint32_t U = 8u;
 	constexpr uint32_t NW = T / WAVE;
 	uint32_t const tid = threadIdx.x;
 	uint32_t const cap_bits = S.cap_words * 32u;
@@ -606,7 +606,7 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m,
 template <int T, typename IdT>
 __device__ __forceinline__ void bk_copy(uint32_t m, IdT const *__restrict__ src, IdT *__restrict__ dst, IdT *__restrict__ dst2 = nullptr)
 {
-	constexpr uint32_t U = sizeof(IdT) == 4 ? 8u : 4u;
+	constexpr uint32_t U = 8u;
 	for (uint32_t r0 = threadIdx.x; r0 < m; r0 += T * U)
 	{
 		IdT v[U];
@@ -626,13 +626,20 @@ __device__ __forceinline__ uint32_t bk_symbol(uint8_t const *msa, size_t ld, uin
 
 // The tree over the block [k0, kend), streamed rows: smem holds the bitmaps, ws = this workgroup's id arrays and
 // group ids (u32).  Returns the number of merges that had to be sliced (diagnostic only).
+// IdT = uint16_t: the ids of the ranges as halfwords (this tree moves ~20 bytes of id traffic per row and rank
+// operation through L2 / HBM and is bound by it; half of that with 16-bit ids) -- as long as no range has more than
+// 65,535 distinct keys: returns BK_WIDE (uniformly, nothing written) at the first one that has, and the caller runs
+// the block again with IdT = uint32_t.
+constexpr uint32_t BK_WIDE = 0xFFFFFFFFu;
+template <typename IdT>
 __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
-	uint32_t *__restrict__ ws, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
+	uint32_t *__restrict__ ws_words, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
 {
 	constexpr int T = 1024;
-	using IdT = uint32_t;
+	constexpr bool NARROW = sizeof(IdT) == 2;
 	using PrefT = uint32_t;
+	IdT *const ws = reinterpret_cast<IdT *>(ws_words);
 	uint32_t const tid = threadIdx.x;
 	uint32_t const bits = 8u >> bsh, cl = 16u / bits, smask = (1u << bits) - 1u;
 	uint32_t const nb = (uint32_t) (kend - k0);
@@ -699,6 +706,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
 			{
 				D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced);
+				if (NARROW && D[sp - 2] > 65536u) { __syncthreads(); return BK_WIDE; }
 				sz[sp - 2] += sz[sp - 1];
 				--sp;
 			}
@@ -715,11 +723,14 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 		{
 			bk_copy<T, IdT>(m, gi, grpid + (size_t) g * m);
 			Dacc = bk_merge<T, IdT, PrefT>(S, m, Dacc, D[0], S.acc, gi, S.acc, &sliced);
+			if (NARROW && Dacc > 65536u) { __syncthreads(); return BK_WIDE; }
 		}
 	}
 
 	// ---- outputs: rank of every row, one representative row per distinct key, the divergence in front of each key
-	IdT *const rep = S.stk(1);
+	// (representatives are ROW numbers, 32 bits whatever the ids: with halfword ids the upper half of the workspace is free)
+	uint32_t *const rep = NARROW ? ws_words + ((size_t) (BK_GL + 2 + ngrp) * m + 3) / 2 : reinterpret_cast<uint32_t *>(S.stk(1));
+	__syncthreads();
 	{
 		constexpr uint32_t U = 8u;
 		for (uint32_t r0 = tid; r0 < m; r0 += T * U)
@@ -729,7 +740,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			for (uint32_t u = 0; u < U; ++u) v[u] = (r0 + u * T < m) ? (uint32_t) S.acc[r0 + u * T] : 0u;
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u)
-				if (r0 + u * T < m) { rank_out[r0 + u * T] = v[u]; rep[v[u]] = (IdT) (r0 + u * T); }
+				if (r0 + u * T < m) { rank_out[r0 + u * T] = v[u]; rep[v[u]] = r0 + u * T; }
 		}
 	}
 	__syncthreads();
@@ -777,16 +788,20 @@ __global__ __launch_bounds__(T) void k_blockkeys(
 __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
-	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced)
+	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide)
 {
+	// wide != 0: 32-bit ids from the start (tests; else a block is tried with halfword ids first)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x)
 	{
 		uint64_t const k0 = col0 + (uint64_t) b * B;
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		size_t const ob = (size_t) b * m;
-		uint32_t const ns = blockkeys_tree_stream(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-		                                          rank + ob, keyd + ob, nkeys + b);
+		uint32_t ns = wide ? BK_WIDE : blockkeys_tree_stream<uint16_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
+		                                                               rank + ob, keyd + ob, nkeys + b);
+		if (ns == BK_WIDE)
+			ns = blockkeys_tree_stream<uint32_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
+			                                     rank + ob, keyd + ob, nkeys + b);
 		if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 	}
 }

@@ -129,6 +129,20 @@ def test_streamed_state_for_large_m(pkg, m, n, L, K, Brec, mu, seed, kind, B):
     compare_long(pkg, msa, L, block_len=B)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
+    """The streamed key-space tree keeps its ids as halfwords and runs a block again with 32-bit ids once a range has
+    more than 65,536 distinct keys: 70,000 random rows are all distinct after a dozen columns (the fallback), a
+    mosaic of few founders never gets there; FSEQ_BLOCKKEYS_WIDE forces 32 bits from the start."""
+    if wide:
+        monkeypatch.setenv("FSEQ_BLOCKKEYS_WIDE", "1")
+    rng = np.random.default_rng(11)
+    msa = (rng.integers(0, 4, size=(70000, 64)) + 65).astype(np.uint8)
+    compare_long(pkg, msa, 8, block_len=32)
+    msa = fso.synth_msa(fso.synth_spec(48, 20, 64, 1e-4, 0), 70000, 96)
+    compare_long(pkg, msa, 8, block_len=40)
+
+
 def test_streamed_phase_c_with_the_plain_scan(pkg, monkeypatch):
     """The streamed tiles scan their running maxima as keys (count << 19 | value id) when the ids allow it; the
     has-based scan they fall back to otherwise must give the same results."""
