@@ -81,6 +81,21 @@ def load_pmc(workload):
     return None, "no PMC summary under profiles/ for workload %s on kernel sources %s" % (workload, sha)
 
 
+def single_gpu_reference(workload):
+    """value / ms_per_step of the newest committed single-GPU bench line of `workload` (profiles/rNN_bench_<workload>.json)."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "r*_bench_%s.json" % workload)), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.loads(f.read().strip().splitlines()[-1])
+            if d.get("n_gpus") == 1:
+                return {"value": d["value"], "ms_per_step": d["ms_per_step"], "source": os.path.relpath(path, here)}
+        except Exception:
+            continue
+    return None
+
+
 def cpu_baseline(ctx, w, threads):
     """The oracle (CPU restatement, -O2) timed on this host: pass 1 on one core as the reference
     runs it, pass 2 on `threads` threads.  Sample = the whole workload when it is
@@ -330,6 +345,9 @@ def main():
             "parallelism": "1 GPU" if world == 1 else "column-block shards x%d: phase A/C/pass 2 and the DP chunks local, %d all-reduces (%.1f MB) per step over %s"
                            % (world, transport.calls // max(1, args.steps + args.warmup), transport.words_moved * 4 / max(1, args.steps + args.warmup) / 1e6,
                               "gloo via host (rehearsal: ranks share a GPU)" if rehearsal else "RCCL"),
+            # strong scaling is judged against ONE GPU on the SAME workload: the N = 1 default of this script is C3, so the
+            # committed single-GPU line of this workload is quoted here (python bench.py --workload C4 reproduces it)
+            "single_gpu_same_workload": single_gpu_reference(args.workload) if world > 1 else None,
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "dp_chunks": t["dp_chunks"], "dp_sweeps": t["dp_sweeps"],
