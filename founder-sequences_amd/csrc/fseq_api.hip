@@ -30,11 +30,12 @@ namespace {
 struct KernelSet {
 	uint32_t T, E, sigma, cap;
 	size_t lds_colblock, lds_snap;
+	uint32_t scan_shift;                     // partition steps of this configuration may scan keys while every divergence is < 2^scan_shift
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t *, uint32_t *, uint32_t *, uint64_t col0);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
-	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d);
+	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d, uint32_t keyed);
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
@@ -43,7 +44,7 @@ struct KernelSet {
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0);
+	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0, uint32_t keyed);
 	hipError_t (*prepare)(size_t lds_columns);
 	hipError_t (*prepare_columns)(size_t lds_columns);
 };
@@ -63,14 +64,15 @@ struct Launch {
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh, rank_, keyd, nkeys,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0,
+		                   (uint64_t) B < (1ull << scan_shift_for(T, E)) ? 1u : 0u);      // (divergences relative to the block start: <= B)
 	}
 	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
-	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d)
+	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d, uint32_t keyed)
 	{
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0);
+		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0, keyed);
 	}
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
@@ -88,10 +90,10 @@ struct Launch {
 	}
 	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
 	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0)
+	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0, uint32_t keyed)
 	{
 		hipLaunchKernelGGL((k_chain<T, E, PK>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
-		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
+		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0, keyed);
 	}
 	static hipError_t prepare(size_t lds_columns)
 	{
@@ -106,7 +108,7 @@ struct Launch {
 	static KernelSet make()
 	{
 		KernelSet k;
-		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E;
+		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E; k.scan_shift = (uint32_t) scan_shift_for(T, E);
 		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
 		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
 		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
@@ -799,6 +801,13 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 
 // ---- launches: LDS-resident kernels, or their HBM-streamed counterparts for large m
 // grid workgroups = the blocks starting at column col0, col0 + B, ...; rank / keyd / nkeys point at the first of them
+// phase B and pass 2 work on absolute divergences (column numbers <= n): their partition steps scan keys while n fits
+// the configuration's key shift (FSEQ_PLAIN_SCAN: never)
+uint32_t scan_keyed(fseq_ctx const *c)
+{
+	return (!c->use_stream && c->p.n < (1ull << c->ks.scan_shift) && !getenv("FSEQ_PLAIN_SCAN")) ? 1u : 0u;
+}
+
 void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0)
 {
 	fseq_params const &p = c->p;
@@ -823,7 +832,7 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	else
 		c->ks.chain(c->stream, grid, c->ks.lds_chain, rank, keyd, nkeys, c->p.m, nb_total, G, cols_per_block, start_a, start_d, out_a, out_d,
-		            out_rank, out_keyd, out_nkeys, grp0);
+		            out_rank, out_keyd, out_nkeys, grp0, scan_keyed(c));
 }
 
 // ---- sharded runs: the one exchange primitive (include/fseq.h, fseq_set_shard) -------------------------------
@@ -1632,7 +1641,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 		else
 			ks.snap(st, (uint32_t) grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, c->d_cols, c->d_grp,
-			        c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d);
+			        c->d_snap_a, c->d_snap_d, c->d_src, c->snap_stride, c->d_ss_a, c->d_ss_d, scan_keyed(c));
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));

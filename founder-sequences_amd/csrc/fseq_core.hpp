@@ -190,6 +190,14 @@ struct Summary {
 	__device__ __forceinline__ uint32_t count(int x) const { return (cnt[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu; }
 };
 
+// largest key shift a step of T * E rows allows: its bucket counts must fit the 32 - KS bits above the value
+constexpr int scan_shift_for(int T, int E)
+{
+	int bits = 0;
+	while ((1ll << bits) <= (long long) T * E) ++bits;
+	return 32 - bits > 25 ? 25 : 32 - bits;
+}
+
 template <int T, int SIGMA>
 struct StepScratch {
 	static constexpr int NW = T / WAVE;
@@ -213,7 +221,7 @@ struct TileCarry {
 // before it (and is advanced past this tile), bucket starts come from tc->start.
 // IDLE0: wave 0 owns no rows (phase C keeps it free for the per-column list, fseq_kernels.hpp): it contributes the
 // identity summary and skips the arithmetic, but meets the step's barrier.
-// KS (key shift, 16 .. 19; 0 = off): every d and first_val is below 2^KS (value ids of phase C, block-relative
+// KS (key shift, 16 .. 25; 0 = off): every d and first_val is below 2^KS (value ids of phase C, block-relative
 // divergences) and one step holds fewer than 2^(32 - KS) rows.
 // The scan of the running maxima -- combine(L, R).val[x] = R.has[x] ? R.val[x] : max(L.val[x], R.val[x]), four
 // instructions per symbol and step -- then becomes a plain max-scan of keys (occurrences of x so far) << KS | val[x]:
@@ -283,7 +291,7 @@ __device__ __forceinline__ void partition_step(
 	if constexpr (KS != 0)
 	{
 		constexpr uint32_t VMASK = (1u << KS) - 1u;
-		static_assert(KS >= 16 && KS <= 19, "key = count << KS | value: counts of one step below 2^(32 - KS)");
+		static_assert(KS >= 16 && KS <= 25, "key = count << KS | value: counts of one step below 2^(32 - KS)");
 		static_assert((uint64_t) T * E < (1ull << (32 - KS)), "counts of one step must fit the key");
 		// ---- bucket counts: inclusive over the lanes (two 16-bit counts per word: at most T * E <= 65535 rows)
 		uint32_t ic[NC];

@@ -256,8 +256,10 @@ __device__ __forceinline__ void colblock_body(char *smem,
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
 	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
 	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
-	uint64_t col0)
+	uint64_t col0, uint32_t keyed)
 {
+	// keyed != 0: every divergence this launch can see is below 2^scan_shift_for(T, E) (the host knows: n, or B for a
+	// rank block) -- the partition step scans keys (fseq_core.hpp)
 	// MODE_RANK: workgroup i owns the block of columns starting at col0 + i * B (col0: first column of this
 	// launch -- a rank of a sharded run owns a contiguous block range); rank / keyd / nkeys are indexed by i
 	constexpr uint32_t CAP = T * E;
@@ -350,7 +352,8 @@ __device__ __forceinline__ void colblock_body(char *smem,
 #pragma unroll
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
-			partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
+			if (keyed) partition_step<T, E, SIGMA, false, false, scan_shift_for(T, E)>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
+			else partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 
 #pragma unroll
 			for (int e = 0; e < E; ++e)
@@ -398,11 +401,11 @@ __global__ __launch_bounds__(T) void k_colblock(
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
 	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
 	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
-	uint64_t col0)
+	uint64_t col0, uint32_t keyed)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	colblock_body<T, E, SIGMA, MODE, PK>(smem, msa, ld, m, n, B, nblocks, npass, bsh, rank, keyd, nkeys, bstate_a, bstate_d, task_rb, task_grp,
-	                                     snap_a, snap_d, task_src, snap_stride, ss_a, ss_d, col0);
+	                                     snap_a, snap_d, task_src, snap_stride, ss_a, ss_d, col0, keyed);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,8 +443,9 @@ __global__ __launch_bounds__(T) void k_chain(
 	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block,
 	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
 	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
-	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0)
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0, uint32_t keyed)
 {
+	// keyed != 0: all divergences are below 2^scan_shift_for(T, E) (n is): the partition steps scan keys
 	// workgroup i of the launch is chain grp = grp0 + i (a rank of a sharded run owns a contiguous range of chains)
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -515,7 +519,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 			for (int e = 0; e < E; ++e)
 				s[e] = (p0 + e < m) ? (((uint32_t) rk[a[e]] >> (2u * p)) & 3u) : 4u;
-			partition_step<T, E, 4>(d, s, 0u, scr, dst, dnew);
+			if (keyed) partition_step<T, E, 4, false, false, scan_shift_for(T, E)>(d, s, 0u, scr, dst, dnew);
+			else partition_step<T, E, 4>(d, s, 0u, scr, dst, dnew);
 #pragma unroll
 			for (int e = 0; e < E; ++e)
 				if (p0 + e < m) { a_l[dst[e]] = (AT) a[e]; d_l[dst[e]] = dnew[e]; }

@@ -143,6 +143,17 @@ def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
     compare_long(pkg, msa, 8, block_len=40)
 
 
+def test_phase_b_and_pass_2_with_the_plain_scan(pkg, monkeypatch):
+    """Phase B and pass 2 scan keys (count << shift | divergence) while n fits the shift of their configuration -- every
+    test shape does; FSEQ_PLAIN_SCAN keeps the has-based scan, which long inputs (BASELINE C5: n = 10^6 on the
+    1024 x 11 kernels) use, covered on the small shapes too."""
+    monkeypatch.setenv("FSEQ_PLAIN_SCAN", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in SPEC_SHAPES[:2] + [(2500, 3000, 30, 16, 500, 1e-3, 91, 0, 100), (9000, 1200, 40, 16, 400, 2e-4, 27, 0, 128),
+                                                                     (5000, 700, 20, 9, 100, 1e-3, 92, 1, 64)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, block_len=B)
+
+
 def test_streamed_phase_c_with_the_plain_scan(pkg, monkeypatch):
     """The streamed tiles scan their running maxima as keys (count << 19 | value id) when the ids allow it; the
     has-based scan they fall back to otherwise must give the same results."""
