@@ -19,8 +19,9 @@
 // Exact whatever the data; a merge whose bitmap would not fit the LDS budget (very diverse blocks: D_prefix x
 // D_group > cap) is done in slices of whole hi values.
 // Two forms: the id arrays in LDS as 16-bit words (m <= 11,264, the LDS-resident kernel configurations; bk_rank8 /
-// blockkeys_tree_lds), or in a per-workgroup HBM / L2 workspace as 32-bit words (the streamed regime: BASELINE
-// C4's m = 100,000; bk_merge / blockkeys_tree_stream).
+// blockkeys_tree_lds), or in a per-workgroup HBM / L2 workspace (the streamed regime: BASELINE C4's m = 100,000;
+// bk_merge / blockkeys_tree_stream) -- as halfwords too while no range has more than 65,536 distinct keys, else as
+// 32-bit words (the tree is bound by that id traffic).
 //
 // LDS-resident form, shaped by what the stamps of the first version showed (245 rank operations of ~5,900 cycles and
 // 123 word builds of ~5,500 per C3 block: LDS instruction issue and barriers, not arithmetic):
