@@ -205,7 +205,14 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 	FSEQ_TRY(512, 7, false)
 	FSEQ_TRY_EW(1024, 7, false)
 	FSEQ_TRY(1024, 7, false)
-	FSEQ_TRY_EW(1024, 11, true)   // 16-bit LDS state: m <= 10,560 with the list wave (BASELINE config C5), 11,264 without
+	// 16-bit LDS state (m <= 11,264).  These kernels want more registers than a wave of a 1024-thread workgroup gets
+	// (~13 per row of E): the fewest rows per thread that hold m, the list wave where the same E allows it
+	// (BASELINE C5, m = 10,000: (1024,10) 56.9 ms of phase C against 61.9 with (1024,11) and the list wave)
+	FSEQ_TRY_EW(1024, 9, true)
+	FSEQ_TRY(1024, 9, true)
+	FSEQ_TRY_EW(1024, 10, true)
+	FSEQ_TRY(1024, 10, true)
+	FSEQ_TRY_EW(1024, 11, true)
 	FSEQ_TRY(1024, 11, true)
 #undef FSEQ_TRY
 #undef FSEQ_TRY_EW
