@@ -203,6 +203,8 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
 	}
 	FSEQ_TRY(512, 5, false)
 	FSEQ_TRY(512, 7, false)
+	FSEQ_TRY_EW(1024, 5, false)    // (3,585 .. 5,120 rows: e.g. the 5,008 haplotypes of 2,504 diploid samples)
+	FSEQ_TRY(1024, 5, false)
 	FSEQ_TRY_EW(1024, 7, false)
 	FSEQ_TRY(1024, 7, false)
 	// 16-bit LDS state (m <= 11,264).  These kernels want more registers than a wave of a 1024-thread workgroup gets

@@ -104,11 +104,11 @@ def test_wide_and_odd_alphabets(pkg, sigma, m, n, L):
     compare_long(pkg, msa, L, block_len=48)
 
 
-@pytest.mark.parametrize("m", [2, 63, 64, 65, 448, 449, 1280, 1281, 2240, 2241, 2560, 2561, 3584, 3585, 6720, 6721, 7168, 7169,
+@pytest.mark.parametrize("m", [2, 63, 64, 65, 448, 449, 1280, 1281, 2240, 2241, 2560, 2561, 3584, 3585, 4800, 4801, 5120, 5121, 6720, 6721, 7168, 7169,
                                8640, 8641, 9216, 9217, 9600, 9601, 10240, 10241, 10560, 10561, 11264, 11265])
 def test_kernel_configuration_boundaries(pkg, m):
     """Row counts on both sides of every <T,E> capacity (64, 448, 1280, 2560, 3584, 7168 | packed) and of the
-    configurations that keep a wave free for the per-column lists (448 x 5 = 2240, 448 x 6 > 2560, 960 x 7 = 6720);
+    configurations that keep a wave free for the per-column lists (448 x 5 = 2240, 448 x 6 > 2560, 960 x 5 = 4800, 960 x 7 = 6720);
     16-bit LDS state: 1024 (960 with the list wave) x 9, 10, 11 rows, then the streamed kernels."""
     n, L = 160, 8
     msa = fso.synth_msa(fso.synth_spec(1000 + m, 7, 40, 4e-3), m, n)
