@@ -587,6 +587,32 @@ def test_random_shapes_match_oracle(pkg, chunk):
         compare_long(pkg, msa, L, check_dp=True, **kw)
 
 
+def test_random_shapes_with_many_rows(pkg):
+    """The same differential test on the row counts of the larger configurations (list wave on 512 / 1024 threads,
+    16-bit state with 9 / 10 / 11 rows per thread, streamed tiles, halfword and 32-bit ids of the streamed phase A)."""
+    import os
+    rng = np.random.default_rng(2024)
+    for _ in range(3 * int(os.environ.get("FSEQ_RANDOM_CASES", "10"))):
+        L = int(rng.integers(2, 60))
+        n = int(rng.integers(2 * L, 2 * L + 500))
+        m = int(rng.choice([1300, 2240, 2241, 2504, 2560, 3000, 4000, 4800, 4801, 5008, 6721, 8000, 8640, 9300, 9601, 10000, 10300,
+                            10800, 11264, 11265, 20000, 66000]))
+        sigma = int(rng.choice([2, 4, 4, 5, 16, 20]))
+        k = int(rng.integers(2, 40))
+        brec = int(rng.integers(5, 300))
+        founders = rng.integers(0, sigma, size=(k, n))
+        pick = rng.integers(0, k, size=(m, (n + brec - 1) // brec))
+        msa = np.empty((m, n), dtype=np.uint8)
+        for b in range(pick.shape[1]):
+            msa[:, b * brec:(b + 1) * brec] = founders[pick[:, b], b * brec:(b + 1) * brec]
+        noise = rng.random((m, n)) < float(rng.choice([0.0, 1e-4, 1e-3]))
+        msa[noise] = rng.integers(0, sigma, size=int(noise.sum()))
+        kw = {"block_len": int(rng.choice([0, 0, 16, 33, 100, 5000]))}
+        if rng.random() < 0.2:
+            kw["list_cap"] = int(rng.choice([2, 17]))
+        compare_long(pkg, np.ascontiguousarray(msa + 33), L, check_dp=True, **kw)
+
+
 def test_native_batch_runner(pkg):
     """fseq_run_segmentation_batch: several contexts in flight from native threads; per-context results and
     return codes (one of the inputs cannot be reduced)."""
