@@ -305,7 +305,7 @@ def main():
     pmc, pmc_src = load_pmc(args.workload)
     launches_c = 1 + t["retries"]
     kernels = {
-        "phase_a k_colblock<RANK> (block-key ranks from the identity)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
+        "phase_a k_blockkeys (block keys ranked in key space)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
         "phase_b k_chain (boundary states)": {"ms": ph["ms_phase_b"], "algorithmic_bytes": 0},
         "phase_c k_columns (per-column update + lists)": {"ms": ph["ms_phase_c"], "algorithmic_bytes": BYTES_PER_CELL * m * n * launches_c},
         "phase_d k_dp<SPEC> sweeps + rebuild kernels": {"ms": ph["ms_dp"], "algorithmic_bytes": 0},
