@@ -294,7 +294,11 @@ struct fseq_ctx {
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
 	uint32_t *d_srank = nullptr, *d_skeyd = nullptr, *d_snkeys = nullptr, *d_sstate_a = nullptr, *d_sstate_d = nullptr;
 	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
-	uint32_t chain_G = 0, n_super = 0;       // super-blocks of chain_G blocks
+	// not sharded: phase B over any number of levels (levels[i - 1] = the composites of chain_fan level-(i - 1) key blocks)
+	struct ChainLevel { uint32_t count = 0; uint64_t cols = 0; uint32_t *rank = nullptr, *keyd = nullptr, *nkeys = nullptr, *state_a = nullptr, *state_d = nullptr; };
+	std::vector<ChainLevel> levels;
+	uint32_t chain_fan = 0;
+	uint32_t chain_G = 0, n_super = 0;       // sharded: super-blocks of chain_G blocks
 	uint32_t chain_G2 = 0, n_hyper = 0;      // third level: hyper-blocks of chain_G2 super-blocks (0 = two levels only)
 	uint2 *d_ent = nullptr;
 	uint4 *d_hdr = nullptr;
@@ -419,7 +423,11 @@ void block_geometry(fseq_ctx *c)
 	{
 		// LDS-resident kernels: ~1024 blocks (2-4 workgroups per CU).  Streamed kernels stage a whole column
 		// in LDS (one workgroup per CU) and pay the phase-B chain per block and per row: ~256 blocks.
-		uint64_t const target = streamed ? 256u : 1024u;
+		// (32-bit LDS state and long inputs: ~4096 blocks -- measured on BASELINE C3: phase C 7.7 -> 7.3 ms with the finer
+		// grain, phase B 0.50 -> 0.74 ms with its two more levels; blocks of fewer than ~200 columns lose more to the
+		// per-block prologues and to phase B than they gain)
+		uint64_t target = streamed ? 256u : 1024u;
+		if (!streamed && p.m <= 7168u && p.n >= 4096u * 200u) target = 4096u;
 		uint64_t b = (p.n + target - 1) / target;
 		if (b < 16) b = 16;
 		if (b > 4096) b = 4096;
@@ -471,23 +479,24 @@ void block_geometry(fseq_ctx *c)
 		return;
 	}
 	{
-		// two levels: super-blocks of G ~ sqrt(nblocks) blocks, serial depth of phase B = G + nblocks/G + G key
-		// blocks; from 216 blocks on three levels (G ~ cbrt(nblocks): 5 launches of ~G serial steps)
-		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) c->nblocks));
+		// Phase B is serial over key blocks, so it is applied recursively: compose groups of G blocks from the identity
+		// (parallel), groups of G of those, ... until at most G are left, chain them, expand level by level.  Serial depth
+		// = G steps per launch, 2 levels - 1 launches (+ about half a step of launch gap each): G = 4 for 100..10^4
+		// blocks (1024 blocks: 9 launches of <= 4 steps instead of the 5 x 11 of a three-level chain).
+		uint32_t best_g = c->nblocks, best_cost = ~0u;
+		for (uint32_t g = 2; g <= 64 && g < std::max(3u, c->nblocks); ++g)
+		{
+			uint32_t lv = 1;
+			for (uint64_t cap = g; cap < c->nblocks; cap *= g) ++lv;
+			uint32_t const cost = (2u * lv - 1u) * (2u * g + 1u);
+			if (cost < best_cost) { best_cost = cost; best_g = g; }
+		}
+		if (c->nblocks <= 8) best_g = std::max(1u, c->nblocks);        // one chain
+		if (getenv("FSEQ_TWO_LEVEL_CHAIN")) best_g = std::max(2u, (uint32_t) std::ceil(std::sqrt((double) c->nblocks)));
+		if (char const *e = getenv("FSEQ_CHAIN_FAN")) best_g = (uint32_t) std::max(2, atoi(e));
+		c->chain_fan = best_g;
+		c->chain_G = best_g; c->n_super = (c->nblocks + best_g - 1) / best_g;      // (diagnostics)
 		c->chain_G2 = 0; c->n_hyper = 0;
-		if (c->nblocks >= 216 && !getenv("FSEQ_TWO_LEVEL_CHAIN"))
-		{
-			g = (uint32_t) std::ceil(std::cbrt((double) c->nblocks));
-			while ((uint64_t) g * g * g < c->nblocks) ++g;
-		}
-		if (g < 1) g = 1;
-		c->chain_G = g;
-		c->n_super = (c->nblocks + g - 1) / g;
-		if (c->nblocks >= 216 && !getenv("FSEQ_TWO_LEVEL_CHAIN"))
-		{
-			c->chain_G2 = g;
-			c->n_hyper = (c->n_super + g - 1) / g;
-		}
 	}
 }
 
@@ -571,12 +580,35 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if ((rc = dev_alloc(c, &c->d_nkeys, c->nblocks))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bstate_a, ((size_t) c->nblocks + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_bstate_d, ((size_t) c->nblocks + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_srank, (size_t) c->n_super * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_skeyd, (size_t) c->n_super * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_snkeys, c->n_super))) return rc;
-		if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
-		if (c->n_hyper)
+		if (!c->sh.on)
+		{
+			// the composites of phase B, level by level, until at most chain_fan are left
+			uint32_t cnt = c->nblocks;
+			uint64_t cols = c->B;
+			while (cnt > c->chain_fan)
+			{
+				fseq_ctx::ChainLevel lv;
+				lv.count = (cnt + c->chain_fan - 1) / c->chain_fan;
+				lv.cols = cols * c->chain_fan;
+				if ((rc = dev_alloc(c, &lv.rank, (size_t) lv.count * m))) return rc;
+				c->levels.push_back(lv);                               // (pushed at once: free_work releases what is there)
+				fseq_ctx::ChainLevel &L = c->levels.back();
+				if ((rc = dev_alloc(c, &L.keyd, (size_t) L.count * m))) return rc;
+				if ((rc = dev_alloc(c, &L.nkeys, L.count))) return rc;
+				if ((rc = dev_alloc(c, &L.state_a, ((size_t) L.count + 1) * m))) return rc;
+				if ((rc = dev_alloc(c, &L.state_d, ((size_t) L.count + 1) * m))) return rc;
+				cnt = L.count; cols = L.cols;
+			}
+		}
+		else
+		{
+			if ((rc = dev_alloc(c, &c->d_srank, (size_t) c->n_super * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_skeyd, (size_t) c->n_super * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_snkeys, c->n_super))) return rc;
+			if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
+			if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
+		}
+		if (c->sh.on && c->n_hyper)
 		{
 			if ((rc = dev_alloc(c, &c->d_hrank, (size_t) c->n_hyper * m))) return rc;
 			if ((rc = dev_alloc(c, &c->d_hkeyd, (size_t) c->n_hyper * m))) return rc;
@@ -655,6 +687,8 @@ void free_work(fseq_ctx *c)
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
 	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
+	for (auto &lv : c->levels) { dev_free(&lv.rank); dev_free(&lv.keyd); dev_free(&lv.nkeys); dev_free(&lv.state_a); dev_free(&lv.state_d); }
+	c->levels.clear();
 	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
 	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
 	dev_free(&c->d_bk); c->bk_blocks = 0; dev_free(&c->d_bkws); c->bkws_words = 0;
@@ -1157,32 +1191,26 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	if (!sharded)
 	{
-		// phase B: compose groups of G blocks into super-blocks (parallel), -- three levels:
-		// compose groups of G2 super-blocks into hyper-blocks (parallel) -- chain the top level (one
-		// workgroup), expand every group back to the boundaries of the level below (parallel)
-		uint32_t const G = c->chain_G, NSB = c->n_super, G2 = c->chain_G2, NH = c->n_hyper;
-		if (NSB <= 1)
-			launch_chain(c, 1, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, c->nblocks, c->B, nullptr, nullptr,
-			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
-		else
-		{
-			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, nullptr, nullptr,
-			             nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys);
-			if (NH > 1)
-			{
-				launch_chain(c, NH, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, nullptr, nullptr,
-				             nullptr, nullptr, c->d_hrank, c->d_hkeyd, c->d_hnkeys);
-				launch_chain(c, 1, c->d_hrank, c->d_hkeyd, c->d_hnkeys, NH, NH, (uint64_t) G2 * G * c->B, nullptr, nullptr,
-				             c->d_hstate_a, c->d_hstate_d, nullptr, nullptr, nullptr);
-				launch_chain(c, NH, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, c->d_hstate_a, c->d_hstate_d,
-				             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
-			}
-			else
-				launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, NSB, (uint64_t) G * c->B, nullptr, nullptr,
-				             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr);
-			launch_chain(c, NSB, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
-			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr);
-		}
+		// phase B: up the levels -- compose groups of G key blocks of a level into one key block of the next
+		// (parallel, from the identity) --, chain the few key blocks of the top level (one workgroup), down the levels --
+		// expand every group from the boundary state the level above gave it (parallel)
+		uint32_t const G = c->chain_fan;
+		size_t const top = c->levels.size();
+		auto rank_of = [&](size_t i) { return i ? c->levels[i - 1].rank : c->d_rank; };
+		auto keyd_of = [&](size_t i) { return i ? c->levels[i - 1].keyd : c->d_keyd; };
+		auto nkeys_of = [&](size_t i) { return i ? c->levels[i - 1].nkeys : c->d_nkeys; };
+		auto sa_of = [&](size_t i) { return i ? c->levels[i - 1].state_a : c->d_bstate_a; };
+		auto sd_of = [&](size_t i) { return i ? c->levels[i - 1].state_d : c->d_bstate_d; };
+		auto count_of = [&](size_t i) { return i ? c->levels[i - 1].count : c->nblocks; };
+		auto cols_of = [&](size_t i) { return i ? c->levels[i - 1].cols : (uint64_t) c->B; };
+		for (size_t i = 1; i <= top; ++i)
+			launch_chain(c, count_of(i), rank_of(i - 1), keyd_of(i - 1), nkeys_of(i - 1), count_of(i - 1), G, cols_of(i - 1), nullptr, nullptr,
+			             nullptr, nullptr, rank_of(i), keyd_of(i), nkeys_of(i));
+		launch_chain(c, 1, rank_of(top), keyd_of(top), nkeys_of(top), count_of(top), count_of(top), cols_of(top), nullptr, nullptr,
+		             sa_of(top), sd_of(top), nullptr, nullptr, nullptr);
+		for (size_t i = top; i-- > 0;)
+			launch_chain(c, count_of(i + 1), rank_of(i), keyd_of(i), nkeys_of(i), count_of(i), G, cols_of(i), sa_of(i + 1), sd_of(i + 1),
+			             sa_of(i), sd_of(i), nullptr, nullptr, nullptr);
 	}
 	else
 	{
