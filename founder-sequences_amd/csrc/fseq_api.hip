@@ -285,6 +285,7 @@ struct fseq_ctx {
 	KernelSet ks{};
 	bool kernels_ready = false;
 	bool use_stream = false;             // m too large for an LDS-resident order: HBM-streamed kernels (fseq_stream.hpp)
+	size_t tb_guess = 0;                 // traceback entries of the last run (sizes the speculative copy of the next)
 	uint32_t *d_ws = nullptr;            // their per-block workspaces
 	size_t ws_words = 0;
 	size_t lds_columns = 0;
@@ -825,14 +826,23 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 	hipLaunchKernelGGL(k_tb_windows, dim3(nwin), dim3(256), 0, st, c->dp.LB, dp_size, L, d_exit_next, d_exit_cnt);
 	hipLaunchKernelGGL(k_tb_chain, dim3(1), dim3(64), 0, st, d_exit_next, d_exit_cnt, dp_size, d_head, nwin, d_count);
 	hipLaunchKernelGGL(k_tb_emit, dim3(nwin), dim3(256), 0, st, c->dp.LB, c->dp.M, c->dp.SZ, dp_size, L, d_head, d_count, c->d_tb, (uint32_t) cap);
+	// the count and -- in the same round trip -- as many entries as the last run of this context had (a second copy
+	// only when there are more this time)
 	uint32_t cnt[4] = {0, 0, 0, 0};
+	size_t const guess = std::min(cap, c->tb_guess ? c->tb_guess + 16 : (size_t) 4096);
+	std::vector<uint4> h(guess);
 	HIP_TRY(c, hipMemcpyAsync(cnt, d_count, 16, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_tb, guess * sizeof(uint4), hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	HIP_TRY(c, hipGetLastError());
 	if (cnt[1] != 1u || cnt[0] == 0 || cnt[0] > cap) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend to lb == 0");
 	size_t const S = cnt[0];
-	std::vector<uint4> h(S);
-	HIP_TRY(c, hipMemcpy(h.data(), c->d_tb, S * sizeof(uint4), hipMemcpyDeviceToHost));
+	if (S > guess)
+	{
+		h.resize(S);
+		HIP_TRY(c, hipMemcpy(h.data() + guess, c->d_tb + guess, (S - guess) * sizeof(uint4), hipMemcpyDeviceToHost));
+	}
+	c->tb_guess = S;
 	c->traceback.resize(S);
 	for (size_t j = 0; j < S; ++j)
 	{
@@ -1038,6 +1048,7 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	SpecCtl h{};
 	sweep(true);
 	uint32_t done_sweeps = 1;
+	std::vector<uint32_t> ovf_early;
 	if (!sharded)
 	{
 		// every kernel returns at once when the iteration has converged, so sweeps are queued ahead of the
@@ -1055,6 +1066,9 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 			}
 			compare(done_sweeps == 1);
 			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+			// (the chunks' "list too short" words in the same round trip: final if the iteration has converged)
+			ovf_early.resize(nch);
+			HIP_TRY(c, hipMemcpyAsync(ovf_early.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(c, hipStreamSynchronize(st));
 			HIP_TRY(c, hipGetLastError());
 			if (h.done || done_sweeps >= max_sweeps) break;
@@ -1108,8 +1122,12 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	{
 		// the chunks' "list too short" words are written by their owners only
 		std::vector<uint32_t> ovf(nch);
-		HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(c, hipStreamSynchronize(st));
+		if (ovf_early.size() == nch) ovf = ovf_early;           // (read together with the control word that said "done")
+		else
+		{
+			HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipStreamSynchronize(st));
+		}
 		uint32_t o = 0;
 		for (uint32_t k = P.mine_lo; k < P.mine_hi; ++k) o |= ovf[k] ? 1u : 0u;
 		*overflow = o;
