@@ -286,6 +286,7 @@ struct fseq_ctx {
 	bool kernels_ready = false;
 	bool use_stream = false;             // m too large for an LDS-resident order: HBM-streamed kernels (fseq_stream.hpp)
 	size_t tb_guess = 0;                 // traceback entries of the last run (sizes the speculative copy of the next)
+	std::vector<uint2> tau_host;         // merge thresholds that came back with the traceback (not sharded)
 	uint32_t *d_ws = nullptr;            // their per-block workspaces
 	size_t ws_words = 0;
 	size_t lds_columns = 0;
@@ -831,6 +832,16 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 	uint32_t cnt[4] = {0, 0, 0, 0};
 	size_t const guess = std::min(cap, c->tb_guess ? c->tb_guess + 16 : (size_t) 4096);
 	std::vector<uint4> h(guess);
+	// not sharded: the merge thresholds of the traceback boundaries (k_seg_tau_tb) ride along -- one workgroup per
+	// POSSIBLE entry, those behind the count return at once
+	c->tau_host.clear();
+	if (!c->sh.on)
+	{
+		if (c->tau_cap < cap) { if ((rc = dev_alloc(c, &c->d_tau, cap))) return rc; c->tau_cap = cap; }
+		hipLaunchKernelGGL(k_seg_tau_tb, dim3((uint32_t) cap), dim3(64), 0, st, reinterpret_cast<uint4 const *>(c->d_tb), d_count, L, c->stride, c->d_ent, c->d_hdr, c->d_tau);
+		c->tau_host.resize(guess);
+		HIP_TRY(c, hipMemcpyAsync(c->tau_host.data(), c->d_tau, guess * sizeof(uint2), hipMemcpyDeviceToHost, st));
+	}
 	HIP_TRY(c, hipMemcpyAsync(cnt, d_count, 16, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_tb, guess * sizeof(uint4), hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
@@ -841,7 +852,13 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 	{
 		h.resize(S);
 		HIP_TRY(c, hipMemcpy(h.data() + guess, c->d_tb + guess, (S - guess) * sizeof(uint4), hipMemcpyDeviceToHost));
+		if (!c->tau_host.empty())
+		{
+			c->tau_host.resize(S);
+			HIP_TRY(c, hipMemcpy(c->tau_host.data() + guess, c->d_tau + guess, (S - guess) * sizeof(uint2), hipMemcpyDeviceToHost));
+		}
 	}
+	if (!c->tau_host.empty()) c->tau_host.resize(S);
 	c->tb_guess = S;
 	c->traceback.resize(S);
 	for (size_t j = 0; j < S; ++j)
@@ -978,14 +995,11 @@ SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 	return P;
 }
 
-// Phase D as chunk-speculative sweeps on the whole chip (fseq_dpspec.hpp).  Leaves M / LB / SZ exactly as
-// k_dp<DP_WHOLE> would (on every rank of a sharded run); *overflow = some cell's list was too short.
-int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t st, uint32_t *overflow, uint32_t *sweeps_out)
+// The arrays a run of the speculative DP starts from (nothing here depends on phases A-C: run_long_path queues it on
+// the second stream while phase C runs)
+int dp_spec_reset(fseq_ctx *c, SpecPlan const &P, hipStream_t s)
 {
-	fseq_params const &p = c->p;
-	uint32_t const m = p.m, n = (uint32_t) p.n, L = (uint32_t) p.segment_length;
 	uint32_t const nch = P.nchunks();
-	bool const sharded = c->sh.on;
 	int rc;
 	if (c->spec_cap < nch)
 	{
@@ -997,7 +1011,31 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		if ((rc = dev_alloc(c, &c->d_chunk_r0, nch + 1u))) return rc;
 		c->chunk_cap = nch + 1u;
 	}
-	HIP_TRY(c, hipMemcpyAsync(c->d_chunk_r0, P.r0.data(), (size_t) (nch + 1u) * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->d_chunk_r0, P.r0.data(), (size_t) (nch + 1u) * 4, hipMemcpyHostToDevice, s));
+	HIP_TRY(c, hipMemsetAsync(c->dp.M, 0, c->dp_size * 4, s));
+	HIP_TRY(c, hipMemsetAsync(c->d_Mprev, 0, c->dp_size * 4, s));
+	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 6 * nch + 16) * 4, s));
+	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0x01, (size_t) nch * 4, s));         // d_active != 0: every chunk runs in sweep 1
+	if (c->sh.on)
+	{
+		// LB / SZ are gathered over the ranks at the end: what nobody writes must be 0 everywhere
+		HIP_TRY(c, hipMemsetAsync(c->dp.LB, 0, c->dp_size * 4, s));
+		HIP_TRY(c, hipMemsetAsync(c->dp.SZ, 0, c->dp_size * 4, s));
+	}
+	return FSEQ_OK;
+}
+
+// Phase D as chunk-speculative sweeps on the whole chip (fseq_dpspec.hpp).  Leaves M / LB / SZ exactly as
+// k_dp<DP_WHOLE> would (on every rank of a sharded run); *overflow = some cell's list was too short.
+// reset_done: dp_spec_reset has been queued (on any stream `st` already waits for).
+int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t st, uint32_t *overflow, uint32_t *sweeps_out, bool reset_done = false)
+{
+	fseq_params const &p = c->p;
+	uint32_t const m = p.m, n = (uint32_t) p.n, L = (uint32_t) p.segment_length;
+	uint32_t const nch = P.nchunks();
+	bool const sharded = c->sh.on;
+	int rc;
+	if (!reset_done && (rc = dp_spec_reset(c, P, st))) return rc;
 	uint32_t *d_active = c->d_spec, *d_changed = d_active + nch, *d_tailmin = d_changed + nch, *d_floor = d_tailmin + nch,
 	         *d_lift = d_floor + nch, *d_ovf = d_lift + nch;
 	SpecCtl *d_ctl = reinterpret_cast<SpecCtl *>(d_ovf + nch);
@@ -1011,16 +1049,6 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	if (char const *e = getenv("FSEQ_DP_SPEC_WIN")) G.win = (uint32_t) std::max(1, atoi(e));
 	uint32_t const ncomplete = G.NR / 64u;
 	uint32_t const grid_c = (uint32_t) ((c->dp_size + 255) / 256);          // 4 blocks of 64 entries per workgroup, incl. the final cell's
-	HIP_TRY(c, hipMemsetAsync(c->dp.M, 0, c->dp_size * 4, st));
-	HIP_TRY(c, hipMemsetAsync(c->d_Mprev, 0, c->dp_size * 4, st));
-	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 6 * nch + 16) * 4, st));
-	HIP_TRY(c, hipMemsetAsync(d_active, 0x01, (size_t) nch * 4, st));        // != 0: every chunk runs in sweep 1
-	if (sharded)
-	{
-		// LB / SZ are gathered over the ranks at the end: what nobody writes must be 0 everywhere
-		HIP_TRY(c, hipMemsetAsync(c->dp.LB, 0, c->dp_size * 4, st));
-		HIP_TRY(c, hipMemsetAsync(c->dp.SZ, 0, c->dp_size * 4, st));
-	}
 
 	DpSpecArgs SP;
 	SP.chunk_r0 = c->d_chunk_r0; SP.nchunks = nch; SP.chunk0 = P.mine_lo; SP.active = d_active; SP.ovf = d_ovf;
@@ -1429,6 +1457,12 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 		else if (parts <= 1)
 		{
+			if (use_spec)
+			{
+				// the arrays the speculative DP starts from are reset on the second stream while phase C runs
+				if ((rc = dp_spec_reset(c, spec, c->stream2))) return rc;
+				HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
+			}
 			if (!sharded) launch_columns(0, c->nblocks);
 			else if (my_blocks)
 			{
@@ -1445,7 +1479,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
 			if (use_spec)
 			{
-				if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps))) return rc;
+				HIP_TRY(c, hipStreamWaitEvent(st, c->ev_part[15], 0));      // the DP arrays were reset beside phase C
+				if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps, true))) return rc;
 			}
 			else if (chunks <= 1)
 				hipLaunchKernelGGL(k_dp<DP_WHOLE>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
@@ -1545,7 +1580,9 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			{
 				uint64_t const own_lo = held_lo(c), own_hi = sharded ? sh.c_hi : n;      // columns whose lists I answer for
 				std::vector<uint2> tau(S);
-				if (S > 1)
+				if (S > 1 && c->tau_host.size() == S)
+					tau = c->tau_host;                                          // came back with the traceback
+				else if (S > 1)
 				{
 					if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
 					if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
@@ -1601,6 +1638,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 						std::vector<uint64_t> qc(2 * Q);
 						for (size_t i = 0; i < Q; ++i) { qc[i] = ask[i].col; qc[Q + i] = ask[i].lb; }
 						std::vector<uint32_t> cnt(Q);
+						if (c->cols_cap < 2 * Q) { if ((rc = dev_alloc(c, &c->d_cols, 2 * Q))) return rc; c->cols_cap = 2 * Q; }
+						if (c->tau_cap < Q) { if ((rc = dev_alloc(c, &c->d_tau, Q))) return rc; c->tau_cap = Q; }
 						HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc.data(), 2 * Q * 8, hipMemcpyHostToDevice, st));
 						uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->d_tau);
 						hipLaunchKernelGGL(k_seg_count, dim3((uint32_t) Q), dim3(64), 0, st, c->d_cols, c->d_cols + Q, own_lo, own_hi, c->stride, c->d_ent, c->d_hdr, d_cnt);

@@ -1087,6 +1087,41 @@ __global__ __launch_bounds__(64) void k_seg_tau(
 		out[blockIdx.x] = h.z ? make_uint2(0u, SEG_TAU_EXACT) : make_uint2(list[h.x - 1u].x, SEG_TAU_OPEN);
 }
 
+// The same straight off the device traceback (k_tb_emit's output: entry i = {end - L, lb, max, size}, the last segment
+// first; count[0] = S entries), so that the thresholds travel to the host together with the traceback: workgroup i
+// answers for the boundary of entry i and writes out[S - 1 - i] (the host's order); max_seg = entry 0's maximum.
+__global__ __launch_bounds__(64) void k_seg_tau_tb(
+	uint4 const *__restrict__ tb, uint32_t const *__restrict__ count, uint32_t L, uint32_t stride,
+	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint2 *__restrict__ out)
+{
+	uint32_t const S = count[0];
+	if (blockIdx.x >= S) return;
+	uint32_t const max_seg = tb[0].z;
+	uint64_t const k = (uint64_t) tb[blockIdx.x].x + L - 1u;          // column rb - 1
+	uint32_t const j = S - 1u - blockIdx.x;
+	uint32_t const lane = lane_id();
+	uint4 const h = hdr[k];
+	uint2 const *list = ent + k * (size_t) stride;
+	uint32_t cum_base = 0;
+	for (uint32_t s0 = 0; s0 < h.x; s0 += 64u)
+	{
+		uint32_t const i = s0 + lane;
+		uint2 const e = i < h.x ? list[i] : make_uint2(0u, 0u);
+		uint32_t const inc = cum_base + wave_incl_add(e.y);
+		uint64_t const over = __ballot(i < h.x && inc > max_seg);
+		if (over)
+		{
+			uint32_t const first = (uint32_t) __builtin_ctzll(over);
+			uint32_t const v = shfl_u32(e.x, (int) first);
+			if (lane == 0) out[j] = (s0 + first == 0u) ? make_uint2(0xFFFFFFFFu, SEG_TAU_NEVER) : make_uint2(v, SEG_TAU_EXACT);
+			return;
+		}
+		cum_base = readlane_u32(inc, 63);
+	}
+	if (lane == 0)
+		out[j] = h.z ? make_uint2(0u, SEG_TAU_EXACT) : make_uint2(list[h.x - 1u].x, SEG_TAU_OPEN);
+}
+
 // ... and the size of a merged segment: #{d_col+1 > lb} for (col, lb) pairs (lp.cc:363,366), same ownership rule
 __global__ __launch_bounds__(64) void k_seg_count(
 	uint64_t const *__restrict__ cols, uint64_t const *__restrict__ lbs, uint64_t col_lo, uint64_t col_hi, uint32_t stride,
