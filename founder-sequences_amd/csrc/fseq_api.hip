@@ -660,13 +660,15 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	{
 		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
 		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
-		// within [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.
+		// within [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.  (FSEQ_DEBUG prints the choice.)
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
 			if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			{
-				uint64_t const reserve = (k_cnt / p.segment_length + 1) * (uint64_t) m * 8ull + (4ull << 30);
+				// (everything else of any size is allocated by now: the margin covers the traceback / task arrays of the
+				// tail, a few MB, and fragmentation -- BASELINE C4 on one GPU sits within 1 GiB of the 64-column stride)
+				uint64_t const reserve = (k_cnt / p.segment_length + 1) * (uint64_t) m * 8ull + (2ull << 30);
 				uint64_t const avail = free_b > reserve ? free_b - reserve : 0;
 				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 64ull << 30));
 			}
@@ -674,6 +676,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		uint64_t st_ = 16;
 		while ((k_cnt / st_ + 2) * (uint64_t) m * 8ull > budget) st_ *= 2;
 		c->snap_stride = (uint32_t) st_;
+		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB)\n", (unsigned long long) st_, budget / 1073741824.0);
 		uint64_t const q_lo = k_lo / st_, q_hi = held_hi(c) / st_;
 		if ((rc = dev_alloc(c, &c->d_ss_a_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
 		if ((rc = dev_alloc(c, &c->d_ss_d_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
