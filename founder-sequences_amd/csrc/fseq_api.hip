@@ -674,6 +674,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			}
 		}
 		uint64_t st_ = 16;
+		if (char const *e = getenv("FSEQ_SNAP_STRIDE")) st_ = (uint64_t) std::max(1, atoi(e));     // (experiments: first stride tried)
 		while ((k_cnt / st_ + 2) * (uint64_t) m * 8ull > budget) st_ *= 2;
 		c->snap_stride = (uint32_t) st_;
 		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB)\n", (unsigned long long) st_, budget / 1073741824.0);

@@ -145,6 +145,26 @@ def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
     compare_long(pkg, msa, 8, block_len=40)
 
 
+@pytest.mark.parametrize("fan", [0, 2, 3, 5, 64])
+def test_phase_b_recursion_with_any_group_size(pkg, monkeypatch, fan):
+    """Phase B composes groups of G key blocks level after level until at most G are left (G = 4 by itself): 600
+    and 37 blocks with G = 2 (nine levels), 3, 5, 64 (one level, then a chain of ten), on the LDS-resident and on the
+    streamed kernels; every block boundary state is compared with the oracle's pBWT."""
+    if fan:
+        monkeypatch.setenv("FSEQ_CHAIN_FAN", str(fan))
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 10), (900, 600, 12, 10, 50, 1e-3, 52, 1, 16),
+                                                  (12000, 900, 10, 12, 200, 3e-4, 46, 0, 12)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctx, _ = compare_long(pkg, msa, L, block_len=B)
+        bl, nbk = ctx.timings()["block_len"], ctx.timings()["n_blocks"]
+        p = fso.Pbwt(msa)
+        for b in range(0, nbk + 1, max(1, nbk // 7)):
+            while p.idx < min(n, b * bl):
+                p.step()
+            a, d = ctx.debug_block_state(b)
+            assert np.array_equal(a, p.a) and np.array_equal(d, p.d), (m, n, b, fan)
+
+
 def test_phase_b_and_pass_2_with_the_plain_scan(pkg, monkeypatch):
     """Phase B and pass 2 scan keys (count << shift | divergence) while n fits the shift of their configuration -- every
     test shape does; FSEQ_PLAIN_SCAN keeps the has-based scan, which long inputs (BASELINE C5: n = 10^6 on the
