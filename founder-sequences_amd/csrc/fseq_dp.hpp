@@ -891,42 +891,59 @@ __global__ __launch_bounds__(1024) void k_dp(
 				single_cell(i);
 			}
 		}
-		else if (wave == DP_LOADER)
-		{
-			// ---- loader: lists of round r+2; then make sure round r+1 has landed
-			if (r + 2u < r_end)
-			{
-				load_round(r + 2u);
-				dp_wait_all_but(npairs + 3u);                  // = everything but the round just issued
-			}
-			else
-				asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-		}
-		else if (wave == DP_WRITER)
-		{
-			// ---- writer: a finished *and indexed* round to HBM
-			uint32_t const lag = S.pipe ? 2u : 1u;
-			if (r >= r_begin + lag) flush_round(r - lag);
-		}
 		else
 		{
-			// ---- pipelined mode, waves 12 and 13: rmq.update of round r-1 (rmq.hh:61-81); the launch before
-			// this one has done it for the round in front of r_begin
-			if (r > r_begin)
-			{
+			// ---- the four waves that own no cells.  Pipelined mode: they share rmq.update of round r-1 (rmq.hh:61-81; the
+			// launch before this one has done it for the round in front of r_begin) slice by slice -- one wave building
+			// all four 16-bit slices of a block (~420 instructions, on a SIMD it shares with three compute waves) was
+			// the critical path of every round (stamps: 6,900 of 7,000 cycles busy against ~5,000 on the compute
+			// waves); the loader and the writer have instructions to spare, and a wave per SIMD evens the four out.
+			auto update_share = [&]() {
+				if (!S.pipe || r <= r_begin) return;
 				DpRound const P = dp_round(S, r - 1u);
-				if (P.len > 0 && !P.final_round)
+				if (P.len == 0 || P.final_round) return;
+				uint32_t const q = wave - 12u;
+				uint32_t const blkA = P.t0 >> 6, blkB = (P.t1 - 1u) >> 6;
+				// slice q of the first block; of a second block the slices that hold fresh lanes go to q = 0, 1, 2, the
+				// rest (no bit can be set there: the fresh lanes lie below them) are zeroed by the writer
+				dp_mask_slice(D, P, blkA, q);
+				if (blkB != blkA)
 				{
-					uint32_t const blkA = P.t0 >> 6, blkB = (P.t1 - 1u) >> 6;
-					if (wave == 12u)
+					uint32_t const nfresh = P.t1 - blkB * 64u;              // fresh lanes 0 .. nfresh - 1 of the second block
+					if (16u * q < nfresh) dp_mask_slice(D, P, blkB, q);
+					if (q == 3u)
 					{
-						dp_mask_block(D, P, blkA);
-						if ((blkA + 1u) * 64u <= P.t1) dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
+						uint32_t const idx = blkB * 64u + lane;
+						if (lane < nfresh)
+							for (uint32_t ch = (nfresh + 15u) / 16u; ch < 4u; ++ch) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + ch] = 0;
 					}
-					else if (blkB != blkA)
-						dp_mask_block(D, P, blkB);
+				}
+				if (q == 3u && (blkA + 1u) * 64u <= P.t1) dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
+			};
+			if (wave == DP_LOADER)
+			{
+				// ---- loader: lists of round r+2; (its share of the update while they fly;) then make sure round r+1 has landed
+				if (r + 2u < r_end)
+				{
+					load_round(r + 2u);
+					update_share();
+					dp_wait_all_but(npairs + 3u);                  // = everything but the round just issued
+				}
+				else
+				{
+					update_share();
+					asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 				}
 			}
+			else if (wave == DP_WRITER)
+			{
+				// ---- writer: a finished *and indexed* round to HBM
+				uint32_t const lag = S.pipe ? 2u : 1u;
+				if (r >= r_begin + lag) flush_round(r - lag);
+				update_share();
+			}
+			else
+				update_share();                                    // (waves 12 and 13 exist for this in pipelined mode)
 		}
 		DP_STAMP(ts1);
 		dp_barrier();
