@@ -540,6 +540,45 @@ __device__ __forceinline__ void dp_mask_slice(DpLds const &D, DpRound const &R, 
 	if (fresh) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + chunk] = (uint16_t) bits;
 }
 
+// Two slices at once (any two (block, chunk) pairs): their dependency chains interleave -- one slice alone is a chain
+// of 16 x (readlane, compare, select, min) that a wave sharing its SIMD with three others issues at ~60 cycles a link.
+__device__ __forceinline__ void dp_mask_slice2(DpLds const &D, DpRound const &R, uint32_t blk0, uint32_t chunk0, uint32_t blk1, uint32_t chunk1)
+{
+	uint32_t const lane = lane_id();
+	uint32_t idx[2] = {blk0 * 64u + lane, blk1 * 64u + lane}, plo[2] = {16u * chunk0, 16u * chunk1};
+	uint32_t mine[2], runmin[2], bits[2];
+#pragma unroll
+	for (int c = 0; c < 2; ++c)
+	{
+		mine[c] = D.Mr[idx[c] & (DPW - 1u)];
+		uint32_t const phi = plo[c] + 16u;
+		uint32_t pm = lane >= phi ? mine[c] : 0xFFFFFFFFu;
+		pm = min(pm, dpp_mov<DPP_ROW_SHR1, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR2, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR4, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_SHR8, 0xF>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST15, 0xA>(0xFFFFFFFFu, pm));
+		pm = min(pm, dpp_mov<DPP_ROW_BCAST31, 0xC>(0xFFFFFFFFu, pm));
+		runmin[c] = lane >= phi ? pm : mine[c];
+		bits[c] = (lane >= plo[c] && lane < phi) ? (1u << (lane - plo[c])) : 0u;
+	}
+#pragma unroll
+	for (int pp = 15; pp >= 0; --pp)
+	{
+#pragma unroll
+		for (int c = 0; c < 2; ++c)
+		{
+			uint32_t const p = plo[c] + (uint32_t) pp;
+			uint32_t const x = readlane_u32(mine[c], (int) p);
+			bool const in = lane > p;
+			bits[c] |= (in && x <= runmin[c]) ? (1u << pp) : 0u;
+			runmin[c] = in ? min(runmin[c], x) : runmin[c];
+		}
+	}
+	if (idx[0] >= R.t0 && idx[0] < R.t1) ((lds_u16 *) D.Kr)[(idx[0] & (DPW - 1u)) * 4u + chunk0] = (uint16_t) bits[0];
+	if (idx[1] >= R.t0 && idx[1] < R.t1) ((lds_u16 *) D.Kr)[(idx[1] & (DPW - 1u)) * 4u + chunk1] = (uint16_t) bits[1];
+}
+
 // Stack masks of a whole 64-block held one key per lane: lane t gets the mask of entry t (bit p <= t set iff
 // key[p] <= min key(p..t]).  Four independent dependency chains (one per 16-bit slice) that interleave.
 __device__ __forceinline__ unsigned long long stack_mask64(uint32_t mine)
@@ -902,23 +941,26 @@ __global__ __launch_bounds__(1024) void k_dp(
 				if (!S.pipe || r <= r_begin) return;
 				DpRound const P = dp_round(S, r - 1u);
 				if (P.len == 0 || P.final_round) return;
-				uint32_t const q = wave - 12u;
+				// Two slices a call (interleaved chains).  Wave 12: slices 0, 1 of the first block; wave 13: its slices 2, 3;
+				// the writer: the samples of a completed block and the slices of a second block that hold fresh lanes (the others cannot have a
+				// bit set -- the fresh lanes lie below them -- and are zeroed).  The loader has its ~27 LDS-DMA issues a
+				// round (measured ~6,400 cycles with M0 to set for each): no share.
 				uint32_t const blkA = P.t0 >> 6, blkB = (P.t1 - 1u) >> 6;
-				// slice q of the first block; of a second block the slices that hold fresh lanes go to q = 0, 1, 2, the
-				// rest (no bit can be set there: the fresh lanes lie below them) are zeroed by the writer
-				dp_mask_slice(D, P, blkA, q);
-				if (blkB != blkA)
+				if (wave == 12u)
+					dp_mask_slice2(D, P, blkA, 0u, blkA, 1u);
+				else if (wave == 13u)
+					dp_mask_slice2(D, P, blkA, 2u, blkA, 3u);
+				else if (wave == DP_WRITER && (blkA + 1u) * 64u <= P.t1)
+					dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
+				if (wave == DP_WRITER && blkB != blkA)
 				{
 					uint32_t const nfresh = P.t1 - blkB * 64u;              // fresh lanes 0 .. nfresh - 1 of the second block
-					if (16u * q < nfresh) dp_mask_slice(D, P, blkB, q);
-					if (q == 3u)
-					{
-						uint32_t const idx = blkB * 64u + lane;
-						if (lane < nfresh)
-							for (uint32_t ch = (nfresh + 15u) / 16u; ch < 4u; ++ch) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + ch] = 0;
-					}
+					if (nfresh > 16u) dp_mask_slice2(D, P, blkB, 0u, blkB, 1u); else dp_mask_slice(D, P, blkB, 0u);
+					if (nfresh > 32u) dp_mask_slice(D, P, blkB, 2u);
+					uint32_t const idx = blkB * 64u + lane;
+					if (lane < nfresh)
+						for (uint32_t ch = (nfresh + 15u) / 16u; ch < 4u; ++ch) ((lds_u16 *) D.Kr)[(idx & (DPW - 1u)) * 4u + ch] = 0;
 				}
-				if (q == 3u && (blkA + 1u) * 64u <= P.t1) dp_push_samples(D, blkA, (r - 1u) % DP_MBSLOTS);
 			};
 			if (wave == DP_LOADER)
 			{
