@@ -765,6 +765,9 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 	__syncthreads();
 
 	bool const zero_present = (V_l[0] == 0u);
+#ifdef FSEQ_KC_STAMPS
+	long long kc_work = 0, kc_wait = 0, kc_last = clock64();
+#endif
 
 	for (uint32_t j = 0; j < nb; ++j)
 	{
@@ -800,7 +803,13 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 			}
 			if (pass + 1 == npass && more && has_chunk)
 				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
+#ifdef FSEQ_KC_STAMPS
+			{ long long const t_ = clock64(); kc_work += t_ - kc_last; kc_last = t_; }
 			__syncthreads();
+			{ long long const t_ = clock64(); kc_wait += t_ - kc_last; kc_last = t_; }
+#else
+			__syncthreads();
+#endif
 		}
 
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
@@ -899,6 +908,10 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 			__builtin_amdgcn_s_setprio(0);
 		}
 	}
+#ifdef FSEQ_KC_STAMPS
+	if (lane_id() == 0 && (blockIdx.x == 100 || blockIdx.x == 3000))
+		printf("kc stamps block %u wave %u: work %lld wait %lld cycles per column (%u columns)\n", blockIdx.x, wave_id(), kc_work / nb, kc_wait / nb, nb);
+#endif
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
 	publish_block_done(done_host, blockIdx.x + block0, epoch);
 }
