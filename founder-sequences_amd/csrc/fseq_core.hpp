@@ -263,7 +263,10 @@ __device__ __forceinline__ void partition_step(
 #pragma unroll
 	for (int x = 0; x < SIGMA; ++x) run[x] = 0;
 	uint32_t has = 0, pend = 0;
-	uint64_t lcp = 0;                       // nibble x = rows with symbol x seen so far in this thread
+	// nibble x = rows with symbol x seen so far in this thread (four symbols: one 32-bit word, and an unused position,
+	// s = 4, counts in a fifth nibble nobody reads -- no 64-bit shifts and nothing conditional in the bookkeeping)
+	using LcpT = std::conditional_t<SIGMA == 4, uint32_t, uint64_t>;
+	LcpT lcp = 0;
 	uint32_t lidx[E];
 #pragma unroll
 	for (int e = 0; e < E; ++e)
@@ -281,12 +284,24 @@ __device__ __forceinline__ void partition_step(
 			run[x] = is ? 0u : r;
 		}
 		dnew[e] = o;
-		uint32_t const sh = (c & 15u) * 4u;
-		lidx[e] = (uint32_t) (lcp >> sh) & 15u;
-		pend |= (act && !((has >> (c & 15u)) & 1u)) ? (1u << e) : 0u;
-		lcp += act ? (1ull << sh) : 0ull;
-		has |= act ? (1u << (c & 15u)) : 0u;
+		if constexpr (SIGMA == 4)
+		{
+			uint32_t const sh = c * 4u;                        // (c <= 4)
+			lidx[e] = (uint32_t) (lcp >> sh) & 15u;
+			pend |= (act && lidx[e] == 0u) ? (1u << e) : 0u;     // first row of its symbol in this thread
+			lcp += (LcpT) 1u << sh;
+		}
+		else
+		{
+			uint32_t const sh = (c & 15u) * 4u;
+			lidx[e] = (uint32_t) (lcp >> sh) & 15u;
+			pend |= (act && !((has >> (c & 15u)) & 1u)) ? (1u << e) : 0u;
+			lcp += act ? ((LcpT) 1u << sh) : (LcpT) 0u;
+			has |= act ? (1u << (c & 15u)) : 0u;
+		}
 	}
+	if constexpr (SIGMA == 4)
+		has = ((lcp & 0xFu) ? 1u : 0u) | ((lcp & 0xF0u) ? 2u : 0u) | ((lcp & 0xF00u) ? 4u : 0u) | ((lcp & 0xF000u) ? 8u : 0u);
 
 	if constexpr (KS != 0)
 	{
