@@ -284,6 +284,9 @@ __device__ __forceinline__ void partition_step(
 			run[x] = is ? 0u : r;
 		}
 		dnew[e] = o;
+		// (the value is needed only behind the barrier; left alone, the compiler sinks the four selects there and keeps
+		// the four (c == x) conditions of every row alive in SGPR pairs instead -- in kernels that already spill them)
+		asm volatile("" : "+v"(dnew[e]));
 		if constexpr (SIGMA == 4)
 		{
 			uint32_t const sh = c * 4u;                        // (c <= 4)
