@@ -243,7 +243,7 @@ struct Shard {
 	uint64_t xwords = 0;
 	fseq_allreduce_fn fn = nullptr;
 	void *user = nullptr;
-	uint32_t bpr = 0;                       // blocks per rank = chain_G * chain_G2 (a rank is one hyper-block of phase B)
+	uint32_t bpr = 0;                       // blocks per rank = shard_q * chain_fan^shard_k (a rank is one hyper-block of phase B)
 	uint32_t active = 1;                    // ranks that own blocks
 	uint32_t b_lo = 0, b_hi = 0;            // my blocks
 	uint64_t c_lo = 0, c_hi = 0, c_end = 0; // my columns [c_lo, c_hi); held: [c_lo, c_end) (halo for my last DP round)
@@ -294,12 +294,12 @@ struct fseq_ctx {
 	// device work buffers
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
-	uint32_t *d_srank = nullptr, *d_skeyd = nullptr, *d_snkeys = nullptr, *d_sstate_a = nullptr, *d_sstate_d = nullptr;
 	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
 	// not sharded: phase B over any number of levels (levels[i - 1] = the composites of chain_fan level-(i - 1) key blocks)
 	struct ChainLevel { uint32_t count = 0; uint64_t cols = 0; uint32_t *rank = nullptr, *keyd = nullptr, *nkeys = nullptr, *state_a = nullptr, *state_d = nullptr; };
 	std::vector<ChainLevel> levels;
 	uint32_t chain_fan = 0;
+	uint32_t shard_k = 0, shard_q = 0;       // sharded: a rank's hyper-block = shard_q groups of chain_fan^shard_k blocks
 	uint32_t chain_G = 0, n_super = 0;       // sharded: super-blocks of chain_G blocks
 	uint32_t chain_G2 = 0, n_hyper = 0;      // third level: hyper-blocks of chain_G2 super-blocks (0 = two levels only)
 	uint2 *d_ent = nullptr;
@@ -413,8 +413,8 @@ int alloc_msa(fseq_ctx *c)
 	return FSEQ_OK;
 }
 
-// Block structure of phases A-C.  Sharded: every rank is one hyper-block of phase B (chain_G2 super-blocks of
-// chain_G blocks), so the only exchange of phase B is the W composite key blocks of the ranks.
+// Block structure of phases A-C.  Sharded: every rank is one hyper-block of phase B (shard_q groups of
+// chain_fan^shard_k blocks), so the only exchange of phase B is the W composite key blocks of the ranks.
 void block_geometry(fseq_ctx *c)
 {
 	fseq_params const &p = c->p;
@@ -460,18 +460,33 @@ void block_geometry(fseq_ctx *c)
 	c->nblocks = (uint32_t) ((p.n + c->B - 1) / c->B);
 	if (sh.on)
 	{
+		// A rank is one hyper-block of phase B: q groups of F^k blocks, composed level by level with fan F (k launches of
+		// <= F serial steps up, the q composites into the hyper key block, and the same down again).  q F^k >= the
+		// blocks a rank needs; (k, q) with the fewest serial steps among those that keep every rank busy.
 		uint32_t const per = (c->nblocks + sh.world - 1) / sh.world;
-		uint32_t g = (uint32_t) std::ceil(std::sqrt((double) per));
-		if (g < 1) g = 1;
-		// a rank is G2 super-blocks of G blocks: G x G2 = per exactly when per has a divisor near its root (the block
-		// counts chosen above do), else the next product above it (the last ranks then own fewer blocks)
-		for (uint32_t t = g; t >= 1 && 2 * t >= g; --t)
-			if (per % t == 0) { g = t; break; }
-		uint32_t const g2 = (per + g - 1) / g;
-		c->chain_G = g; c->chain_G2 = g2;
-		sh.bpr = g * g2;
-		c->n_super = (c->nblocks + g - 1) / g;
-		c->n_hyper = (c->n_super + g2 - 1) / g2;
+		uint32_t F = 4;
+		if (char const *e = getenv("FSEQ_CHAIN_FAN")) F = (uint32_t) std::max(2, atoi(e));
+		uint32_t best_k = 0, best_q = std::max(1u, per), best_cost = ~0u;
+		{
+			uint64_t pw = 1;
+			for (uint32_t k = 0; pw <= per; ++k, pw *= F)
+			{
+				uint32_t const q = (uint32_t) ((per + pw - 1) / pw);
+				uint64_t const bpr = (uint64_t) q * pw;
+				bool const all_busy = bpr == per || bpr * (sh.world - 1) < c->nblocks;      // the last rank still owns blocks
+				uint32_t const cost = F * k + q;
+				if ((all_busy || k == 0) && cost < best_cost) { best_cost = cost; best_k = k; best_q = q; }
+			}
+		}
+		c->chain_fan = F; c->shard_k = best_k; c->shard_q = best_q;
+		{
+			uint64_t pw = 1;
+			for (uint32_t i = 0; i < best_k; ++i) pw *= F;
+			sh.bpr = (uint32_t) (best_q * pw);
+			c->chain_G = (uint32_t) pw; c->chain_G2 = best_q;          // (diagnostics: a rank = chain_G2 groups of chain_G blocks)
+		}
+		c->n_super = (c->nblocks + c->chain_G - 1) / c->chain_G;
+		c->n_hyper = (c->nblocks + sh.bpr - 1) / sh.bpr;
 		sh.active = c->n_hyper;                                 // <= world
 		sh.b_lo = std::min<uint64_t>(c->nblocks, (uint64_t) sh.rank * sh.bpr);
 		sh.b_hi = std::min<uint64_t>(c->nblocks, (uint64_t) (sh.rank + 1) * sh.bpr);
@@ -604,11 +619,24 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		}
 		else
 		{
-			if ((rc = dev_alloc(c, &c->d_srank, (size_t) c->n_super * m))) return rc;
-			if ((rc = dev_alloc(c, &c->d_skeyd, (size_t) c->n_super * m))) return rc;
-			if ((rc = dev_alloc(c, &c->d_snkeys, c->n_super))) return rc;
-			if ((rc = dev_alloc(c, &c->d_sstate_a, ((size_t) c->n_super + 1) * m))) return rc;
-			if ((rc = dev_alloc(c, &c->d_sstate_d, ((size_t) c->n_super + 1) * m))) return rc;
+			// sharded: shard_k levels below the hyper key blocks (indexed like the blocks: by their place in the whole
+			// alignment; a rank fills its own range)
+			uint32_t cnt = c->nblocks;
+			uint64_t cols = c->B;
+			for (uint32_t i = 0; i < c->shard_k; ++i)
+			{
+				fseq_ctx::ChainLevel lv;
+				lv.count = (cnt + c->chain_fan - 1) / c->chain_fan;
+				lv.cols = cols * c->chain_fan;
+				if ((rc = dev_alloc(c, &lv.rank, (size_t) lv.count * m))) return rc;
+				c->levels.push_back(lv);
+				fseq_ctx::ChainLevel &L = c->levels.back();
+				if ((rc = dev_alloc(c, &L.keyd, (size_t) L.count * m))) return rc;
+				if ((rc = dev_alloc(c, &L.nkeys, L.count))) return rc;
+				if ((rc = dev_alloc(c, &L.state_a, ((size_t) L.count + 1) * m))) return rc;
+				if ((rc = dev_alloc(c, &L.state_d, ((size_t) L.count + 1) * m))) return rc;
+				cnt = L.count; cols = L.cols;
+			}
 		}
 		if (c->sh.on && c->n_hyper)
 		{
@@ -691,7 +719,6 @@ void free_work(fseq_ctx *c)
 {
 	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
 	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
-	dev_free(&c->d_srank); dev_free(&c->d_skeyd); dev_free(&c->d_snkeys); dev_free(&c->d_sstate_a); dev_free(&c->d_sstate_d);
 	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
 	for (auto &lv : c->levels) { dev_free(&lv.rank); dev_free(&lv.keyd); dev_free(&lv.nkeys); dev_free(&lv.state_a); dev_free(&lv.state_d); }
 	c->levels.clear();
@@ -1264,16 +1291,27 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	}
 	else
 	{
-		// Sharded phase B: rank r is hyper-block r.  Compose my super-blocks, compose them into my hyper key block,
-		// exchange the W hyper key blocks (the one collective of pass 1's column work), chain them (every rank, same
-		// result), expand my hyper-block to my super-block and then my block boundaries.
-		uint32_t const G = c->chain_G, NSB = c->n_super, G2 = c->chain_G2, NH = c->n_hyper;
+		// Sharded phase B: rank r is hyper-block r.  Up the levels over my own block range (fan F, as on one GPU), my
+		// last composites into my hyper key block, exchange the W hyper key blocks (the one collective of pass 1's column
+		// work), chain them (every rank, same result), then down again from the state in front of my hyper-block.
+		uint32_t const F = c->chain_fan, NH = c->n_hyper, K = c->shard_k, Q = c->shard_q;
 		bool const have = sh.rank < NH;
-		uint32_t const s_lo = std::min(NSB, sh.rank * G2), s_hi = std::min(NSB, (sh.rank + 1u) * G2);
-		launch_chain(c, s_hi - s_lo, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, nullptr, nullptr,
-		             nullptr, nullptr, c->d_srank, c->d_skeyd, c->d_snkeys, s_lo);
+		auto rank_of = [&](size_t i) { return i ? c->levels[i - 1].rank : c->d_rank; };
+		auto keyd_of = [&](size_t i) { return i ? c->levels[i - 1].keyd : c->d_keyd; };
+		auto nkeys_of = [&](size_t i) { return i ? c->levels[i - 1].nkeys : c->d_nkeys; };
+		auto sa_of = [&](size_t i) { return i ? c->levels[i - 1].state_a : c->d_bstate_a; };
+		auto sd_of = [&](size_t i) { return i ? c->levels[i - 1].state_d : c->d_bstate_d; };
+		auto count_of = [&](size_t i) { return i ? c->levels[i - 1].count : c->nblocks; };
+		auto cols_of = [&](size_t i) { return i ? c->levels[i - 1].cols : (uint64_t) c->B; };
+		// my items of level i: [lo_i, hi_i) (rank boundaries are multiples of F^K blocks)
+		std::vector<uint32_t> lo(K + 1), hi(K + 1);
+		lo[0] = b_lo; hi[0] = b_hi;
+		for (uint32_t i = 1; i <= K; ++i) { lo[i] = lo[i - 1] / F; hi[i] = (hi[i - 1] + F - 1) / F; }
+		for (uint32_t i = 1; have && i <= K; ++i)
+			launch_chain(c, hi[i] - lo[i], rank_of(i - 1), keyd_of(i - 1), nkeys_of(i - 1), count_of(i - 1), F, cols_of(i - 1), nullptr, nullptr,
+			             nullptr, nullptr, rank_of(i), keyd_of(i), nkeys_of(i), lo[i]);
 		if (have)
-			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, nullptr, nullptr,
+			launch_chain(c, 1, rank_of(K), keyd_of(K), nkeys_of(K), count_of(K), Q, cols_of(K), nullptr, nullptr,
 			             nullptr, nullptr, c->d_hrank, c->d_hkeyd, c->d_hnkeys, sh.rank);
 		{
 			// xbuf: [hrank NH x m][hkeyd NH x m][hnkeys NH]
@@ -1290,14 +1328,15 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			HIP_TRY(c, hipMemcpyAsync(c->d_hkeyd, sh.xbuf + w, w * 4, hipMemcpyDeviceToDevice, st));
 			HIP_TRY(c, hipMemcpyAsync(c->d_hnkeys, sh.xbuf + 2 * w, (size_t) NH * 4, hipMemcpyDeviceToDevice, st));
 		}
-		launch_chain(c, 1, c->d_hrank, c->d_hkeyd, c->d_hnkeys, NH, NH, (uint64_t) G2 * G * c->B, nullptr, nullptr,
+		launch_chain(c, 1, c->d_hrank, c->d_hkeyd, c->d_hnkeys, NH, NH, (uint64_t) sh.bpr * c->B, nullptr, nullptr,
 		             c->d_hstate_a, c->d_hstate_d, nullptr, nullptr, nullptr);
 		if (have)
 		{
-			launch_chain(c, 1, c->d_srank, c->d_skeyd, c->d_snkeys, NSB, G2, (uint64_t) G * c->B, c->d_hstate_a, c->d_hstate_d,
-			             c->d_sstate_a, c->d_sstate_d, nullptr, nullptr, nullptr, sh.rank);
-			launch_chain(c, s_hi - s_lo, c->d_rank, c->d_keyd, c->d_nkeys, c->nblocks, G, c->B, c->d_sstate_a, c->d_sstate_d,
-			             c->d_bstate_a, c->d_bstate_d, nullptr, nullptr, nullptr, s_lo);
+			launch_chain(c, 1, rank_of(K), keyd_of(K), nkeys_of(K), count_of(K), Q, cols_of(K), c->d_hstate_a, c->d_hstate_d,
+			             sa_of(K), sd_of(K), nullptr, nullptr, nullptr, sh.rank);
+			for (uint32_t i = K; i >= 1; --i)
+				launch_chain(c, hi[i] - lo[i], rank_of(i - 1), keyd_of(i - 1), nkeys_of(i - 1), count_of(i - 1), F, cols_of(i - 1), sa_of(i), sd_of(i),
+				             sa_of(i - 1), sd_of(i - 1), nullptr, nullptr, nullptr, lo[i]);
 			// the state behind my last block = in front of the next rank's hyper-block (or behind the whole alignment,
 			// which the expansion has written itself): my halo block starts from it
 			if (b_hi < c->nblocks)

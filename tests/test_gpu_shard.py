@@ -115,6 +115,18 @@ def test_sharded_run_matches_oracle(pkg, world, shape):
     assert len(calls) == 1                            # every rank made the same exchanges
 
 
+@pytest.mark.parametrize("fan", [2, 3, 8])
+def test_sharded_phase_b_recursion(pkg, monkeypatch, fan):
+    """A rank composes its hyper key block level by level (groups of F key blocks; F = 4 by itself): 1000 and 600 blocks
+    over 2 and 3 ranks with F = 2 (seven or eight levels per rank), 3, 8 -- block states included."""
+    monkeypatch.setenv("FSEQ_CHAIN_FAN", str(fan))
+    for world, (m, n, L, K, Brec, mu, seed, kind, B) in [(2, (64, 4000, 6, 5, 90, 5e-3, 29, 0, 4)), (3, (300, 6000, 25, 8, 200, 2e-3, 51, 0, 10)),
+                                                          (2, (12000, 900, 10, 12, 200, 3e-4, 46, 0, 12))]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctxs = run_world(pkg, world, lambda c: c.set_sequences(msa), m, n, L, block_len=B)
+        check_against_oracle(pkg, ctxs, msa, L)
+
+
 def test_sharded_device_generator_and_short_lists(pkg, monkeypatch):
     """Device-side generation of the rank's own columns; a list capacity too small for the DP is found out by all
     ranks together and retried."""
