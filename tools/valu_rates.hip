@@ -1,0 +1,311 @@
+// valu_rates.hip -- issue cost of the instruction classes the column kernels are made of, on gfx950.
+//
+// Every wave runs REPS x 16 copies of ONE instruction on independent registers (no dependency stalls inside the
+// 16; a DPP / readlane copy reads the result of the copy before it where the class is used that way) between two
+// s_memtime stamps.  Launched with 1, 2 and 4 waves per SIMD on every CU; reported per class:
+//   cycles per wave-instruction per SIMD = (slowest wave's ticks) / (instructions per wave * waves per SIMD)
+// i.e. what one SIMD pays per instruction when all its waves issue that class.  A second column prices the same
+// launch by wall time (HIP events) and the shader clock (ticks / wall of the same launch).
+// Build: hipcc --offload-arch=gfx950 -O2 -o tools/valu_rates tools/valu_rates.hip ; run: tools/valu_rates [out.json]
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+constexpr int REPS = 256;      // x 16 instructions per repetition
+
+__device__ __forceinline__ uint64_t memtime()
+{
+	uint64_t t;
+	asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+	return t;
+}
+
+// 16 independent copies inside ONE asm statement (between separate statements the compiler pads with s_nop):
+// I(R) is the instruction text for the copy whose own register is R; $a / $b = two shared vector inputs (%16, %17),
+// $s = a shared scalar (%18), $c = a scalar pair (%19)
+#define X16(I)                                                                                                          \
+	asm volatile(I("%0") I("%1") I("%2") I("%3") I("%4") I("%5") I("%6") I("%7") I("%8") I("%9") I("%10") I("%11") I("%12") I("%13") I("%14") I("%15") \
+	             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),    \
+	               "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])                                                                         \
+	             : "v"(a), "v"(b), "s"(s), "s"(cond) : "s20", "s21", "vcc");
+
+#define I_NONE(R) ""
+#define I_0(R) "v_max_u32 " R ", " R ", %16" "\n\t"
+#define I_1(R) "v_add_u32 " R ", " R ", %16" "\n\t"
+#define I_2(R) "v_and_b32 " R ", " R ", %16" "\n\t"
+#define I_3(R) "v_lshlrev_b32 " R ", 3, " R "" "\n\t"
+#define I_4(R) "v_lshl_add_u32 " R ", " R ", 2, %16" "\n\t"
+#define I_5(R) "v_bfe_u32 " R ", " R ", 4, 8" "\n\t"
+#define I_6(R) "v_and_or_b32 " R ", " R ", %16, %17" "\n\t"
+#define I_7(R) "v_max3_u32 " R ", " R ", %16, %17" "\n\t"
+#define I_8(R) "v_cndmask_b32 " R ", " R ", %16, vcc" "\n\t"
+#define I_9(R) "v_cndmask_b32_e64 " R ", " R ", %16, %19" "\n\t"
+#define I_10(R) "v_cmp_eq_u32 vcc, " R ", %16" "\n\t"
+#define I_11(R) "v_cmp_eq_u32_e64 s[20:21], " R ", %16" "\n\t"
+#define I_12(R) "v_max_u32_dpp " R ", " R ", " R " row_shr:1 row_mask:0xf bank_mask:0xf" "\n\t"
+#define I_13(R) "v_max_u32_dpp " R ", " R ", " R " row_bcast:15 row_mask:0xa bank_mask:0xf" "\n\t"
+#define I_14(R) "v_mov_b32_dpp " R ", %16 wave_shr:1 row_mask:0xf bank_mask:0xf" "\n\t"
+#define I_15(R) "v_add_u32_dpp " R ", " R ", " R " row_shr:2 row_mask:0xf bank_mask:0xf" "\n\t"
+#define I_16(R) "v_readlane_b32 s20, " R ", 63" "\n\t"
+#define I_17(R) "v_writelane_b32 " R ", %18, 5" "\n\t"
+#define I_18(R) "v_readfirstlane_b32 s20, " R "" "\n\t"
+#define I_19(R) "v_pk_max_u16 " R ", " R ", %16" "\n\t"
+#define I_20(R) "v_pk_add_u16 " R ", " R ", %16" "\n\t"
+#define I_21(R) "v_fma_f32 " R ", " R ", %16, %17" "\n\t"
+#define I_23(R) "v_mul_lo_u32 " R ", " R ", %16" "\n\t"
+#define I_24(R) "v_mad_u32_u24 " R ", " R ", %16, %17" "\n\t"
+#define I_25(R) "v_bcnt_u32_b32 " R ", " R ", %16" "\n\t"
+#define I_26(R) "v_mbcnt_lo_u32_b32 " R ", " R ", %16" "\n\t"
+#define I_28(R) "v_add_co_u32 " R ", vcc, " R ", %16" "\n\t"
+#define I_29(R) "v_perm_b32 " R ", " R ", %16, %17" "\n\t"
+#define I_30(R) "v_alignbit_b32 " R ", " R ", %16, 8" "\n\t"
+#define I_31(R) "v_mov_b32 " R ", %16" "\n\t"
+#define I_37(R) "v_min_u32 " R ", " R ", %16" "\n\t"
+#define I_38(R) "v_sub_u32 " R ", " R ", %16" "\n\t"
+#define I_39(R) "v_or3_b32 " R ", " R ", %16, %17" "\n\t"
+#define I_40(R) "v_add3_u32 " R ", " R ", %16, %17" "\n\t"
+
+#define I_41(R) "v_or_b32 " R ", " R ", %16\n\t"
+#define I_42(R) "v_xor_b32 " R ", " R ", %16\n\t"
+#define I_43(R) "v_lshrrev_b32 " R ", 3, " R "\n\t"
+#define I_44(R) "v_max_f32 " R ", " R ", %16\n\t"
+#define I_45(R) "v_max_i32 " R ", " R ", %16\n\t"
+#define I_46(R) "v_add_f32 " R ", " R ", %16\n\t"
+#define I_47(R) "v_mul_f32 " R ", " R ", %16\n\t"
+#define I_48(R) "v_max_u16 " R ", " R ", %16\n\t"
+#define I_49(R) "v_add_u32_e64 " R ", " R ", %16\n\t"
+#define I_50(R) "v_add_u32 " R ", %18, " R "\n\t"
+#define I_51(R) "v_cndmask_b32 " R ", %16, %17, vcc\n\t"
+#define I_52(R) "v_cndmask_b32_e64 " R ", " R ", %16, vcc\n\t"
+#define I_53(R) "v_cmp_eq_u32 vcc, " R ", %16\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\t"
+#define I_54(R) "v_addc_co_u32 " R ", vcc, " R ", %16, vcc\n\t"
+#define I_55(R) "v_ashrrev_i32 " R ", 3, " R "\n\t"
+#define I_56(R) "v_mul_u32_u24 " R ", " R ", %16\n\t"
+#define I_57(R) "v_subrev_u32 " R ", " R ", %16\n\t"
+#define I_58(R) "v_not_b32 " R ", " R "\n\t"
+#define I_59(R) "v_add_u32 " R ", 0x12345, " R "\n\t"
+#define I_60(R) "v_lshlrev_b32 " R ", %16, " R "\n\t"
+#define I_61(R) "v_and_b32 " R ", 15, " R "\n\t"
+#define I_62(R) "v_min_f32 " R ", " R ", %16\n\t"
+#define I_63(R) "v_max_i16 " R ", " R ", %16\n\t"
+#define I_64(R) "v_add_u16 " R ", " R ", %16\n\t"
+#define I_65(R) "v_sub_f32 " R ", " R ", %16\n\t"
+#define I_66(R) "v_sub_u32 " R ", 7, " R "\n\t"
+#define I_67(R) "v_fmac_f32 " R ", %16, %17\n\t"
+#define I_68(R) "v_max_u32_e64 " R ", " R ", %16\n\t"
+#define I_69(R) "v_and_b32_e64 " R ", " R ", %16\n\t"
+#define I_70(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\tv_add_u32 " R ", " R ", %17\n\t"
+#define I_71(R) "v_cmp_eq_u32 vcc, " R ", %16\n\tv_add_u32 " R ", " R ", %17\n\t"
+#define I_72(R) "v_cvt_f32_u32 " R ", " R "\n\t"
+#define I_73(R) "v_add_u32_sdwa " R ", " R ", %16 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"
+#define I_74(R) "v_cndmask_b32_dpp " R ", " R ", %16, vcc row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define I_75(R) "v_xad_u32 " R ", " R ", %16, %17\n\t"
+#define I_76(R) "v_add_lshl_u32 " R ", " R ", %16, 2\n\t"
+#define I_77(R) "v_lshl_or_b32 " R ", " R ", 4, %16\n\t"
+#define I_78(R) "v_sad_u32 " R ", " R ", %16, %17\n\t"
+#define I_79(R) "v_med3_u32 " R ", " R ", %16, %17\n\t"
+
+#define CLASSES(X)                                                                           \
+	X(0, "v_max_u32 (VOP2)", I_0)                                         \
+	X(1, "v_add_u32 (VOP2)", I_1)                                         \
+	X(2, "v_and_b32 (VOP2)", I_2)                                         \
+	X(3, "v_lshlrev_b32 (VOP2, literal shift)", I_3)                   \
+	X(4, "v_lshl_add_u32 (VOP3)", I_4)                            \
+	X(5, "v_bfe_u32 (VOP3)", I_5)                                       \
+	X(6, "v_and_or_b32 (VOP3)", I_6)                               \
+	X(7, "v_max3_u32 (VOP3)", I_7)                                   \
+	X(8, "v_cndmask_b32 (VOP2, vcc)", I_8)                       \
+	X(9, "v_cndmask_b32 (VOP3, SGPR-pair condition)", I_9)    \
+	X(10, "v_cmp_eq_u32 -> vcc (VOPC)", I_10)                          \
+	X(11, "v_cmp_eq_u32 -> SGPR pair (VOP3)", I_11)           \
+	X(12, "v_max_u32_dpp row_shr:1", I_12) \
+	X(13, "v_max_u32_dpp row_bcast:15", I_13) \
+	X(14, "v_mov_b32_dpp wave_shr:1", I_14) \
+	X(15, "v_add_u32_dpp row_shr:2", I_15) \
+	X(16, "v_readlane_b32 (to SGPR)", I_16)                          \
+	X(17, "v_writelane_b32", I_17)                                    \
+	X(18, "v_readfirstlane_b32", I_18)                              \
+	X(19, "v_pk_max_u16 (VOP3P)", I_19)                                 \
+	X(20, "v_pk_add_u16 (VOP3P)", I_20)                                 \
+	X(21, "v_fma_f32 (VOP3)", I_21)                                    \
+	X(22, "v_pk_fma_f32 (VOP3P, 64-bit operands)", I_NONE)                                       \
+	X(23, "v_mul_lo_u32", I_23)                                         \
+	X(24, "v_mad_u32_u24", I_24)                                   \
+	X(25, "v_bcnt_u32_b32", I_25)                                     \
+	X(26, "v_mbcnt_lo_u32_b32", I_26)                             \
+	X(27, "v_lshlrev_b64", I_NONE)                                                               \
+	X(28, "v_add_co_u32 (carry out to vcc)", I_28)                 \
+	X(29, "v_perm_b32", I_29)                                         \
+	X(30, "v_alignbit_b32", I_30)                                  \
+	X(31, "v_mov_b32 (VOP1)", I_31)                                            \
+	X(32, "s_add_u32 (SALU)", I_NONE)                                                            \
+	X(33, "v_max_u32 + s_add_u32 alternating (8 + 8)", I_NONE)                                   \
+	X(34, "ds_bpermute_b32", I_NONE)                                                             \
+	X(35, "ds_read_b32 (lane-consecutive)", I_NONE)                                              \
+	X(36, "v_cmp_eq_u32 -> SGPR pair + v_cndmask_b32 on it (8 + 8)", I_NONE)                     \
+	X(37, "v_min_u32 (VOP2)", I_37)                                        \
+	X(38, "v_sub_u32 (VOP2)", I_38)                                        \
+	X(39, "v_or3_b32 (VOP3)", I_39)                                    \
+	X(40, "v_add3_u32 (VOP3)", I_40) \
+	X(41, "v_or_b32 (VOP2)", I_41) X(42, "v_xor_b32 (VOP2)", I_42) X(43, "v_lshrrev_b32 (VOP2, literal shift)", I_43) \
+	X(44, "v_max_f32 (VOP2)", I_44) X(45, "v_max_i32 (VOP2)", I_45) X(46, "v_add_f32 (VOP2)", I_46) X(47, "v_mul_f32 (VOP2)", I_47) \
+	X(48, "v_max_u16 (VOP2)", I_48) X(49, "v_add_u32_e64 (VOP3 encoding)", I_49) X(50, "v_add_u32 (VOP2, SGPR src0)", I_50) \
+	X(51, "v_cndmask_b32 (VOP2, vcc), dst != src", I_51) X(52, "v_cndmask_b32_e64 (VOP3) on vcc", I_52) \
+	X(53, "v_cmp_eq_u32 -> vcc + v_cndmask_b32 vcc (VOPC + VOP2, 16 + 16: cost per PAIR)", I_53) X(54, "v_addc_co_u32 (VOP2, vcc in and out)", I_54) \
+	X(55, "v_ashrrev_i32 (VOP2)", I_55) X(56, "v_mul_u32_u24 (VOP2)", I_56) X(57, "v_subrev_u32 (VOP2)", I_57) X(58, "v_not_b32 (VOP1)", I_58) \
+	X(59, "v_add_u32 (VOP2, 32-bit literal)", I_59) X(60, "v_lshlrev_b32 (VOP2, register shift)", I_60) X(61, "v_and_b32 (VOP2, inline constant)", I_61) \
+	X(62, "v_min_f32 (VOP2)", I_62) X(63, "v_max_i16 (VOP2)", I_63) X(64, "v_add_u16 (VOP2)", I_64) X(65, "v_sub_f32 (VOP2)", I_65) \
+	X(66, "v_sub_u32 (VOP2, inline constant)", I_66) X(67, "v_fmac_f32 (VOP2)", I_67) X(68, "v_max_u32_e64 (VOP3 encoding)", I_68) X(69, "v_and_b32_e64 (VOP3 encoding)", I_69) \
+	X(70, "v_cndmask_b32 vcc + v_add_u32 (16 + 16: cost per PAIR)", I_70) X(71, "v_cmp_eq_u32 -> vcc + v_add_u32 (16 + 16: cost per PAIR)", I_71) \
+	X(72, "v_cvt_f32_u32 (VOP1)", I_72) X(73, "v_add_u32_sdwa", I_73) X(74, "v_cndmask_b32_dpp vcc row_shr:1", I_74) X(75, "v_xad_u32 (VOP3)", I_75) \
+	X(76, "v_add_lshl_u32 (VOP3)", I_76) X(77, "v_lshl_or_b32 (VOP3)", I_77) X(78, "v_sad_u32 (VOP3)", I_78) X(79, "v_med3_u32 (VOP3)", I_79)
+
+template <int CLS>
+__global__ __launch_bounds__(1024) void k_rate(uint64_t *ticks, uint32_t *sink, uint32_t seed)
+{
+	__shared__ uint32_t lds[1024];
+	uint32_t r[16];
+#pragma unroll
+	for (int i = 0; i < 16; ++i) r[i] = threadIdx.x * 7u + i + seed;
+	uint32_t a = threadIdx.x ^ seed, b = (threadIdx.x << 3) | 1u, s = seed | 3u;
+	uint64_t cond = 0x5555AAAA3333CCCCull ^ seed;
+	cond = __builtin_amdgcn_readfirstlane((uint32_t) cond) | ((uint64_t) __builtin_amdgcn_readfirstlane((uint32_t) (cond >> 32)) << 32);
+	s = __builtin_amdgcn_readfirstlane(s);
+	lds[threadIdx.x] = a;
+	__syncthreads();
+	uint64_t const t0 = memtime();
+	for (int it = 0; it < REPS; ++it)
+	{
+		if constexpr (CLS == 22)
+		{
+			// v_pk_fma_f32 works on register pairs: 8 pairs, two rounds
+			uint64_t *q = reinterpret_cast<uint64_t *>(r);
+			uint64_t const aa = ((uint64_t) a << 32) | b;
+#pragma unroll
+			for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+				for (int i = 0; i < 8; ++i) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[i]) : "v"(aa));
+		}
+		else if constexpr (CLS == 27)
+		{
+			uint64_t *q = reinterpret_cast<uint64_t *>(r);
+#pragma unroll
+			for (int rep = 0; rep < 2; ++rep)
+#pragma unroll
+				for (int i = 0; i < 8; ++i) asm volatile("v_lshlrev_b64 %0, 1, %0" : "+v"(q[i]));
+		}
+		else if constexpr (CLS == 32)
+		{
+			uint32_t x0 = s, x1 = s + 1, x2 = s + 2, x3 = s + 3;
+#pragma unroll
+			for (int i = 0; i < 4; ++i)
+				asm volatile("s_add_u32 %0, %0, %4\n\ts_add_u32 %1, %1, %4\n\ts_add_u32 %2, %2, %4\n\ts_add_u32 %3, %3, %4"
+				             : "+s"(x0), "+s"(x1), "+s"(x2), "+s"(x3) : "s"(s) : "scc");
+			r[0] += x0 + x1 + x2 + x3;           // (one VALU per 16 SALU keeps the results alive)
+		}
+		else if constexpr (CLS == 33)
+		{
+#define I_MIX(R) "v_max_u32 " R ", " R ", %16\n\ts_add_u32 s20, s20, %18\n\t"
+			asm volatile(I_MIX("%0") I_MIX("%1") I_MIX("%2") I_MIX("%3") I_MIX("%4") I_MIX("%5") I_MIX("%6") I_MIX("%7")
+			             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
+			               "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+			             : "v"(a), "v"(b), "s"(s), "s"(cond) : "s20", "s21", "vcc", "scc");
+		}
+		else if constexpr (CLS == 34)
+		{
+#pragma unroll
+			for (int i = 0; i < 16; ++i) r[i] = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (b & 252u), (int) r[i]);
+		}
+		else if constexpr (CLS == 35)
+		{
+#pragma unroll
+			for (int i = 0; i < 16; ++i) r[i] += lds[(threadIdx.x + r[(i + 1) & 15]) & 1023u];
+		}
+		else if constexpr (CLS == 36)
+		{
+#define I_PAIR(R) "v_cmp_eq_u32_e64 s[20:21], " R ", %16\n\tv_cndmask_b32_e64 " R ", " R ", %17, s[20:21]\n\t"
+			asm volatile(I_PAIR("%0") I_PAIR("%1") I_PAIR("%2") I_PAIR("%3") I_PAIR("%4") I_PAIR("%5") I_PAIR("%6") I_PAIR("%7")
+			             : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]), "+v"(r[8]), "+v"(r[9]), "+v"(r[10]),
+			               "+v"(r[11]), "+v"(r[12]), "+v"(r[13]), "+v"(r[14]), "+v"(r[15])
+			             : "v"(a), "v"(b), "s"(s), "s"(cond) : "s20", "s21", "vcc");
+		}
+		else
+		{
+			switch (CLS)
+			{
+#define X(ID, NAME, I) case ID: { X16(I) } break;
+				CLASSES(X)
+#undef X
+			}
+		}
+	}
+	uint64_t const t1 = memtime();
+	uint32_t acc = 0;
+#pragma unroll
+	for (int i = 0; i < 16; ++i) acc ^= r[i];
+	if (acc == 0x12345u) sink[0] = acc;         // never true in practice: keeps the chain alive
+	if ((threadIdx.x & 63u) == 0) ticks[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+struct Row { int id; std::string name; double cyc[3], cyc_wall[3]; };
+
+template <int CLS>
+int run_class(char const *name, uint64_t *d_ticks, uint32_t *d_sink, int ncu, std::vector<Row> &rows)
+{
+	Row row;
+	row.id = CLS; row.name = name;
+	int const wps[3] = {1, 2, 4};
+	for (int k = 0; k < 3; ++k)
+	{
+		int const threads = wps[k] * 4 * 64;          // 4 SIMDs per CU
+		int const waves = ncu * wps[k] * 4;
+		hipEvent_t e0, e1;
+		CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+		hipLaunchKernelGGL(k_rate<CLS>, dim3(ncu), dim3(threads), 0, 0, d_ticks, d_sink, 1u);      // warm
+		CHECK(hipEventRecord(e0, 0));
+		hipLaunchKernelGGL(k_rate<CLS>, dim3(ncu), dim3(threads), 0, 0, d_ticks, d_sink, 2u);
+		CHECK(hipEventRecord(e1, 0));
+		CHECK(hipDeviceSynchronize());
+		float ms = 0;
+		CHECK(hipEventElapsedTime(&ms, e0, e1));
+		std::vector<uint64_t> t(waves);
+		CHECK(hipMemcpy(t.data(), d_ticks, waves * 8, hipMemcpyDeviceToHost));
+		std::sort(t.begin(), t.end());
+		double const worst = (double) t[waves - 1 - waves / 50];      // (98th percentile: a few waves start late)
+		double const instr = (double) REPS * 16;
+		row.cyc[k] = worst / (instr * wps[k]);
+		row.cyc_wall[k] = ms;                                       // kept as wall ms; priced below
+		(void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+	}
+	rows.push_back(row);
+	return 0;
+}
+
+int main(int argc, char **argv)
+{
+	int ncu = 0;
+	CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, 0));
+	uint64_t *d_ticks; uint32_t *d_sink;
+	CHECK(hipMalloc(&d_ticks, (size_t) ncu * 16 * 8));
+	CHECK(hipMalloc(&d_sink, 64));
+	std::vector<Row> rows;
+#define X(ID, NAME, I) if (run_class<ID>(NAME, d_ticks, d_sink, ncu, rows)) return 1;
+	CLASSES(X)
+#undef X
+	FILE *f = argc > 1 ? fopen(argv[1], "w") : stdout;
+	if (!f) { perror("open"); return 1; }
+	fprintf(f, "{\"device_cus\": %d, \"reps_x16\": %d, \"unit\": \"s_memtime ticks per wave-instruction per SIMD (98th-percentile wave)\",\n \"columns\": [\"1 wave/SIMD\", \"2 waves/SIMD\", \"4 waves/SIMD\"],\n \"classes\": [\n", ncu, REPS);
+	for (size_t i = 0; i < rows.size(); ++i)
+		fprintf(f, "  {\"id\": %d, \"class\": \"%s\", \"cycles\": [%.2f, %.2f, %.2f], \"wall_ms\": [%.4f, %.4f, %.4f]}%s\n", rows[i].id, rows[i].name.c_str(),
+		        rows[i].cyc[0], rows[i].cyc[1], rows[i].cyc[2], rows[i].cyc_wall[0], rows[i].cyc_wall[1], rows[i].cyc_wall[2], i + 1 < rows.size() ? "," : "");
+	fprintf(f, " ]}\n");
+	if (f != stdout) fclose(f);
+	for (auto const &r : rows) printf("%-58s %6.2f %6.2f %6.2f\n", r.name.c_str(), r.cyc[0], r.cyc[1], r.cyc[2]);
+	return 0;
+}
