@@ -5,8 +5,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "fseq_api.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("fseq_kernels.hpp", "fseq_dp.hpp", "fseq_dpspec.hpp", "fseq_blockkeys.hpp", "fseq_core.hpp", "fseq_stream.hpp", "fseq_join.hpp")] \
-    + [os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
+import glob
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
 OUT = os.path.join(HERE, "libfseq_hip.so")
 
 

@@ -10,6 +10,7 @@
 #include "fseq_dp.hpp"
 #include "fseq_dpspec.hpp"
 #include "fseq_stream.hpp"
+#include "fseq_stream2.hpp"
 #include "fseq_blockkeys.hpp"
 #include "fseq_rowshard.hpp"
 #include "fseq_join.hpp"
@@ -227,6 +228,30 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 #endif
 constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column list capacity tried (the estimate and the retries raise it)
 
+// phase C, streamed rows, second form (fseq_stream2.hpp): <threads, rows per thread>
+#define FSEQ_S2_CONFIGS(X) X(512, 8) X(1024, 4) X(1024, 6) X(1024, 8) X(512, 12)
+struct Stream2Config { uint32_t T, E, key_shift; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
+	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
+	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t); };
+template <int T, int E>
+struct LaunchS2 {
+	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E>(colbytes); }
+	static hipError_t prepare(size_t bytes) { return allow_lds(k_columns_stream2<T, E>, bytes); }
+	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
+	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch)
+	{
+		hipLaunchKernelGGL((k_columns_stream2<T, E>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch);
+	}
+	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), &lds, &prepare, &launch}; }
+};
+bool select_stream2(uint32_t T, uint32_t E, Stream2Config *out)
+{
+#define X(T_, E_) if (T == T_ && E == E_) { *out = LaunchS2<T_, E_>::make(); return true; }
+	FSEQ_S2_CONFIGS(X)
+#undef X
+	return false;
+}
+
 double now_ms()
 {
 	using namespace std::chrono;
@@ -280,6 +305,8 @@ struct fseq_ctx {
 
 	// geometry
 	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
+	Stream2Config s2{};                      // streamed phase C, second form (T = 0: not in use)
+	size_t s2_lds = 0;
 	bool stream_staged = false;              // streamed kernels lay tiles out in LDS before writing them (needs 64 KiB more)
 	uint32_t bsh = 0;                        // alignment packing: 8 >> bsh bits per symbol (fseq_kernels.hpp sym_bytes)
 	KernelSet ks{};
@@ -545,6 +572,26 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_columns_stream<19>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream<0>, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
+		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
+		// (FSEQ_STREAM2=T,E picks another configuration, FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
+		c->s2 = Stream2Config{};
+		{
+			uint32_t T2 = 512, E2 = 8;
+			char const *e = getenv("FSEQ_STREAM2");
+			bool off = getenv("FSEQ_STREAM_PLAIN_SCAN") != nullptr;
+			if (e && sscanf(e, "%u,%u", &T2, &E2) < 2) off = true;
+			Stream2Config cfg;
+			if (!off && select_stream2(T2, E2, &cfg) && (uint64_t) p.m + c->B < (1ull << cfg.key_shift) && c->stream_staged)
+			{
+				size_t const bytes = cfg.lds(sym_bytes(p.m, c->bsh));
+				if (bytes <= LDS_LIMIT)
+				{
+					HIP_TRY(c, cfg.prepare(bytes));
+					HIP_TRY(c, allow_lds(k_columns_stream2_prologue, stream_lds_bytes(0, true)));
+					c->s2 = cfg; c->s2_lds = bytes;
+				}
+			}
+		}
 		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
 		c->bk_cap_words = 12288;                               // two bitmaps + 32-bit prefix counts: 12 B per word
 		if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) c->bk_cap_words = (uint32_t) std::max(2048, atoi(e));
@@ -1435,7 +1482,13 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
 		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
-			if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !getenv("FSEQ_STREAM_PLAIN_SCAN"))
+			if (c->use_stream && c->s2.T)
+			{
+				hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0);
+				c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
+				             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+			}
+			else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !getenv("FSEQ_STREAM_PLAIN_SCAN"))
 				hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
 				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
 			else if (c->use_stream)

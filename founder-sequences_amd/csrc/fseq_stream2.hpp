@@ -1,0 +1,598 @@
+// fseq_stream2.hpp -- phase C for orders that do not fit LDS (m > 11,264 rows), second form.
+//
+// Same algorithm and outputs as k_columns_stream (fseq_stream.hpp): the order of a block lives in a per-block
+// HBM/L2 workspace and every column pass streams it through the workgroup tile by tile with a running TileCarry.
+// What changed is the tile step, rebuilt around what profiles/r03_valu_rates.* and the round-2 counters showed (the
+// old step issues ~490 vector instructions per thread and tile of 4 rows -- 122 per cell, ~70 % of the SIMDs' issue
+// time at 4.2 cycles each -- among them 170 v_readlane / 70 v_writelane of spilled SGPRs, 145 64-bit address
+// computations and flat_ (not global_) memory instructions):
+//   * (a, d) of a row are ONE 8-byte pair in the workspace: one 16-byte load per two rows, one 8-byte LDS write
+//     and one 8-byte store per row, one address each;
+//   * T threads x E consecutive rows with E = 8 (fewer, longer threads: the scan and its second level over the
+//     waves cost the same per thread whatever E is);
+//   * loads and stores are buffer instructions on a descriptor of the workspace (uniform base + 32-bit offset:
+//     no per-lane 64-bit address arithmetic; rows behind m of the last tile read as zero);
+//   * the destination of a row is resolved in TILE-LOCAL coordinates: tile-local bucket start + rows of the
+//     bucket in front (13 bits) and the prefix maximum (value ids < 2^KS) share a word, so one select tree per
+//     row yields both, and the write-out takes the bucket of 64 consecutive output slots from scalar compares
+//     (a wave's 64 slots straddle a bucket boundary in at most 3 of a tile's T * E / 64 stores);
+//   * the next tile's rows are loaded into registers before the write-out of this one (the old form touched
+//     them into L2 through an LDS-DMA sink); barriers inside a column wait for LDS only, two per tile;
+//   * first_val (the id of the new column) is the largest id there is, so "first of its bucket" needs no select:
+//     the prefix maximum of a bucket nobody has seen is first_val itself.
+// The prologue of a block (sort of the boundary divergences -> value ids) stays the old code, as its own kernel.
+#pragma once
+
+#include "fseq_stream.hpp"
+
+namespace fseq {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(void const *p, uint32_t bytes)
+{
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int) bytes, 0x00020000);
+}
+
+// barrier that waits for this wave's LDS traffic only (loads of the next tile stay in flight across it)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// key = (rows of the bucket up to and including me, inside the tile) << KS | running maximum: the count of a tile of
+// `tile` rows must fit above the shift
+constexpr int s2_key_shift(int tile)
+{
+	int bits = 0;
+	while ((1ll << bits) <= (long long) tile) ++bits;
+	return 32 - bits;
+}
+
+// -DFSEQ_S2_SKIP=bits: timing experiments (results are wrong): 1 no write-out stores, 2 no histogram atomics, 4 no list,
+// 8 no tile loads (the first tile's rows are reused), 16 no LDS staging
+#ifndef FSEQ_S2_SKIP
+#define FSEQ_S2_SKIP 0
+#endif
+// -DFSEQ_S2_STAMPS: per-wave cycle stamps of the tile loop (diagnostic build), printed for two blocks
+#ifdef FSEQ_S2_STAMPS
+#define S2_STAMP(i) do { long long const t_ = clock64(); s2_seg[i] += t_ - s2_last; s2_last = t_; } while (0)
+#else
+#define S2_STAMP(i) do { } while (0)
+#endif
+
+template <int T>
+struct S2Lds {
+	uint32_t cnt[T / WAVE][2];
+	uint32_t val[T / WAVE][4];
+	uint32_t red[4 * (T / WAVE) + 8];
+};
+
+template <int T, int E>
+__host__ __device__ inline size_t stream2_lds_bytes(uint32_t colbytes)
+{
+	return carve_bytes((size_t) colbytes + 16, 1) + carve_bytes(1, sizeof(S2Lds<T>)) + carve_bytes((size_t) T * E, 8);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Prologue of every block (the old kernel's, on its own): sorted distinct boundary divergences -> V, their
+// counts -> cnt, the order as (a, value id) pairs -> pairs0, D0 -> w[9m + B].  ST threads.
+// Workspace (words): pairs0 2m | pairs1 2m | keys 2m | V m | Vpos m | cnt m + B | D0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
+	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	StreamLds &L = *cv.take<StreamLds>(1);
+	uint32_t *const stage = cv.take<uint32_t>(2 * (size_t) SCAP);
+	uint32_t const tid = threadIdx.x;
+	uint32_t const blk = blockIdx.x + block0;
+	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
+	uint2 *pairs0 = reinterpret_cast<uint2 *>(w);
+	uint32_t *keys[2] = {w + 4u * (size_t) m, w + 5u * (size_t) m};
+	uint32_t *V = w + 6u * (size_t) m, *Vpos = w + 7u * (size_t) m, *cnt = w + 8u * (size_t) m;
+	uint64_t const k0 = (uint64_t) blk * B;
+	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
+	uint32_t const nb = (uint32_t) (kend - k0);
+	uint32_t const *sa = bstate_a + (size_t) blk * m, *sd = bstate_d + (size_t) blk * m;
+
+	for (uint32_t i = tid; i < m; i += ST) keys[0][i] = sd[i];
+	__syncthreads();
+	uint32_t kc = 0;
+	{
+		uint32_t bits = 1;
+		while (bits < 32u && (k0 >> bits) != 0) ++bits;          // divergences at the boundary are <= k0
+		for (uint32_t sh = 0; sh < bits; sh += 2)
+		{
+			stream_pass<true>(m, keys[kc], nullptr, keys[kc ^ 1u], nullptr, 0u, DigitKey{sh}, NoHook{}, L, nullptr, stage);
+			kc ^= 1u;
+		}
+	}
+	uint32_t D0 = 0;
+	{
+		uint32_t const *sk = keys[kc];
+		for (uint32_t base = 0; base < m; base += SCAP)
+		{
+			uint32_t kv[SE], nf = 0;
+#pragma unroll
+			for (int e = 0; e < SE; ++e)
+			{
+				uint32_t const pos = base + tid * SE + e;
+				kv[e] = pos < m ? sk[pos] : 0u;
+				nf += (pos < m && (pos == 0 || kv[e] != sk[pos - 1u])) ? 1u : 0u;
+			}
+			uint32_t total;
+			uint32_t wv = D0 + block_excl_add<ST>(nf, L.red, &total);
+#pragma unroll
+			for (int e = 0; e < SE; ++e)
+			{
+				uint32_t const pos = base + tid * SE + e;
+				if (pos < m && (pos == 0 || kv[e] != sk[pos - 1u])) { V[wv] = kv[e]; Vpos[wv] = pos; ++wv; }
+			}
+			D0 += total;
+			__syncthreads();
+		}
+	}
+	for (uint32_t i = tid; i < D0 + nb; i += ST)
+		cnt[i] = i < D0 ? ((i + 1u < D0 ? Vpos[i + 1u] : m) - Vpos[i]) : 0u;
+	for (uint32_t i = tid; i < m; i += ST)
+	{
+		uint32_t lo = 0, hi = D0;
+		uint32_t const key = sd[i];
+		while (lo < hi)
+		{
+			uint32_t const mid = (lo + hi) >> 1;
+			if (V[mid] < key) lo = mid + 1; else hi = mid;
+		}
+		pairs0[i] = make_uint2(sa[i], lo);
+	}
+	if (tid == 0) w[9u * (size_t) m + B] = D0;
+}
+
+// block-wide sum of four counters (T threads); every thread gets the totals.  Two barriers.
+template <int T>
+__device__ __forceinline__ void s2_block_sum4(uint32_t (&c)[4], uint32_t *red)
+{
+	uint32_t const lane = lane_id(), wave = wave_id();
+#pragma unroll
+	for (int x = 0; x < 4; ++x) c[x] = readlane_u32(wave_incl_add(c[x]), 63);
+	__syncthreads();
+	if (lane == 0)
+#pragma unroll
+		for (int x = 0; x < 4; ++x) red[wave * 4 + x] = c[x];
+	__syncthreads();
+#pragma unroll
+	for (int x = 0; x < 4; ++x) c[x] = 0;
+#pragma unroll
+	for (int w = 0; w < T / WAVE; ++w)
+	{
+		uint4 const r = *reinterpret_cast<uint4 const *>(red + w * 4);
+		c[0] += r.x; c[1] += r.y; c[2] += r.z; c[3] += r.w;
+	}
+}
+
+// bucket sizes of a column pass straight off the staged packed column (as column_digit_counts, T threads)
+template <int T>
+__device__ __forceinline__ void s2_column_digit_counts(uint8_t const *sym, uint32_t m, uint32_t bsh, uint32_t pass, uint32_t (&cnt)[4], uint32_t *red)
+{
+#pragma unroll
+	for (int x = 0; x < 4; ++x) cnt[x] = 0;
+	uint32_t const spw = 4u << bsh, bits = 8u >> bsh;
+	uint32_t const nwords = (sym_bytes(m, bsh) + 3u) / 4u;
+	uint32_t const ones = bsh == 2 ? 0x55555555u : bsh == 1 ? 0x11111111u : 0x01010101u;
+	for (uint32_t wi = threadIdx.x; wi < nwords; wi += T)
+	{
+		uint32_t const w = *reinterpret_cast<uint32_t const *>(sym + wi * 4u);
+		uint32_t const r0 = wi * spw;
+		uint32_t const nv = min(spw, m - r0);
+		uint32_t const valid = nv == spw ? ones : (ones & ((1u << (nv * bits)) - 1u));
+		uint32_t const lo = (w >> (2u * pass)) & valid, hi = (w >> (2u * pass + 1u)) & valid;
+		cnt[0] += (uint32_t) __popc(valid & ~lo & ~hi);
+		cnt[1] += (uint32_t) __popc(lo & ~hi);
+		cnt[2] += (uint32_t) __popc(hi & ~lo);
+		cnt[3] += (uint32_t) __popc(lo & hi);
+	}
+	s2_block_sum4<T>(cnt, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// One tile: the stable 4-bucket partition of T * E consecutive rows of the order, in tile-local coordinates.
+// In: d[e] (value ids < 2^KS), s[e] (s = 4: no row at this position -- last tile only; its d is 0).
+// Out: lp[e] = slot of the row in the tile's output layout (the four bucket runs back to back), dnew[e];
+// lofs[x] = first slot of bucket x, gsh[x] = (global position of the tile's run of bucket x) - lofs[x]: both uniform.
+// first_val must be >= every value in the order (phase C: the id of the new column).  One LDS-only barrier.
+// ------------------------------------------------------------------------------------------------
+template <int T, int E, int KS, bool FULL>
+__device__ __forceinline__ void s2_tile_step(
+	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val, S2Lds<T> &L, TileCarry &tc,
+	uint32_t (&lp)[E], uint32_t (&dnew)[E], uint32_t (&lofs)[4], uint32_t (&gsh)[4]
+#ifdef FSEQ_S2_STAMPS
+	, long long (&s2_seg)[12], long long &s2_last
+#endif
+	)
+{
+	constexpr int NW = T / WAVE;
+	constexpr uint32_t VMASK = (1u << KS) - 1u;
+	static_assert(E <= 15, "local counts are nibble-packed");
+	static_assert(NW >= 2 && NW <= 16, "wave totals fit one DPP row");
+	static_assert((uint64_t) T * E < (1ull << (32 - KS)), "counts of one tile must fit the key");
+	uint32_t const lane = lane_id();
+	uint32_t const wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+	// ---- the thread's own rows: running maximum per symbol since its last row, rank of a row among the thread's
+	// rows of its symbol (nibble counters; position without a row: fifth nibble)
+	uint32_t run[4] = {0u, 0u, 0u, 0u};
+	uint32_t lcp = 0, pend = 0;
+	uint32_t lidx[E];
+#pragma unroll
+	for (int e = 0; e < E; ++e)
+	{
+		uint32_t const c = s[e];
+		uint32_t const de = d[e];
+		uint32_t o = 0;
+#pragma unroll
+		for (int x = 0; x < 4; ++x)
+		{
+			uint32_t const r = max(run[x], de);
+			bool const is = (c == (uint32_t) x);
+			o = is ? r : o;
+			run[x] = is ? 0u : r;
+		}
+		dnew[e] = o;
+		asm volatile("" : "+v"(dnew[e]));                       // (selected here, not behind the barrier: fseq_core.hpp)
+		uint32_t const sh = c * 4u;
+		lidx[e] = (lcp >> sh) & 15u;
+		pend |= ((FULL || c < 4u) && lidx[e] == 0u) ? (1u << e) : 0u;
+		lcp += 1u << sh;
+	}
+
+	// ---- bucket counts, inclusive over the lanes (two 16-bit counts per word), then the keys
+	uint32_t ic[2];
+	ic[0] = wave_incl_add((lcp & 15u) | (((lcp >> 4) & 15u) << 16));
+	ic[1] = wave_incl_add(((lcp >> 8) & 15u) | (((lcp >> 12) & 15u) << 16));
+	auto occ_key = [](uint32_t const (&c)[2], int x) -> uint32_t {
+		return (x & 1) ? ((c[x >> 1] >> 16) << KS) : ((c[x >> 1] & 0xFFFFu) << KS);
+	};
+	uint32_t key[4];
+#pragma unroll
+	for (int x = 0; x < 4; ++x) key[x] = wave_incl_max(occ_key(ic, x) | run[x]);
+	if (lane == 63)
+	{
+		L.cnt[wave][0] = ic[0]; L.cnt[wave][1] = ic[1];
+#pragma unroll
+		for (int x = 0; x < 4; ++x) L.val[wave][x] = key[x] & VMASK;
+	}
+	uint32_t ek[4];
+#pragma unroll
+	for (int x = 0; x < 4; ++x) ek[x] = dpp_mov<DPP_WAVE_SHR1, 0xF>(0u, key[x]);
+	S2_STAMP(1);
+	lds_barrier();
+	S2_STAMP(2);
+
+	// ---- second level over the NW wave totals (lanes 0 .. NW-1 of DPP row 0), every wave for itself
+	uint32_t wc[2], wk[4];
+#pragma unroll
+	for (int i = 0; i < 2; ++i) wc[i] = lane < (uint32_t) NW ? L.cnt[lane][i] : 0u;
+#pragma unroll
+	for (int x = 0; x < 4; ++x) wk[x] = lane < (uint32_t) NW ? L.val[lane][x] : 0u;
+#pragma unroll
+	for (int i = 0; i < 2; ++i)
+	{
+		wc[i] += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, wc[i]);
+		if (NW > 2) wc[i] += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, wc[i]);
+		if (NW > 4) wc[i] += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, wc[i]);
+		if (NW > 8) wc[i] += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, wc[i]);
+	}
+#pragma unroll
+	for (int x = 0; x < 4; ++x)
+	{
+		uint32_t k = occ_key(wc, x) | wk[x];
+		k = max(k, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, k));
+		if (NW > 2) k = max(k, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, k));
+		if (NW > 4) k = max(k, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, k));
+		if (NW > 8) k = max(k, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, k));
+		wk[x] = k;
+	}
+	uint32_t totc[2], totk[4], pc[2] = {0u, 0u}, pk[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+	for (int i = 0; i < 2; ++i) totc[i] = readlane_u32(wc[i], NW - 1);
+#pragma unroll
+	for (int x = 0; x < 4; ++x) totk[x] = readlane_u32(wk[x], NW - 1);
+	if (wave > 0)
+	{
+		int const src = (int) wave - 1;
+#pragma unroll
+		for (int i = 0; i < 2; ++i) pc[i] = readlane_u32(wc[i], src);
+#pragma unroll
+		for (int x = 0; x < 4; ++x) pk[x] = readlane_u32(wk[x], src);
+	}
+
+	// ---- per bucket: tile-local start, rows in front of this thread, prefix maximum -- one word
+	uint32_t pv[4];
+	{
+		uint32_t acc = 0;
+#pragma unroll
+		for (int x = 0; x < 4; ++x)
+		{
+			uint32_t const tot = (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+			lofs[x] = acc;
+			gsh[x] = tc.start[x] + tc.cnt[x] - acc;
+			uint32_t const k = max(pk[x], ek[x] + occ_key(pc, x));
+			// nobody in front of me inside the tile: the tiles to the left decide (and if they never saw the bucket
+			// either, its first row takes first_val, which is >= every other value)
+			uint32_t const left = ((tc.has >> x) & 1u) ? tc.val[x] : first_val;
+			uint32_t const low = (k >> KS) ? 0u : left;
+			pv[x] = max(k, (k & ~VMASK) | low) + (acc << KS);
+			acc += tot;
+			// the carry moves past this tile
+			tc.cnt[x] += tot;
+			tc.val[x] = (totk[x] >> KS) ? (totk[x] & VMASK) : max(tc.val[x], totk[x] & VMASK);
+			tc.has |= (totk[x] >> KS) ? (1u << x) : 0u;
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < E; ++e)
+	{
+		uint32_t const c = s[e];
+		bool const b0 = c & 1u, b1 = c & 2u;
+		uint32_t const lo2 = b0 ? pv[1] : pv[0], hi2 = b0 ? pv[3] : pv[2];
+		uint32_t const sel = b1 ? hi2 : lo2;
+		lp[e] = (sel >> KS) + lidx[e];
+		if ((pend >> e) & 1u) dnew[e] = max(sel & VMASK, dnew[e]);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase C, streamed, second form.  After k_columns_stream2_prologue on the same blocks.
+// ------------------------------------------------------------------------------------------------
+template <int T, int E>
+__global__ __launch_bounds__(T) void k_columns_stream2(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
+	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
+	uint32_t *done_host, uint32_t epoch)
+{
+	constexpr int KS = s2_key_shift(T * E);
+	constexpr uint32_t TILE = (uint32_t) T * E;
+	static_assert(E % 2 == 0, "a thread loads its rows as 16-byte pieces of two (a, d) pairs");
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	uint8_t *sym = cv.take<uint8_t>((size_t) sym_bytes(m, bsh) + 16);
+	S2Lds<T> &L = *cv.take<S2Lds<T>>(1);
+	uint2 *const stage = cv.take<uint2>(TILE);
+	uint32_t const tid = threadIdx.x;
+	uint32_t const lane = lane_id();
+	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	uint32_t const blk = blockIdx.x + block0;
+	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
+	uint2 *pairs[2] = {reinterpret_cast<uint2 *>(w), reinterpret_cast<uint2 *>(w + 2u * (size_t) m)};
+	uint32_t const *V = w + 6u * (size_t) m;
+	uint32_t *cnt = w + 8u * (size_t) m;
+	uint32_t const D0 = __builtin_amdgcn_readfirstlane(w[9u * (size_t) m + B]);
+
+	uint64_t const k0 = (uint64_t) blk * B;
+	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
+	uint32_t const nb = (uint32_t) (kend - k0);
+	bool const zero_present = (V[0] == 0u);
+	uint32_t const colbytes = sym_bytes(m, bsh);
+	uint32_t cur = 0;
+#ifdef FSEQ_S2_STAMPS
+	long long s2_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s2_last = clock64();
+#endif
+
+	for (uint32_t j = 0; j < nb; ++j)
+	{
+		{
+			uint8_t const *col = msa + (k0 + j) * ld;
+			for (uint32_t i = tid * 16u; i < colbytes; i += T * 16u)
+				*reinterpret_cast<uint4 *>(sym + i) = *reinterpret_cast<uint4 const *>(col + i);
+		}
+		__syncthreads();
+		S2_STAMP(11);
+		for (uint32_t pass = 0; pass < npass; ++pass)
+		{
+			uint32_t cnt4[4];
+			s2_column_digit_counts<T>(sym, m, bsh, pass, cnt4, L.red);
+#pragma unroll
+			for (int x = 0; x < 4; ++x) cnt4[x] = __builtin_amdgcn_readfirstlane(cnt4[x]);      // (sums read from LDS: uniform, but not to the compiler)
+			TileCarry tc;
+			{
+				uint32_t acc = 0;
+#pragma unroll
+				for (int x = 0; x < 4; ++x) { tc.cnt[x] = 0; tc.val[x] = 0; tc.start[x] = acc; acc += cnt4[x]; }
+				tc.has = 0;
+			}
+			__amdgpu_buffer_rsrc_t const rs = make_rsrc(pairs[cur], m * 8u), rd = make_rsrc(pairs[cur ^ 1u], m * 8u);
+			uint32_t const first_val = D0 + j;
+			uint32_t const toff = tid * (uint32_t) (E * 8);          // byte offset of the thread's rows inside a tile
+			// rows of the tile at `base` (rows behind m read as zero)
+			uint32_t an[E], dn[E];
+			auto load_tile = [&](uint32_t base) {
+#pragma unroll
+				for (int q = 0; q < E / 2; ++q)
+				{
+					u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16u * q, base * 8u, 0);
+					an[2 * q] = v.x; dn[2 * q] = v.y; an[2 * q + 1] = v.z; dn[2 * q + 1] = v.w;
+				}
+			};
+			auto tile = [&](uint32_t base, auto full_tag) {
+				constexpr bool FULL = decltype(full_tag)::value;
+				uint32_t a[E], d[E], s[E], lp[E], dnew[E], lofs[4], gsh[4];
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					a[e] = an[e]; d[e] = dn[e];
+					s[e] = (FULL || base + tid * E + e < m) ? sym_digit(sym, a[e], bsh, pass) : 4u;
+				}
+				// the next tile's rows on their way while this one is partitioned, staged and written out (issued last thing
+				// before the write-out, they were 5 of 21 ms of the C4 prefix: all waves of the workgroup wait for them together)
+				if (FULL && base + TILE < m && !(FSEQ_S2_SKIP & 8)) load_tile(base + TILE);
+				S2_STAMP(0);
+#ifdef FSEQ_S2_STAMPS
+				s2_tile_step<T, E, KS, FULL>(d, s, first_val, L, tc, lp, dnew, lofs, gsh, s2_seg, s2_last);
+#else
+				s2_tile_step<T, E, KS, FULL>(d, s, first_val, L, tc, lp, dnew, lofs, gsh);
+#endif
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					if (FULL || base + tid * E + e < m)
+					{
+						if (!(FSEQ_S2_SKIP & 16)) stage[lp[e]] = make_uint2(a[e], dnew[e]);
+						if (!(FSEQ_S2_SKIP & 2) && d[e] != dnew[e])
+						{
+							(void) __hip_atomic_fetch_add(&cnt[d[e]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+							(void) __hip_atomic_fetch_add(&cnt[dnew[e]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						}
+					}
+				}
+				S2_STAMP(3);
+				lds_barrier();
+				S2_STAMP(4);
+				uint32_t const tile_n = FULL ? TILE : m - base;
+				// Output slots go out in groups of 128 (one 16-byte store per lane: the memory pipeline of a CU, ~10 bytes per
+				// cycle, takes wide stores at twice the rate of 8-byte ones).  gb[x] = first group that lies entirely behind the
+				// start of bucket x; a group that holds a bucket start strictly inside it takes the per-slot path.
+				auto ge = [](uint32_t j, uint32_t l) -> uint32_t { return (l - 1u - j) >> 31; };      // j >= l as 0 / 1 (both < 2^31)
+				uint32_t const gb1 = (lofs[1] + 127u) >> 7, gb2 = (lofs[2] + 127u) >> 7, gb3 = (lofs[3] + 127u) >> 7;
+				uint32_t const sg1 = (lofs[1] & 127u) ? (lofs[1] >> 7) : 0xFFFFFFFFu, sg2 = (lofs[2] & 127u) ? (lofs[2] >> 7) : 0xFFFFFFFFu,
+				               sg3 = (lofs[3] & 127u) ? (lofs[3] >> 7) : 0xFFFFFFFFu;
+#pragma unroll
+				for (int e = 0; e < E / 2; ++e)
+				{
+					uint32_t const g = (uint32_t) e * (T / WAVE) + wave;      // this store's group of 128 output slots: uniform
+					uint32_t const j0 = g * 128u;
+					if (!FULL && j0 >= tile_n) break;
+					uint4 const v = *reinterpret_cast<uint4 const *>(stage + j0 + 2u * lane);
+					if (FULL && g != sg1 && g != sg2 && g != sg3)
+					{
+						uint32_t sh = gsh[0];
+						sh = ge(g, gb1) ? gsh[1] : sh;
+						sh = ge(g, gb2) ? gsh[2] : sh;
+						sh = ge(g, gb3) ? gsh[3] : sh;
+						u32x4 const vv = {v.x, v.y, v.z, v.w};
+						if (!(FSEQ_S2_SKIP & 1))
+						__builtin_amdgcn_raw_buffer_store_b128(vv, rd, lane * 16u, (j0 + sh) * 8u, 0);
+					}
+					else
+					{
+#pragma unroll
+						for (int h = 0; h < 2; ++h)
+						{
+							uint32_t const jj = j0 + 2u * lane + (uint32_t) h;
+							uint32_t sh = gsh[0];
+							sh = jj >= lofs[1] ? gsh[1] : sh;
+							sh = jj >= lofs[2] ? gsh[2] : sh;
+							sh = jj >= lofs[3] ? gsh[3] : sh;
+							u32x2 const vv = {h ? v.z : v.x, h ? v.w : v.y};
+							if (FULL || jj < tile_n)
+								__builtin_amdgcn_raw_buffer_store_b64(vv, rd, (jj + sh) * 8u, 0u, 0);
+						}
+					}
+				}
+				S2_STAMP(5);
+				// (no barrier here: the next tile's stage writes come behind its own barrier, which every wave reaches only
+				// after its reads above; the scan scratch is rewritten only by waves that have passed the barrier above)
+			};
+			uint32_t base = 0;
+			load_tile(0);
+			S2_STAMP(6);
+			for (; base + TILE <= m; base += TILE) tile(base, std::true_type{});
+			if (base < m) tile(base, std::false_type{});
+			cur ^= 1u;
+			__syncthreads();
+			S2_STAMP(7);
+		}
+		uint2 const *P = pairs[cur];
+		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
+		if (ss_a && (k0 + j + 1) % snap_stride == 0)
+		{
+			size_t const ob = (size_t) ((k0 + j + 1) / snap_stride) * m;
+			for (uint32_t i = tid; i < m; i += T)
+			{
+				uint2 const p = P[i];
+				ss_a[ob + i] = p.x;
+				ss_d[ob + i] = p.y < D0 ? V[p.y] : (uint32_t) (k0 + (p.y - D0) + 1u);
+			}
+		}
+		S2_STAMP(8);
+		// ---- emit the top of the histogram (same list format as k_columns); counters were updated
+		// with device-scope atomics, read them past L1
+		if (wave == 0 && !(FSEQ_S2_SKIP & 4))
+		{
+			// LQ ids per lane and step (the id space is sparse -- one id per column and boundary value, most of them with
+			// count 0 by now -- and every step is a round trip to L2: with one id per lane the list was ~20 % of a column)
+			constexpr int LQ = 8;
+			uint64_t const k = k0 + j;
+			uint32_t const thr = (k + 2 > (uint64_t) Lseg) ? (uint32_t) (k + 2 - Lseg) : 0u;
+			uint2 *out = ent + k * (size_t) stride;
+			int32_t const top = (int32_t) (D0 + j);
+			uint32_t cumN = 0, nent = 1, R = 0;       // cumN: count of the values below thr taken so far
+			for (int32_t base = top; base >= 0; base -= 64 * LQ)
+			{
+				// lane l holds the ids base - LQ l - q: descending ids = descending values, lane-major
+				uint32_t c[LQ], v[LQ];
+				uint32_t lane_c = 0, lane_o = 0, lane_rc = 0, candm = 0;
+#pragma unroll
+				for (int q = 0; q < LQ; ++q)
+				{
+					int32_t const i = base - LQ * (int32_t) lane - q;
+					c[q] = (i >= 0) ? __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+					v[q] = (i < 0) ? 0u : (((uint32_t) i < D0) ? V[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
+				}
+#pragma unroll
+				for (int q = 0; q < LQ; ++q)
+				{
+					bool const nz = c[q] > 0;
+					bool const rec = nz && v[q] >= thr;       // the values >= thr are a prefix of the non-zero entries
+					candm |= (nz && !rec) ? (1u << q) : 0u;
+					lane_c += c[q];
+					lane_o += (nz && !rec) ? 1u : 0u;
+					lane_rc += rec ? c[q] : 0u;
+				}
+				uint32_t const inc_c = wave_incl_add(lane_c), inc_o = wave_incl_add(lane_o);
+				uint32_t const r_tot = readlane_u32(wave_incl_add(lane_rc), 63);
+				uint32_t const tot_o = readlane_u32(inc_o, 63);
+				uint32_t run_c = inc_c - lane_c;          // counts in front of this lane's entries
+				uint32_t run_o = inc_o - lane_o;          // candidates in front of them
+				uint32_t lastP = 0, ntk = 0;
+#pragma unroll
+				for (int q = 0; q < LQ; ++q)
+				{
+					// a candidate is taken while the below-thr counts in front of it do not exceed X
+					uint32_t const excN = cumN + run_c - r_tot;
+					bool const cand = (candm >> q) & 1u;
+					bool const tk = cand && excN <= X;
+					if (tk) { out[nent + run_o] = make_uint2(v[q], c[q]); lastP = excN + c[q]; ++ntk; }
+					run_o += cand ? 1u : 0u;
+					run_c += c[q];
+				}
+				uint32_t const taken = readlane_u32(wave_incl_add(ntk), 63);
+				// the taken entries are a prefix of the candidates: the largest inclusive count among them is the new cumN
+				uint32_t const mx = readlane_u32(wave_incl_max(lastP), 63);
+				nent += taken;
+				if (taken) cumN = mx;
+				R += r_tot;
+				if (taken != tot_o || cumN > X) break;
+			}
+			uint32_t const cum = R + cumN;
+			if (lane == 0)
+			{
+				uint32_t const c0 = zero_present ? __hip_atomic_load(&cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+				out[0] = make_uint2((uint32_t) (k + 1), R);
+				hdr[k] = make_uint4(nent, c0, cum == m ? 1u : 0u, cum);
+			}
+		}
+		S2_STAMP(9);
+		__syncthreads();
+		S2_STAMP(10);
+	}
+#ifdef FSEQ_S2_STAMPS
+	if (lane == 0 && (blockIdx.x == 7 || blockIdx.x == 200) && nb)
+		printf("s2 stamps block %u wave %2u, cycles per column: loads+symbols %lld | own rows+scan %lld | barrier A %lld | resolve+stage+hook %lld | barrier B %lld | "
+		       "write-out %lld | counts + first load %lld | pass tail barrier %lld | snapshot %lld | list %lld | column end barrier %lld | column staged %lld\n", blockIdx.x, wave,
+		       s2_seg[0] / nb, s2_seg[1] / nb, s2_seg[2] / nb, s2_seg[3] / nb, s2_seg[4] / nb, s2_seg[5] / nb, s2_seg[6] / nb, s2_seg[7] / nb, s2_seg[8] / nb, s2_seg[9] / nb, s2_seg[10] / nb, s2_seg[11] / nb);
+#endif
+	publish_block_done(done_host, blk, epoch);
+}
+
+} // namespace fseq
