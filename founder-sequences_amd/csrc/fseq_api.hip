@@ -228,25 +228,25 @@ constexpr size_t LDS_LIMIT = 160 * 1024;
 #endif
 constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column list capacity tried (the estimate and the retries raise it)
 
-// phase C, streamed rows, second form (fseq_stream2.hpp): <threads, rows per thread>
-#define FSEQ_S2_CONFIGS(X) X(512, 8) X(1024, 4) X(1024, 6) X(1024, 8) X(512, 12)
-struct Stream2Config { uint32_t T, E, key_shift; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
+// phase C, streamed rows, second form (fseq_stream2.hpp): <threads, rows per thread, 5-byte rows>
+#define FSEQ_S2_CONFIGS(X) X(512, 8, true) X(1024, 4, true) X(1024, 8, true) X(256, 8, true) X(256, 12, true) X(512, 8, false) X(1024, 6, false) X(1024, 8, false) X(256, 8, false) X(256, 12, false)
+struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
 	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
-	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t); };
-template <int T, int E>
+	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t); };
+template <int T, int E, bool PACK>
 struct LaunchS2 {
-	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E>(colbytes); }
-	static hipError_t prepare(size_t bytes) { return allow_lds(k_columns_stream2<T, E>, bytes); }
+	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E, PACK>(colbytes); }
+	static hipError_t prepare(size_t bytes) { return allow_lds(k_columns_stream2<T, E, PACK>, bytes); }
 	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
-	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch)
+	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch, uint32_t ss_pack)
 	{
-		hipLaunchKernelGGL((k_columns_stream2<T, E>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch);
+		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack);
 	}
-	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), &lds, &prepare, &launch}; }
+	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch}; }
 };
-bool select_stream2(uint32_t T, uint32_t E, Stream2Config *out)
+bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out)
 {
-#define X(T_, E_) if (T == T_ && E == E_) { *out = LaunchS2<T_, E_>::make(); return true; }
+#define X(T_, E_, P_) if (T == T_ && E == E_ && (pack != 0) == P_) { *out = LaunchS2<T_, E_, P_>::make(); return true; }
 	FSEQ_S2_CONFIGS(X)
 #undef X
 	return false;
@@ -348,6 +348,7 @@ struct fseq_ctx {
 	size_t src_cap = 0;
 	uint32_t snap_stride = 16;            // phase C drops the exact (a,d) every snap_stride columns for pass 2
 	uint32_t *d_ss_a = nullptr, *d_ss_d = nullptr;
+	uint32_t ss_pack = 0;                 // streamed rows: stride states packed to 5 bytes per row (bits of a row id; fseq_stream.hpp)
 	uint2 *d_gent = nullptr;
 	uint4 *d_ghdr = nullptr;
 	size_t gather_cap = 0, gather_stride = 0;
@@ -573,15 +574,15 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_columns_stream<0>, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
 		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
-		// (FSEQ_STREAM2=T,E picks another configuration, FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
+		// (FSEQ_STREAM2=T,E[,0] picks another configuration [8-byte rows], FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
 		c->s2 = Stream2Config{};
 		{
-			uint32_t T2 = 512, E2 = 8;
+			uint32_t T2 = 512, E2 = 8, P2 = 1;
 			char const *e = getenv("FSEQ_STREAM2");
 			bool off = getenv("FSEQ_STREAM_PLAIN_SCAN") != nullptr;
-			if (e && sscanf(e, "%u,%u", &T2, &E2) < 2) off = true;
+			if (e && sscanf(e, "%u,%u,%u", &T2, &E2, &P2) < 2) off = true;
 			Stream2Config cfg;
-			if (!off && select_stream2(T2, E2, &cfg) && (uint64_t) p.m + c->B < (1ull << cfg.key_shift) && c->stream_staged)
+			if (!off && select_stream2(T2, E2, P2, &cfg) && (uint64_t) p.m + c->B < (1ull << cfg.key_shift) && c->stream_staged)
 			{
 				size_t const bytes = cfg.lds(sym_bytes(p.m, c->bsh));
 				if (bytes <= LDS_LIMIT)
@@ -596,7 +597,9 @@ int prepare_geometry(fseq_ctx *c)
 		c->bk_cap_words = 12288;                               // two bitmaps + 32-bit prefix counts: 12 B per word
 		if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) c->bk_cap_words = (uint32_t) std::max(2048, atoi(e));
 		c->bk_lds = blockkeys_stream_lds_bytes(c->bk_cap_words, 1024);
-		if (c->bk_lds <= LDS_LIMIT) HIP_TRY(c, allow_lds(k_blockkeys_stream, c->bk_lds));
+		// (bk_merge slices a merge by whole `hi` values: one hi value's Dlo <= m keys must fit the bitmap -- with more rows
+		// than bitmap bits a diverse block could overrun it, so such inputs take the column sweep k_colblock_stream<MODE_RANK>)
+		if (c->bk_lds <= LDS_LIMIT && (uint64_t) p.m <= (uint64_t) c->bk_cap_words * 32u) HIP_TRY(c, allow_lds(k_blockkeys_stream, c->bk_lds));
 		else c->bk_cap_words = 0;
 	}
 	else
@@ -735,7 +738,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	{
 		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
 		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
-		// within [4 GiB, 64 GiB]; the stride doubles from 16 until they fit.  (FSEQ_DEBUG prints the choice.)
+		// within [4 GiB, 160 GiB]; the smallest stride >= 16 that fits.  (FSEQ_DEBUG prints the choice.)
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
@@ -745,19 +748,40 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 				// tail, a few MB, and fragmentation -- BASELINE C4 on one GPU sits within 1 GiB of the 64-column stride)
 				uint64_t const reserve = (k_cnt / p.segment_length + 1) * (uint64_t) m * 8ull + (2ull << 30);
 				uint64_t const avail = free_b > reserve ? free_b - reserve : 0;
-				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 64ull << 30));
+				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 160ull << 30));
 			}
 		}
+		// streamed rows: 5 bytes per row when a row id and a column number fit 40 bits together (fseq_stream.hpp)
+		c->ss_pack = 0;
+		if (c->use_stream && !getenv("FSEQ_SS_UNPACKED"))
+		{
+			uint32_t abits = 1, dbits = 1;
+			while ((1ull << abits) < m) ++abits;
+			while ((1ull << dbits) <= p.n) ++dbits;
+			if (abits + dbits <= 40 && abits < 32) c->ss_pack = abits;
+		}
+		uint64_t const state_bytes = c->ss_pack ? (uint64_t) m * 4ull + ss_high_stride(p.m) : (uint64_t) m * 8ull;
 		uint64_t st_ = 16;
 		if (char const *e = getenv("FSEQ_SNAP_STRIDE")) st_ = (uint64_t) std::max(1, atoi(e));     // (experiments: first stride tried)
-		while ((k_cnt / st_ + 2) * (uint64_t) m * 8ull > budget) st_ *= 2;
+		// the smallest stride >= 16 whose states fit (any number, not a power of two: pass 2 costs ~stride / 2 columns per boundary)
+		if ((k_cnt / st_ + 2) * state_bytes > budget) st_ = std::max<uint64_t>(st_, (k_cnt * state_bytes + budget - 1) / std::max<uint64_t>(1, budget - 2 * state_bytes));
+		while ((k_cnt / st_ + 2) * state_bytes > budget) ++st_;
 		c->snap_stride = (uint32_t) st_;
-		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB)\n", (unsigned long long) st_, budget / 1073741824.0);
+		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB, %llu bytes per state)\n", (unsigned long long) st_, budget / 1073741824.0, (unsigned long long) state_bytes);
 		uint64_t const q_lo = k_lo / st_, q_hi = held_hi(c) / st_;
 		if ((rc = dev_alloc(c, &c->d_ss_a_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_ss_d_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
 		c->d_ss_a = c->d_ss_a_alloc - (size_t) q_lo * m;         // state at column q * snap_stride at d_ss_* + q * m
-		c->d_ss_d = c->d_ss_d_alloc - (size_t) q_lo * m;
+		if (c->ss_pack)
+		{
+			size_t const hs = ss_high_stride(p.m);
+			if ((rc = dev_alloc(c, &c->d_ss_d_alloc, ((size_t) (q_hi - q_lo + 1) * hs + 3) / 4))) return rc;
+			c->d_ss_d = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(c->d_ss_d_alloc) - (size_t) q_lo * hs);
+		}
+		else
+		{
+			if ((rc = dev_alloc(c, &c->d_ss_d_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
+			c->d_ss_d = c->d_ss_d_alloc - (size_t) q_lo * m;
+		}
 	}
 	return FSEQ_OK;
 }
@@ -964,7 +988,7 @@ void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint3
 		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
 		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
-		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0);
+		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0, 0u);
 	else
 		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys, col0);
 }
@@ -1313,6 +1337,34 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	else
 		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
+	char const *const sync_env = getenv("FSEQ_SYNC_PHASES");             // diagnostic ("ABC"): a fault shows up at the phase that caused it
+	auto sync_at = [&](char ph) { return sync_env && strchr(sync_env, ph); };
+	if (sync_at('A')) { fprintf(stderr, "[fseq] phase A queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase A done\n"); }
+	if (getenv("FSEQ_CHECK_PHASE_A"))
+	{
+		// diagnostic: the key blocks must be well-formed before anything indexes with them (ranks < nkeys <= m, the
+		// divergence in front of a key inside the block's columns)
+		HIP_TRY(c, hipStreamSynchronize(st));
+		std::vector<uint32_t> rk(m), kd(m);
+		for (uint32_t b = b_lo; b < b_hi; ++b)
+		{
+			uint32_t nk = 0;
+			HIP_TRY(c, hipMemcpy(&nk, c->d_nkeys + b, 4, hipMemcpyDeviceToHost));
+			HIP_TRY(c, hipMemcpy(rk.data(), c->d_rank + (size_t) b * m, (size_t) m * 4, hipMemcpyDeviceToHost));
+			HIP_TRY(c, hipMemcpy(kd.data(), c->d_keyd + (size_t) b * m, (size_t) m * 4, hipMemcpyDeviceToHost));
+			uint64_t const k0 = (uint64_t) b * c->B, k1 = std::min<uint64_t>(n, k0 + c->B);
+			uint32_t bad_r = 0, bad_k = 0;
+			for (uint32_t i = 0; i < m; ++i) if (rk[i] >= nk) ++bad_r;
+			for (uint32_t j = 0; j < nk && j < m; ++j) if (kd[j] <= k0 || kd[j] > k1) ++bad_k;
+			if (nk == 0 || nk > m || bad_r || bad_k)
+			{
+				char what[200];
+				snprintf(what, sizeof(what), "phase A check: block %u has %u keys (m = %u), %u ranks out of range, %u key divergences outside (%llu, %llu]",
+				         b, nk, m, bad_r, bad_k, (unsigned long long) k0, (unsigned long long) k1);
+				return fail(c, FSEQ_E_HIP, what);
+			}
+		}
+	}
 	if (!sharded)
 	{
 		// phase B: up the levels -- compose groups of G key blocks of a level into one key block of the next
@@ -1395,6 +1447,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
+	if (sync_at('B')) { fprintf(stderr, "[fseq] phase B queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase B done\n"); }
 	if (!p.list_cap && !c->X_hint)
 	{
 		// first run on this input: size the lists from the block boundary states (k_boundary_recent)
@@ -1411,8 +1464,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		{
 			std::nth_element(recent.begin(), recent.begin() + recent.size() / 2, recent.end());
 			uint64_t const med = recent[recent.size() / 2];
+			// (a quarter above the median, to the next multiple of 64 -- not the next 2^k - 1: the lists of BASELINE C4 are
+			// 5,000,000 x (X + 3) x 8 bytes, and what they do not take goes to the stride states of pass 2)
 			uint64_t const want = med + med / 4;
-			while (X < want) X = 2 * X + 1;
+			if (X < want) X = (uint32_t) (((want + 63) & ~63ull) - 1);
 			if (getenv("FSEQ_DEBUG"))
 				fprintf(stderr, "[fseq] list capacity estimate: %zu boundaries, median recent count %llu -> X = %u\n",
 				        recent.size(), (unsigned long long) med, X);
@@ -1484,16 +1539,18 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
 			if (c->use_stream && c->s2.T)
 			{
-				hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0);
+				uint32_t pack_abits = 0;
+				if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
+				hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
 				c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
-				             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+				             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 			}
 			else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !getenv("FSEQ_STREAM_PLAIN_SCAN"))
 				hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 			else if (c->use_stream)
 				hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 			else
 				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
 				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
@@ -1560,7 +1617,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
 			}
 			if (!sharded) launch_columns(0, c->nblocks);
-			else if (my_blocks)
+			if (sync_at('C')) { fprintf(stderr, "[fseq] phase C queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase C done\n"); }
+			if (sharded && my_blocks)
 			{
 				// my blocks, and the block behind them for as far as the halo reaches (k_columns stops at n_c)
 				uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
@@ -1826,7 +1884,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 				size_t const cnt = std::min(cap, grp.size() - g0);
 				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
 				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
-				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d, (uint64_t) 0);
+				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d, (uint64_t) 0, c->ss_pack);
 			}
 		}
 		else

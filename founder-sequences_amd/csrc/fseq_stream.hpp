@@ -16,6 +16,11 @@ constexpr int ST = 1024, SE = 4;                   // measured on m = 100,000 wi
 constexpr uint32_t SCAP = ST * SE;
 constexpr uint32_t STREAM_MAX_COLBYTES = 147456;   // column staging: one packed column (sym_bytes(m, bsh)) in LDS
 
+// Stride states of the streamed regime are packed when a row id and a divergence fit 40 bits together (ss_pack = bits
+// of a row id, 0 = not packed): word = a | d << ss_pack in the first array, byte = d >> (32 - ss_pack) in the second
+// (ss_high_stride(m) bytes per state) -- 5 instead of 8 bytes per row, so the states can lie closer together.
+__host__ __device__ inline size_t ss_high_stride(uint32_t m) { return ((size_t) m + 15) & ~size_t(15); }
+
 struct StreamLds {
 	StepScratch<ST, 4> scr;
 	uint32_t red[4 * (ST / WAVE) + 8];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 	uint64_t const *__restrict__ task_rb, uint2 const *__restrict__ task_grp,
 	uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d,
 	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
-	uint64_t col0)
+	uint64_t col0, uint32_t ss_pack)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -315,8 +320,17 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 		k0 = from_stride ? sidx * snap_stride : sidx * B;
 		kend = task_rb[t_first + t_count - 1u];
 		uint32_t const *sa = (from_stride ? ss_a : bstate_a) + sidx * (size_t) m;
-		uint32_t const *sd = (from_stride ? ss_d : bstate_d) + sidx * (size_t) m;
-		for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = sa[i]; buf[0][1][i] = sd[i]; }
+		if (from_stride && ss_pack)
+		{
+			// packed stride states (ss_unpack): 5 bytes per row
+			uint8_t const *sh = reinterpret_cast<uint8_t const *>(ss_d) + sidx * (size_t) ss_high_stride(m);
+			for (uint32_t i = tid; i < m; i += ST) { uint32_t const w = sa[i]; buf[0][0][i] = w & ((1u << ss_pack) - 1u); buf[0][1][i] = (w >> ss_pack) | ((uint32_t) sh[i] << (32u - ss_pack)); }
+		}
+		else
+		{
+			uint32_t const *sd = (from_stride ? ss_d : bstate_d) + sidx * (size_t) m;
+			for (uint32_t i = tid; i < m; i += ST) { buf[0][0][i] = sa[i]; buf[0][1][i] = sd[i]; }
+		}
 	}
 	__syncthreads();
 	uint32_t cur = 0;
@@ -427,7 +441,7 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch)
+	uint32_t *done_host, uint32_t epoch, uint32_t ss_pack)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -515,12 +529,14 @@ __global__ __launch_bounds__(ST) void k_columns_stream(
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
 		if (ss_a && (k0 + j + 1) % snap_stride == 0)
 		{
-			size_t const ob = (size_t) ((k0 + j + 1) / snap_stride) * m;
+			size_t const q = (size_t) ((k0 + j + 1) / snap_stride), ob = q * m;
+			uint8_t *sh = reinterpret_cast<uint8_t *>(ss_d) + q * ss_high_stride(m);
 			for (uint32_t i = tid; i < m; i += ST)
 			{
 				uint32_t const vid = buf[cur][1][i];
-				ss_a[ob + i] = buf[cur][0][i];
-				ss_d[ob + i] = vid < D0 ? V[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
+				uint32_t const dv = vid < D0 ? V[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
+				if (ss_pack) { ss_a[ob + i] = buf[cur][0][i] | (dv << ss_pack); sh[i] = (uint8_t) (dv >> (32u - ss_pack)); }
+				else { ss_a[ob + i] = buf[cur][0][i]; ss_d[ob + i] = dv; }
 			}
 		}
 		// ---- emit the top of the histogram (same list format as k_columns); counters were updated

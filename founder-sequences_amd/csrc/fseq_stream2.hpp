@@ -66,19 +66,26 @@ struct S2Lds {
 	uint32_t red[4 * (T / WAVE) + 8];
 };
 
-template <int T, int E>
+// PACK: a row of the order is 5 bytes in the workspace instead of 8 -- a word a | d << abits (abits = bits of a row id)
+// and the byte d >> (32 - abits) in a second array: value ids are < 2^KS <= 2^19 and row ids < m <= 2^KS, so 40 bits
+// always hold both.  A CU moves ~10 bytes per cycle through its memory pipeline whatever the chip's HBM does, and the
+// order crosses it twice per column: 16 bytes per row were ~75 % of a column's time on the C4 rows.
+template <int T, int E, bool PACK>
 __host__ __device__ inline size_t stream2_lds_bytes(uint32_t colbytes)
 {
-	return carve_bytes((size_t) colbytes + 16, 1) + carve_bytes(1, sizeof(S2Lds<T>)) + carve_bytes((size_t) T * E, 8);
+	return carve_bytes((size_t) colbytes + 16, 1) + carve_bytes(1, sizeof(S2Lds<T>))
+	     + (PACK ? carve_bytes((size_t) T * E, 4) + carve_bytes((size_t) T * E, 1) : carve_bytes((size_t) T * E, 8));
 }
 
 // ------------------------------------------------------------------------------------------------
 // Prologue of every block (the old kernel's, on its own): sorted distinct boundary divergences -> V, their
 // counts -> cnt, the order as (a, value id) pairs -> pairs0, D0 -> w[9m + B].  ST threads.
 // Workspace (words): pairs0 2m | pairs1 2m | keys 2m | V m | Vpos m | cnt m + B | D0
+// pack_abits != 0 (PACK kernels): the first 4m words hold words0 m | words1 m | bytes0 m / 4 | .. | bytes1 m / 4 (at 3m) instead
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
-	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0)
+	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0,
+	uint32_t pack_abits)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
@@ -143,7 +150,12 @@ __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 			uint32_t const mid = (lo + hi) >> 1;
 			if (V[mid] < key) lo = mid + 1; else hi = mid;
 		}
-		pairs0[i] = make_uint2(sa[i], lo);
+		if (pack_abits)
+		{
+			w[i] = sa[i] | (lo << pack_abits);
+			reinterpret_cast<uint8_t *>(w + 2u * (size_t) m)[i] = (uint8_t) (lo >> (32u - pack_abits));
+		}
+		else pairs0[i] = make_uint2(sa[i], lo);
 	}
 	if (tid == 0) w[9u * (size_t) m + B] = D0;
 }
@@ -344,27 +356,38 @@ __device__ __forceinline__ void s2_tile_step(
 // ------------------------------------------------------------------------------------------------
 // phase C, streamed, second form.  After k_columns_stream2_prologue on the same blocks.
 // ------------------------------------------------------------------------------------------------
-template <int T, int E>
-__global__ __launch_bounds__(T) void k_columns_stream2(
+// (at least four waves per SIMD: two workgroups of 512 threads -- or three to four of 256 -- share a CU, and what one of
+// them waits for at its barriers the others compute)
+template <int T, int E, bool PACK>
+__global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch)
+	uint32_t *done_host, uint32_t epoch, uint32_t ss_pack)
 {
 	constexpr int KS = s2_key_shift(T * E);
 	constexpr uint32_t TILE = (uint32_t) T * E;
 	static_assert(E % 2 == 0, "a thread loads its rows as 16-byte pieces of two (a, d) pairs");
+	static_assert(!PACK || E % 4 == 0, "packed rows: 16-byte pieces of four words, 4-byte pieces of four bytes");
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
 	uint8_t *sym = cv.take<uint8_t>((size_t) sym_bytes(m, bsh) + 16);
 	S2Lds<T> &L = *cv.take<S2Lds<T>>(1);
-	uint2 *const stage = cv.take<uint2>(TILE);
+	uint2 *const stage = PACK ? nullptr : cv.take<uint2>(TILE);
+	uint32_t *const stage_w = PACK ? cv.take<uint32_t>(TILE) : nullptr;
+	uint8_t *const stage_h = PACK ? cv.take<uint8_t>(TILE) : nullptr;
 	uint32_t const tid = threadIdx.x;
 	uint32_t const lane = lane_id();
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	uint32_t const blk = blockIdx.x + block0;
 	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
 	uint2 *pairs[2] = {reinterpret_cast<uint2 *>(w), reinterpret_cast<uint2 *>(w + 2u * (size_t) m)};
+	uint32_t *words[2] = {w, w + (size_t) m};                                 // PACK
+	uint8_t *highs[2] = {reinterpret_cast<uint8_t *>(w + 2u * (size_t) m), reinterpret_cast<uint8_t *>(w + 3u * (size_t) m)};
+	uint32_t abits = 1;
+	while ((1u << abits) < m) ++abits;
+	abits = __builtin_amdgcn_readfirstlane(abits);
+	uint32_t const amask = (1u << abits) - 1u, hshift = 32u - abits;
 	uint32_t const *V = w + 6u * (size_t) m;
 	uint32_t *cnt = w + 8u * (size_t) m;
 	uint32_t const D0 = __builtin_amdgcn_readfirstlane(w[9u * (size_t) m + B]);
@@ -401,17 +424,42 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 				for (int x = 0; x < 4; ++x) { tc.cnt[x] = 0; tc.val[x] = 0; tc.start[x] = acc; acc += cnt4[x]; }
 				tc.has = 0;
 			}
-			__amdgpu_buffer_rsrc_t const rs = make_rsrc(pairs[cur], m * 8u), rd = make_rsrc(pairs[cur ^ 1u], m * 8u);
+			__amdgpu_buffer_rsrc_t const rs = PACK ? make_rsrc(words[cur], m * 4u) : make_rsrc(pairs[cur], m * 8u),
+			                             rd = PACK ? make_rsrc(words[cur ^ 1u], m * 4u) : make_rsrc(pairs[cur ^ 1u], m * 8u);
+			// (bytes: the range rounded up to whole words -- a word that straddles the end of a descriptor's range reads as zero)
+			__amdgpu_buffer_rsrc_t const rsh = make_rsrc(highs[cur], (m + 3u) & ~3u), rdh = make_rsrc(highs[cur ^ 1u], (m + 3u) & ~3u);      // PACK
 			uint32_t const first_val = D0 + j;
-			uint32_t const toff = tid * (uint32_t) (E * 8);          // byte offset of the thread's rows inside a tile
+			uint32_t const toff = tid * (uint32_t) (E * (PACK ? 4 : 8));          // byte offset of the thread's rows inside a tile
 			// rows of the tile at `base` (rows behind m read as zero)
 			uint32_t an[E], dn[E];
 			auto load_tile = [&](uint32_t base) {
-#pragma unroll
-				for (int q = 0; q < E / 2; ++q)
+				if constexpr (PACK)
 				{
-					u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16u * q, base * 8u, 0);
-					an[2 * q] = v.x; dn[2 * q] = v.y; an[2 * q + 1] = v.z; dn[2 * q + 1] = v.w;
+					uint32_t hw[E / 4];
+#pragma unroll
+					for (int q = 0; q < E / 4; ++q)
+					{
+						u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16u * q, base * 4u, 0);
+						an[4 * q] = v.x; an[4 * q + 1] = v.y; an[4 * q + 2] = v.z; an[4 * q + 3] = v.w;
+						hw[q] = __builtin_amdgcn_raw_buffer_load_b32(rsh, tid * (uint32_t) E + 4u * q, base, 0);
+					}
+					// (unpacked where they arrive: dn = value id, an = row id)
+#pragma unroll
+					for (int e = 0; e < E; ++e)
+					{
+						uint32_t const hb = (hw[e / 4] >> (8 * (e % 4))) & 255u;
+						dn[e] = (an[e] >> abits) | (hb << hshift);
+						an[e] &= amask;
+					}
+				}
+				else
+				{
+#pragma unroll
+					for (int q = 0; q < E / 2; ++q)
+					{
+						u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16u * q, base * 8u, 0);
+						an[2 * q] = v.x; dn[2 * q] = v.y; an[2 * q + 1] = v.z; dn[2 * q + 1] = v.w;
+					}
 				}
 			};
 			auto tile = [&](uint32_t base, auto full_tag) {
@@ -420,8 +468,9 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 #pragma unroll
 				for (int e = 0; e < E; ++e)
 				{
-					a[e] = an[e]; d[e] = dn[e];
-					s[e] = (FULL || base + tid * E + e < m) ? sym_digit(sym, a[e], bsh, pass) : 4u;
+					bool const in = FULL || base + tid * E + e < m;
+					a[e] = an[e]; d[e] = in ? dn[e] : 0u;                  // (a position without a row must carry d = 0)
+					s[e] = in ? sym_digit(sym, a[e], bsh, pass) : 4u;
 				}
 				// the next tile's rows on their way while this one is partitioned, staged and written out (issued last thing
 				// before the write-out, they were 5 of 21 ms of the C4 prefix: all waves of the workgroup wait for them together)
@@ -437,7 +486,12 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 				{
 					if (FULL || base + tid * E + e < m)
 					{
-						if (!(FSEQ_S2_SKIP & 16)) stage[lp[e]] = make_uint2(a[e], dnew[e]);
+						if constexpr (PACK)
+						{
+							stage_w[lp[e]] = a[e] | (dnew[e] << abits);
+							stage_h[lp[e]] = (uint8_t) (dnew[e] >> hshift);
+						}
+						else if (!(FSEQ_S2_SKIP & 16)) stage[lp[e]] = make_uint2(a[e], dnew[e]);
 						if (!(FSEQ_S2_SKIP & 2) && d[e] != dnew[e])
 						{
 							(void) __hip_atomic_fetch_add(&cnt[d[e]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -449,10 +503,82 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 				lds_barrier();
 				S2_STAMP(4);
 				uint32_t const tile_n = FULL ? TILE : m - base;
+				auto ge = [](uint32_t j, uint32_t l) -> uint32_t { return (l - 1u - j) >> 31; };      // j >= l as 0 / 1 (both < 2^31)
+				if constexpr (PACK)
+				{
+					// words: groups of 256 output slots (16 bytes per lane); bytes: groups of 64 (one byte per lane -- a run of a
+					// bucket starts at any byte of the array).  gb[x] = first group entirely behind the start of bucket x; a group
+					// that holds a bucket start strictly inside it takes the per-slot path.
+					uint32_t const gb1 = (lofs[1] + 255u) >> 8, gb2 = (lofs[2] + 255u) >> 8, gb3 = (lofs[3] + 255u) >> 8;
+					uint32_t const sg1 = (lofs[1] & 255u) ? (lofs[1] >> 8) : 0xFFFFFFFFu, sg2 = (lofs[2] & 255u) ? (lofs[2] >> 8) : 0xFFFFFFFFu,
+					               sg3 = (lofs[3] & 255u) ? (lofs[3] >> 8) : 0xFFFFFFFFu;
+#pragma unroll
+					for (int e = 0; e < E / 4; ++e)
+					{
+						uint32_t const g = (uint32_t) e * (T / WAVE) + wave;
+						uint32_t const j0 = g * 256u;
+						if (!FULL && j0 >= tile_n) break;
+						uint4 const v = *reinterpret_cast<uint4 const *>(stage_w + j0 + 4u * lane);
+						if (FULL && g != sg1 && g != sg2 && g != sg3)
+						{
+							uint32_t sh = gsh[0];
+							sh = ge(g, gb1) ? gsh[1] : sh;
+							sh = ge(g, gb2) ? gsh[2] : sh;
+							sh = ge(g, gb3) ? gsh[3] : sh;
+							u32x4 const vv = {v.x, v.y, v.z, v.w};
+							__builtin_amdgcn_raw_buffer_store_b128(vv, rd, lane * 16u, (j0 + sh) * 4u, 0);
+						}
+						else
+						{
+							uint32_t const vq[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+							for (int h = 0; h < 4; ++h)
+							{
+								uint32_t const jj = j0 + 4u * lane + (uint32_t) h;
+								uint32_t sh = gsh[0];
+								sh = jj >= lofs[1] ? gsh[1] : sh;
+								sh = jj >= lofs[2] ? gsh[2] : sh;
+								sh = jj >= lofs[3] ? gsh[3] : sh;
+								if (FULL || jj < tile_n)
+									__builtin_amdgcn_raw_buffer_store_b32(vq[h], rd, (jj + sh) * 4u, 0u, 0);
+							}
+						}
+					}
+					uint32_t const hb1 = (lofs[1] + 63u) >> 6, hb2 = (lofs[2] + 63u) >> 6, hb3 = (lofs[3] + 63u) >> 6;
+					uint32_t const hs1 = (lofs[1] & 63u) ? (lofs[1] >> 6) : 0xFFFFFFFFu, hs2 = (lofs[2] & 63u) ? (lofs[2] >> 6) : 0xFFFFFFFFu,
+					               hs3 = (lofs[3] & 63u) ? (lofs[3] >> 6) : 0xFFFFFFFFu;
+#pragma unroll
+					for (int e = 0; e < E; ++e)
+					{
+						uint32_t const g = (uint32_t) e * (T / WAVE) + wave;
+						uint32_t const j0 = g * 64u;
+						if (!FULL && j0 >= tile_n) break;
+						uint8_t const hv = stage_h[j0 + lane];
+						if (FULL && g != hs1 && g != hs2 && g != hs3)
+						{
+							uint32_t sh = gsh[0];
+							sh = ge(g, hb1) ? gsh[1] : sh;
+							sh = ge(g, hb2) ? gsh[2] : sh;
+							sh = ge(g, hb3) ? gsh[3] : sh;
+							__builtin_amdgcn_raw_buffer_store_b8(hv, rdh, lane, j0 + sh, 0);
+						}
+						else
+						{
+							uint32_t const jj = j0 + lane;
+							uint32_t sh = gsh[0];
+							sh = jj >= lofs[1] ? gsh[1] : sh;
+							sh = jj >= lofs[2] ? gsh[2] : sh;
+							sh = jj >= lofs[3] ? gsh[3] : sh;
+							if (FULL || jj < tile_n)
+								__builtin_amdgcn_raw_buffer_store_b8(hv, rdh, jj + sh, 0u, 0);
+						}
+					}
+				}
+				else
+				{
 				// Output slots go out in groups of 128 (one 16-byte store per lane: the memory pipeline of a CU, ~10 bytes per
 				// cycle, takes wide stores at twice the rate of 8-byte ones).  gb[x] = first group that lies entirely behind the
 				// start of bucket x; a group that holds a bucket start strictly inside it takes the per-slot path.
-				auto ge = [](uint32_t j, uint32_t l) -> uint32_t { return (l - 1u - j) >> 31; };      // j >= l as 0 / 1 (both < 2^31)
 				uint32_t const gb1 = (lofs[1] + 127u) >> 7, gb2 = (lofs[2] + 127u) >> 7, gb3 = (lofs[3] + 127u) >> 7;
 				uint32_t const sg1 = (lofs[1] & 127u) ? (lofs[1] >> 7) : 0xFFFFFFFFu, sg2 = (lofs[2] & 127u) ? (lofs[2] >> 7) : 0xFFFFFFFFu,
 				               sg3 = (lofs[3] & 127u) ? (lofs[3] >> 7) : 0xFFFFFFFFu;
@@ -489,6 +615,7 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 						}
 					}
 				}
+				}
 				S2_STAMP(5);
 				// (no barrier here: the next tile's stage writes come behind its own barrier, which every wave reaches only
 				// after its reads above; the scan scratch is rewritten only by waves that have passed the barrier above)
@@ -503,15 +630,21 @@ __global__ __launch_bounds__(T) void k_columns_stream2(
 			S2_STAMP(7);
 		}
 		uint2 const *P = pairs[cur];
+		uint32_t const *PW = words[cur];
+		uint8_t const *PH = highs[cur];
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
 		if (ss_a && (k0 + j + 1) % snap_stride == 0)
 		{
-			size_t const ob = (size_t) ((k0 + j + 1) / snap_stride) * m;
+			size_t const q = (size_t) ((k0 + j + 1) / snap_stride), ob = q * m;
+			uint8_t *sh = reinterpret_cast<uint8_t *>(ss_d) + q * ss_high_stride(m);
 			for (uint32_t i = tid; i < m; i += T)
 			{
-				uint2 const p = P[i];
-				ss_a[ob + i] = p.x;
-				ss_d[ob + i] = p.y < D0 ? V[p.y] : (uint32_t) (k0 + (p.y - D0) + 1u);
+				uint2 p;
+				if constexpr (PACK) { uint32_t const pw = PW[i]; p = make_uint2(pw & amask, (pw >> abits) | ((uint32_t) PH[i] << hshift)); }
+				else p = P[i];
+				uint32_t const dv = p.y < D0 ? V[p.y] : (uint32_t) (k0 + (p.y - D0) + 1u);
+				if (ss_pack) { ss_a[ob + i] = p.x | (dv << ss_pack); sh[i] = (uint8_t) (dv >> (32u - ss_pack)); }
+				else { ss_a[ob + i] = p.x; ss_d[ob + i] = dv; }
 			}
 		}
 		S2_STAMP(8);

@@ -129,12 +129,14 @@ class Rmq:
 
 
 class Pbwt:
-    def __init__(self, msa, with_counts=True, debug=True):
+    def __init__(self, msa, with_counts=True, debug=True, col0=0):
+        """col0: msa holds the columns [col0, col0 + msa.shape[1]) of a longer alignment (a replay from a state set
+        with set_state(a, d, idx >= col0): the oracle only reads columns >= idx)."""
         self.L = lib(debug)
         self.msa = msa
         base, rs, cs = _strides(msa)
-        self.m, self.n = msa.shape
-        self.h = self.L.fso_pbwt_new(base, rs, cs, self.m, self.n, 1 if with_counts else 0)
+        self.m, self.n = msa.shape[0], col0 + msa.shape[1]
+        self.h = self.L.fso_pbwt_new(base - col0 * cs, rs, cs, self.m, self.n, 1 if with_counts else 0)
         self.L.fso_pbwt_prepare(self.h)
 
     def set_state(self, a, d, idx):

@@ -145,6 +145,17 @@ def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
     compare_long(pkg, msa, 8, block_len=40)
 
 
+def test_streamed_phase_a_with_more_rows_than_bitmap_bits(pkg, monkeypatch):
+    """A merge of the streamed key-space tree is sliced by whole `hi` values, so one value's Dlo <= m keys must fit the
+    LDS bitmap: with a forced small bitmap (2048 words = 65,536 bits) and 70,000 all-distinct rows phase A must take the
+    column sweep instead (it used to overrun the bitmap)."""
+    monkeypatch.setenv("FSEQ_BLOCKKEYS_CAP", "2048")
+    rng = np.random.default_rng(12)
+    msa = (rng.integers(0, 4, size=(70000, 48)) + 65).astype(np.uint8)
+    ctx, _ = compare_long(pkg, msa, 8, block_len=24)
+    assert ctx.timings()["phase_a_fallbacks"] == 0           # (the key-space kernel did not run at all)
+
+
 @pytest.mark.parametrize("fan", [0, 2, 3, 5, 64])
 def test_phase_b_recursion_with_any_group_size(pkg, monkeypatch, fan):
     """Phase B composes groups of G key blocks level after level until at most G are left (G = 4 by itself): 600
@@ -487,6 +498,92 @@ def check_full_size_properties(pkg, ctx, res, m, n, L, prefix_cols):
     assert np.array_equal(sz[:k], ref["dp"]["segment_size"][:k])
 
 
+def check_depth_against_oracle(pkg, ctx, m, n, L, blocks, list_every=1, cells_per_block=150, seed=1):
+    """Oracle evidence at depth, at full size.  For every block b of `blocks`: the oracle's pBWT starts from the
+    GPU's boundary state of b (debug_block_state) and runs the block's columns.  On the way
+      * every merged boundary inside the block must equal fseq_boundary_state (pass 2 from the stride states),
+      * the per-column list of every `list_every`-th column (and of the block's last 8) must be the top of the
+        oracle's divergence-value counts,
+      * `cells_per_block` sampled DP cells are evaluated again by the oracle's calculate_segmentation_lp_dp_arg on the
+        oracle's counts of that column, over the GPU's own DP array with the oracle's rmq built on it: each must
+        reproduce (lb, max, size) -- the fixed-point property of segmentation_lp_context.cc:393-481,
+    and the state the oracle ends in must equal the GPU's boundary state of b + 1."""
+    t = ctx.timings()
+    B, nblocks, X = t["block_len"], t["n_blocks"], t["list_cap_used"]
+    lb, mx, sz = ctx.debug_dp()
+    k_dp = n - L + 1
+    mx = mx.copy()
+    mx[n - 2 * L + 1:n - L] = 0xFFFFFFFF                       # entries no cell writes (the oracle's initial value)
+    dp = np.zeros(k_dp, dtype=fso.DP_DTYPE)
+    dp["lb"], dp["rb"], dp["segment_max_size"], dp["segment_size"] = lb, np.arange(k_dp, dtype=np.uint64) + L, mx, sz
+    rmq = fso.Rmq(mx, debug=False)
+    for i in range(63, k_dp, 64):
+        rmq.update(i)                                          # (append-only tables: a query only reads what was final when its cell ran)
+    red = ctx.reduced_traceback()
+    rb_index = {int(rb): i for i, rb in enumerate(red["rb"])}
+    part2_limit, part3_limit = min(2 * L, n - L) - 1, n - L
+    rng = np.random.default_rng(seed)
+    checked = dict(blocks=0, boundaries=0, lists=0, cells=0)
+    for b in sorted(set(int(x) for x in blocks)):
+        assert 0 <= b < nblocks
+        c0, c1 = b * B, min(n, (b + 1) * B)
+        sub = ctx.get_sequences(c0, c1)
+        p = fso.Pbwt(sub, debug=False, col0=c0)
+        a, d = ctx.debug_block_state(b)
+        p.set_state(a, d, c0)
+        lo, hi = max(c0, part2_limit), min(c1, part3_limit)
+        cell_cols = set(rng.choice(np.arange(lo, hi), size=min(cells_per_block, hi - lo), replace=False).tolist()) if hi > lo else set()
+        for k in range(c0, c1):
+            p.step()
+            if k + 1 in rb_index:
+                ga, gd = ctx.boundary_state(rb_index[k + 1])
+                assert np.array_equal(ga, p.a) and np.array_equal(gd, p.d), ("boundary", b, k + 1)
+                checked["boundaries"] += 1
+            want_list = (k - c0) % list_every == 0 or k >= c1 - 8
+            if want_list or k in cell_cols:
+                v, c = p.counts()
+            if want_list:
+                gv, gc, cnt0, complete = ctx.debug_column_list(k)
+                thr = max(0, k + 2 - L)
+                rec = v >= thr
+                ev = np.concatenate([[k + 1], v[~rec][::-1]])
+                ec = np.concatenate([[c[rec].sum()], c[~rec][::-1]])
+                assert complete or gc[1:].sum() > X, ("list", b, k)
+                assert np.array_equal(gv, ev[:len(gv)]) and np.array_equal(gc, ec[:len(gc)]), ("list", b, k)
+                assert complete == (len(gv) == len(ev)) and cnt0 == (c[0] if v[0] == 0 else 0), ("list", b, k)
+                checked["lists"] += 1
+            if k in cell_cols:
+                got = fso.dp_step(v, c, dp, rmq.h, m, L, 0, k, (0, k + 1, m, m), debug=False)
+                tt = k + 1 - L
+                assert got == (int(lb[tt]), k + 1, int(mx[tt]), int(sz[tt])), ("cell", b, k, got)
+                checked["cells"] += 1
+        a, d = ctx.debug_block_state(b + 1)
+        assert np.array_equal(a, p.a) and np.array_equal(d, p.d), ("block end", b)
+        checked["blocks"] += 1
+    return checked
+
+
+def depth_blocks(t, n):
+    """Blocks worth a replay: the first ones, both sides of every boundary between groups of 4^k blocks that is still
+    inside the alignment for the largest k (phase B's levels), both sides of a boundary between two DP chunks in the
+    middle of the alignment, a few arbitrary ones, the last two."""
+    nb, B = t["n_blocks"], t["block_len"]
+    pick = {0, 1, nb - 2, nb - 1, nb // 3, (2 * nb) // 3 + 1}
+    g = 1
+    while g * 4 < nb:
+        g *= 4
+    for q in (g // 4, g):
+        for x in (q - 1, q):
+            if 0 <= x < nb:
+                pick.add(x)
+    if t["dp_chunks"] > 1:
+        col = n * (t["dp_chunks"] // 2) // t["dp_chunks"]      # about where chunk dp_chunks / 2 begins
+        for x in (col // B - 1, col // B, col // B + 1):
+            if 0 <= x < nb:
+                pick.add(x)
+    return sorted(pick)
+
+
 def test_config_c5_full_size_properties(pkg):
     """BASELINE config C5 at full size (m = 10,000 x n = 1,000,000, sigma = 16, 4 bits per cell, 16-bit LDS state)."""
     c = fso.CONFIGS["C5"]
@@ -497,6 +594,36 @@ def test_config_c5_full_size_properties(pkg):
     t = ctx.timings()
     assert t["dp_chunks"] > 100 and t["dp_sweeps"] < 1000
     check_full_size_properties(pkg, ctx, res, m, n, L, 6000)
+    blocks = depth_blocks(t, n) + list(range(37, t["n_blocks"], 41))
+    got = check_depth_against_oracle(pkg, ctx, m, n, L, blocks, list_every=1, cells_per_block=40)
+    assert got["blocks"] >= 30 and got["cells"] >= 1000 and got["boundaries"] >= 32 and got["lists"] >= 20000, got
+
+
+def test_config_c5_full_size_matches_oracle(pkg):
+    """The whole of BASELINE config C5 through the oracle (pass 1 + DP on one thread, as the reference runs them: about
+    a minute of CPU): DP array, traceback, merged segments and every boundary state, as for C3."""
+    c = fso.CONFIGS["C5"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    ctx.run()
+    msa = ctx.get_sequences()
+    ref = fso.segment_long(msa, L, keep_dp=True, threads=8)
+    lb, mx, sz = ctx.debug_dp()
+    dp = ref["dp"]
+    written = np.ones(len(dp), dtype=bool)
+    written[n - 2 * L + 1:n - L] = False
+    assert np.array_equal(mx[written], dp["segment_max_size"][written])
+    assert np.array_equal(lb[written], dp["lb"][written].astype(np.uint32))
+    assert np.array_equal(sz[written], dp["segment_size"][written])
+    tb, red = ctx.traceback(), ctx.reduced_traceback()
+    for f in ("lb", "rb", "segment_max_size", "segment_size"):
+        assert np.array_equal(tb[f], ref["traceback"][f]), f
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f]), f
+    for i in range(len(red)):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i]), i
 
 
 def test_config_c4_full_size_properties(pkg):
@@ -511,6 +638,9 @@ def test_config_c4_full_size_properties(pkg):
     ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
     res = ctx.run()
     check_full_size_properties(pkg, ctx, res, m, n, L, 2400)
+    t = ctx.timings()
+    got = check_depth_against_oracle(pkg, ctx, m, n, L, depth_blocks(t, n), list_every=16, cells_per_block=100)
+    assert got["blocks"] >= 8 and got["cells"] >= 1000 and got["boundaries"] >= 32 and got["lists"] >= 2000, got
     ctx.close()
 
 
