@@ -183,10 +183,12 @@ def rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehe
         dt = fdist.timed_steps(step, 1, 1, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
                                tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cpu" if rehearsal else "cuda"))
         transport_name = "1 GPU, no exchange" if world == 1 else ("gloo via host (rehearsal: ranks share a GPU)" if rehearsal else "RCCL")
+    # devices the ranks really ran on (ranks as threads, or a rehearsal with ranks sharing the cards: fewer than ranks)
+    n_devices = 1 if (nthreads or world == 1) else (min(world, max(1, torch.cuda.device_count())) if rehearsal else world)
     if rank == 0:
         print(json.dumps({
             "metric": "row-sharded pBWT sweep, columns/s (north-star partition; conformance path)",
-            "value": cols / dt, "unit": "columns/s", "n_gpus": world, "ranks": W, "higher_is_better": True,
+            "value": cols / dt, "unit": "columns/s", "n_gpus": n_devices, "ranks": W, "higher_is_better": True,
             "us_per_column": dt / cols * 1e6, "cells_per_s": m * cols / dt, "exchanges": int(nex),
             "exchanges_per_column": nex / cols, "scaling": "strong", "data": "synthetic", "dtype": "u32",
             "config": {"workload": "%s prefix: m=%d x %d columns, sigma=%d; positions of the order and rows of the alignment sharded over %d ranks"
@@ -255,6 +257,10 @@ def main():
     if world > 1:
         # ONE alignment over the ranks: this rank generates and keeps its own column blocks only
         transport = fdist.shard_context(ctx, rank, world, dist, torch.device("cuda", local_rank), via_host=rehearsal)
+        if rehearsal:
+            # ranks that share a card must not each plan with the whole of it (the pass-2 stride states take what is free)
+            sharing = (world + max(1, torch.cuda.device_count()) - 1) // max(1, torch.cuda.device_count())
+            ctx.set_memory_budget(int(torch.cuda.get_device_properties(local_rank).total_memory * 0.9 / sharing))
     ctx.generate_synthetic(w["seed"], w["K"], w["B"], w["mu"], w["kind"])
     # optional: more alignments in flight on the same GPU (the DP of one alignment occupies one CU)
     extra = []
@@ -327,7 +333,8 @@ def main():
         "metric": "alignment cells/s (m*n/T) through pBWT+DP",
         "value": max(1, args.concurrent) * m * n * steps / dt,
         "unit": "cells/s",
-        "n_gpus": world,
+        "n_gpus": (min(world, max(1, torch.cuda.device_count())) if rehearsal else world),      # devices, not ranks: a rehearsal shares cards
+        "ranks": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": step_ms,

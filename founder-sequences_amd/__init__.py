@@ -73,7 +73,15 @@ EXPORTS = [
     "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
+    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget",
 ]
+# ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
+DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule"]
+
+FSEQ_E_PEER = 6
+STAGE_TRACEBACK, STAGE_MERGE, STAGE_SAMPLES = 0, 1, 2
+# fseq_progress_fn (include/fseq.h): (user, stage, current_step, step_max)
+PROGRESS_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int, C.c_uint64, C.c_uint64)
 
 JOIN_GREEDY, JOIN_BIPARTITE, JOIN_RANDOM = 0, 1, 2
 
@@ -136,6 +144,12 @@ def load_library():
     L.fseq_rowshard_xbuf_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.fseq_rowshard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fseq_rowshard_pbwt.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(u64)]
+    L.fseq_set_progress.argtypes = [vp, PROGRESS_FN, vp]
+    L.fseq_step_max.restype = u64
+    L.fseq_step_max.argtypes = [vp]
+    L.fseq_current_step.restype = u64
+    L.fseq_current_step.argtypes = [vp]
+    L.fseq_set_memory_budget.argtypes = [vp, u64]
     _lib = L
     return L
 
@@ -344,6 +358,22 @@ class SegmentationContext:
         self._shard_cb = ALLREDUCE_FN(_cb)         # keep the thunk alive as long as the context
         self._check(self.L.fseq_set_shard(self.h, rank, world, xbuf_ptr, xbuf_words, self._shard_cb, None))
         self.rank, self.world = rank, world
+
+    def set_memory_budget(self, nbytes):
+        """Device memory this context may hold in all (ranks that share a card); 0 = whatever is free."""
+        self._check(self.L.fseq_set_memory_budget(self.h, int(nbytes)))
+
+    def set_progress(self, fn):
+        """fn(stage, current_step, step_max) at the phase boundaries of run() (None: off); step_max() / current_step()
+        may be polled from another thread."""
+        self._progress = PROGRESS_FN(lambda _u, stage, cur, mx: fn(stage, cur, mx)) if fn else PROGRESS_FN()
+        self._check(self.L.fseq_set_progress(self.h, self._progress, None))
+
+    def step_max(self):
+        return int(self.L.fseq_step_max(self.h))
+
+    def current_step(self):
+        return int(self.L.fseq_current_step(self.h))
 
     def shard_xbuf_words(self, world):
         return int(self.L.fseq_shard_xbuf_words(self.h, world))

@@ -28,8 +28,11 @@ def build(force=False, verbose=False):
     if not force and not needs_build():
         return OUT
     # FSEQ_HIPCC_FLAGS: extra flags for diagnostic builds (-DFSEQ_DP_STAMPS, -DFSEQ_DP_STATS)
+    # roctx ranges per phase when the image has the library (rocprofv3 --marker-trace shows them)
+    roctx = ["-DFSEQ_WITH_ROCTX", "-L/opt/rocm/lib", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"] \
+        if os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so") and os.path.exists("/opt/rocm/include/rocprofiler-sdk-roctx/roctx.h") else []
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("FSEQ_HIPCC_FLAGS", "").split() \
-        + ["-o", OUT, SRC]
+        + ["-o", OUT, SRC] + roctx
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -6,6 +6,7 @@
 // There is deliberately NO CPU fallback for the column work: if the device or a kernel shape is
 // unavailable the call fails with an error code.
 #include "../../include/fseq.h"
+#include "../../include/fseq_debug.h"
 #include "fseq_kernels.hpp"
 #include "fseq_dp.hpp"
 #include "fseq_dpspec.hpp"
@@ -16,13 +17,24 @@
 #include "fseq_join.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
+
+#ifdef FSEQ_WITH_ROCTX
+#include <rocprofiler-sdk-roctx/roctx.h>
+#define FSEQ_RANGE_PUSH(name) (void) roctxRangePushA(name)
+#define FSEQ_RANGE_POP() (void) roctxRangePop()
+#else
+#define FSEQ_RANGE_PUSH(name) do { } while (0)
+#define FSEQ_RANGE_POP() do { } while (0)
+#endif
 
 using namespace fseq;
 
@@ -276,6 +288,12 @@ struct Shard {
 
 struct fseq_ctx {
 	fseq_params p{};
+	std::unordered_map<void *, size_t> alloc_sizes;   // device allocations of this context (dev_alloc / dev_free)
+	size_t alloc_total = 0;
+	uint64_t mem_budget = 0;                  // fseq_set_memory_budget: 0 = whatever is free on the device
+	std::atomic<uint64_t> step_max{0}, current_step{0};      // fseq_step_max / fseq_current_step (segmentation_lp_context.hh:122-127)
+	fseq_progress_fn progress_fn = nullptr;
+	void *progress_user = nullptr;
 	hipStream_t stream = nullptr;
 	std::string err;
 	Shard sh;
@@ -386,6 +404,14 @@ int fail(fseq_ctx *c, int code, char const *what, hipError_t e = hipSuccess)
 	return code;
 }
 
+// progress (include/fseq.h, fseq_set_progress): counters another thread may poll + the caller's callback
+void progress(fseq_ctx *c, int stage, uint64_t current, uint64_t max)
+{
+	c->step_max.store(max, std::memory_order_relaxed);
+	c->current_step.store(current, std::memory_order_relaxed);
+	if (c->progress_fn) c->progress_fn(c->progress_user, stage, current, max);
+}
+
 #define HIP_TRY(c, expr)                                                   \
 	do {                                                                   \
 		hipError_t e_ = (expr);                                            \
@@ -393,32 +419,40 @@ int fail(fseq_ctx *c, int code, char const *what, hipError_t e = hipSuccess)
 	} while (0)
 
 template <typename U>
+void dev_free(fseq_ctx *c, U **p)
+{
+	if (!*p) return;
+	auto it = c->alloc_sizes.find(static_cast<void *>(*p));
+	if (it != c->alloc_sizes.end()) { c->alloc_total -= it->second; c->alloc_sizes.erase(it); }
+	(void) hipFree(*p);
+	*p = nullptr;
+}
+
+// every device allocation of a context goes through here: alloc_total is what the context holds (the memory plan of
+// the stride states stays inside fseq_set_memory_budget's figure when ranks share a card)
+template <typename U>
 int dev_alloc(fseq_ctx *c, U **p, size_t count)
 {
-	if (*p) { (void) hipFree(*p); *p = nullptr; }
-	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(U));
+	dev_free(c, p);
+	size_t const bytes = std::max<size_t>(count, 1) * sizeof(U);
+	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
 	if (e != hipSuccess)
 	{
 		*p = nullptr;
 		size_t free_b = 0, total_b = 0;
 		(void) hipMemGetInfo(&free_b, &total_b);
 		char what[160];
-		snprintf(what, sizeof(what), "hipMalloc of %zu bytes (%zu of %zu bytes free on the device)",
-		         std::max<size_t>(count, 1) * sizeof(U), free_b, total_b);
+		snprintf(what, sizeof(what), "hipMalloc of %zu bytes (%zu of %zu bytes free on the device)", bytes, free_b, total_b);
 		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, what, e);
 	}
+	c->alloc_sizes[static_cast<void *>(*p)] = bytes;
+	c->alloc_total += bytes;
 	return FSEQ_OK;
-}
-
-template <typename U>
-void dev_free(U **p)
-{
-	if (*p) { (void) hipFree(*p); *p = nullptr; }
 }
 
 void free_msa(fseq_ctx *c)
 {
-	if (c->own_msa) dev_free(&c->d_msa_alloc);
+	if (c->own_msa) dev_free(c, &c->d_msa_alloc);
 	c->d_msa_alloc = nullptr;
 	c->d_msa = nullptr;
 	c->own_msa = false;
@@ -723,12 +757,12 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	{
 		c->X = X;
 		c->stride = (X + 3) & ~1u;                // lump + up to X+1 entries, even
-		dev_free(&c->d_ent_alloc); c->d_ent = nullptr;
+		dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr;
 		rc = dev_alloc(c, &c->d_ent_alloc, (size_t) k_cnt * c->stride + 256);   // padded: the DP loads strips unconditionally
 		if (rc == FSEQ_E_OOM && c->d_ss_a)
 		{
 			// the stride states were sized before the lists grew: give their memory back and size them again below
-			dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
+			dev_free(c, &c->d_ss_a_alloc); dev_free(c, &c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
 			rc = dev_alloc(c, &c->d_ent_alloc, (size_t) k_cnt * c->stride + 256);
 		}
 		if (rc) return rc;
@@ -747,7 +781,10 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 				// (everything else of any size is allocated by now: the margin covers the traceback / task arrays of the
 				// tail, a few MB, and fragmentation -- BASELINE C4 on one GPU sits within 1 GiB of the 64-column stride)
 				uint64_t const reserve = (k_cnt / p.segment_length + 1) * (uint64_t) m * 8ull + (2ull << 30);
-				uint64_t const avail = free_b > reserve ? free_b - reserve : 0;
+				// (a context with a memory budget -- ranks that share a card -- plans inside what is left of it)
+				uint64_t mine = free_b;
+				if (c->mem_budget) mine = std::min<uint64_t>(mine, c->mem_budget > c->alloc_total ? c->mem_budget - c->alloc_total : 0);
+				uint64_t const avail = mine > reserve ? mine - reserve : 0;
 				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 160ull << 30));
 			}
 		}
@@ -788,20 +825,20 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 
 void free_work(fseq_ctx *c)
 {
-	dev_free(&c->d_rank); dev_free(&c->d_keyd); dev_free(&c->d_nkeys);
-	dev_free(&c->d_bstate_a); dev_free(&c->d_bstate_d);
-	dev_free(&c->d_hrank); dev_free(&c->d_hkeyd); dev_free(&c->d_hnkeys); dev_free(&c->d_hstate_a); dev_free(&c->d_hstate_d);
-	for (auto &lv : c->levels) { dev_free(&lv.rank); dev_free(&lv.keyd); dev_free(&lv.nkeys); dev_free(&lv.state_a); dev_free(&lv.state_d); }
+	dev_free(c, &c->d_rank); dev_free(c, &c->d_keyd); dev_free(c, &c->d_nkeys);
+	dev_free(c, &c->d_bstate_a); dev_free(c, &c->d_bstate_d);
+	dev_free(c, &c->d_hrank); dev_free(c, &c->d_hkeyd); dev_free(c, &c->d_hnkeys); dev_free(c, &c->d_hstate_a); dev_free(c, &c->d_hstate_d);
+	for (auto &lv : c->levels) { dev_free(c, &lv.rank); dev_free(c, &lv.keyd); dev_free(c, &lv.nkeys); dev_free(c, &lv.state_a); dev_free(c, &lv.state_d); }
 	c->levels.clear();
-	dev_free(&c->d_ent_alloc); c->d_ent = nullptr; dev_free(&c->d_hdr); dev_free(&c->d_flags); dev_free(&c->d_recent);
-	dev_free(&c->d_chunk_r0); c->chunk_cap = 0; dev_free(&c->d_tau); c->tau_cap = 0;
-	dev_free(&c->d_bk); c->bk_blocks = 0; dev_free(&c->d_bkws); c->bkws_words = 0;
-	dev_free(&c->d_tb); c->tb_cap = 0; c->tb_win = 0;
-	dev_free(&c->dp.M); dev_free(&c->dp.LB); dev_free(&c->dp.SZ); dev_free(&c->dp.K); dev_free(&c->dp.Tb); dev_free(&c->dp.Tbv);
-	dev_free(&c->d_Mprev); dev_free(&c->d_spec); c->spec_cap = 0;
-	dev_free(&c->d_cols); dev_free(&c->d_grp); dev_free(&c->d_src); dev_free(&c->d_ss_a_alloc); dev_free(&c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
-	dev_free(&c->d_gent); dev_free(&c->d_ghdr);
-	dev_free(&c->d_snap_a); dev_free(&c->d_snap_d); dev_free(&c->d_ws);
+	dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr; dev_free(c, &c->d_hdr); dev_free(c, &c->d_flags); dev_free(c, &c->d_recent);
+	dev_free(c, &c->d_chunk_r0); c->chunk_cap = 0; dev_free(c, &c->d_tau); c->tau_cap = 0;
+	dev_free(c, &c->d_bk); c->bk_blocks = 0; dev_free(c, &c->d_bkws); c->bkws_words = 0;
+	dev_free(c, &c->d_tb); c->tb_cap = 0; c->tb_win = 0;
+	dev_free(c, &c->dp.M); dev_free(c, &c->dp.LB); dev_free(c, &c->dp.SZ); dev_free(c, &c->dp.K); dev_free(c, &c->dp.Tb); dev_free(c, &c->dp.Tbv);
+	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
+	dev_free(c, &c->d_cols); dev_free(c, &c->d_grp); dev_free(c, &c->d_src); dev_free(c, &c->d_ss_a_alloc); dev_free(c, &c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
+	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
+	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws);
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 }
 
@@ -809,6 +846,7 @@ void free_work(fseq_ctx *c)
 // (consecutive_alphabet_as_builder, generate_context.cc:135-147: dense codes in ascending byte order,
 // Appendix B A2) and the row-major -> column-major transpose run on the GPU.
 int shard_exchange(fseq_ctx *c, uint64_t words, int op);
+void shard_post_failure(fseq_ctx *c, int code);
 
 int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 {
@@ -819,8 +857,8 @@ int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
 	uint32_t *d_present = nullptr;
 	int rc;
 	if ((rc = dev_alloc(c, &d_raw, total + 16))) return rc;
-	if ((rc = dev_alloc(c, &d_present, 8))) { dev_free(&d_raw); return rc; }
-	auto cleanup = [&]() { dev_free(&d_raw); dev_free(&d_present); };
+	if ((rc = dev_alloc(c, &d_present, 8))) { dev_free(c, &d_raw); return rc; }
+	auto cleanup = [&]() { dev_free(c, &d_raw); dev_free(c, &d_present); };
 	for (uint32_t r = 0; r < p.m && nloc; ++r)
 	{
 		hipError_t const e = hipMemcpyAsync(d_raw + (size_t) r * nloc, rows[r] + k_lo, nloc, hipMemcpyHostToDevice, c->stream);
@@ -1010,13 +1048,45 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 // ---- sharded runs: the one exchange primitive (include/fseq.h, fseq_set_shard) -------------------------------
 // all-reduce of xbuf[0 .. words) over the ranks through the caller's function; the data must already be queued
 // into xbuf on c->stream.  Not sharded: nothing to do.
+// Every exchange starts with a one-word maximum of the ranks' status words (the last word of the buffer): a rank that
+// has failed (out of memory, a HIP error) posts its error code there ONCE, in the exchange the others make next, and
+// every rank leaves with FSEQ_E_PEER instead of waiting in a collective for a rank that will never arrive.
+int shard_status(fseq_ctx *c, uint32_t mine)
+{
+	Shard &sh = c->sh;
+	uint64_t const slot = sh.xwords - 1;
+	HIP_TRY(c, hipMemcpyAsync(sh.xbuf + slot, &mine, 4, hipMemcpyHostToDevice, c->stream));
+	HIP_TRY(c, hipStreamSynchronize(c->stream));
+	if (sh.fn(sh.user, slot, 1, 1) != 0) return fail(c, FSEQ_E_HIP, "the caller's all-reduce failed");
+	uint32_t got = 0;
+	HIP_TRY(c, hipMemcpy(&got, sh.xbuf + slot, 4, hipMemcpyDeviceToHost));
+	if (got && !mine)
+	{
+		char what[96];
+		snprintf(what, sizeof(what), "another rank of the sharded run failed (its error code: %u)", got);
+		return fail(c, FSEQ_E_PEER, what);
+	}
+	return FSEQ_OK;
+}
+
 int shard_exchange(fseq_ctx *c, uint64_t words, int op)
 {
 	if (!c->sh.on) return FSEQ_OK;
-	if (words > c->sh.xwords) return fail(c, FSEQ_E_ARG, "exchange buffer too small (fseq_shard_xbuf_words)");
+	if (words + 1 > c->sh.xwords) return fail(c, FSEQ_E_ARG, "exchange buffer too small (fseq_shard_xbuf_words)");
+	int rc = shard_status(c, 0);
+	if (rc) return rc;
 	HIP_TRY(c, hipStreamSynchronize(c->stream));
 	if (c->sh.fn(c->sh.user, 0, words, op) != 0) return fail(c, FSEQ_E_HIP, "the caller's all-reduce failed");
 	return FSEQ_OK;
+}
+
+// a rank that failed on its own tells the others (best effort: its device may be what failed)
+void shard_post_failure(fseq_ctx *c, int code)
+{
+	if (!c->sh.on || code == FSEQ_OK || code == FSEQ_E_NO_REDUCTION || code == FSEQ_E_PEER) return;
+	std::string const keep = c->err;
+	(void) shard_status(c, (uint32_t) code);
+	c->err = keep;
 }
 
 // "every rank contributes its own slice": zero the buffer, copy my words [lo, hi) of src in, all-reduce (sum), copy
@@ -1303,6 +1373,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : c->nblocks;     // my blocks
 	uint32_t const my_blocks = b_hi - b_lo;
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
+	progress(c, FSEQ_STAGE_TRACEBACK, 0, n);
+	FSEQ_RANGE_PUSH("fseq pass 1: phases A + B (block keys, boundary states)");
 	bool const keyspace = c->bk_cap_words && my_blocks && !getenv("FSEQ_PHASE_A_CLASSIC");
 	if (keyspace && c->use_stream)
 	{
@@ -1337,6 +1409,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	else
 		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
+	if (char const *e = getenv("FSEQ_INJECT_FAILURE_RANK"))
+		if (sharded && (uint32_t) atoi(e) == sh.rank) return fail(c, FSEQ_E_OOM, "injected failure (FSEQ_INJECT_FAILURE_RANK)");
 	char const *const sync_env = getenv("FSEQ_SYNC_PHASES");             // diagnostic ("ABC"): a fault shows up at the phase that caused it
 	auto sync_at = [&](char ph) { return sync_env && strchr(sync_env, ph); };
 	if (sync_at('A')) { fprintf(stderr, "[fseq] phase A queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase A done\n"); }
@@ -1447,6 +1521,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
+	FSEQ_RANGE_POP();
+	progress(c, FSEQ_STAGE_TRACEBACK, n / 5, n);                  // (phases A and B queued: about a fifth of pass 1)
 	if (sync_at('B')) { fprintf(stderr, "[fseq] phase B queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase B done\n"); }
 	if (!p.list_cap && !c->X_hint)
 	{
@@ -1536,6 +1612,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			}
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[3], st));
+		FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
 		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
 			if (c->use_stream && c->s2.T)
 			{
@@ -1711,6 +1788,9 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			fprintf(stderr, "\n");
 		}
 #endif
+		FSEQ_RANGE_POP();
+		progress(c, FSEQ_STAGE_TRACEBACK, n, n);
+		FSEQ_RANGE_PUSH("fseq traceback + find_segments_greedy");
 		double const th0 = now_ms();
 		bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
 		c->tm.dp_sweeps = spec_sweeps;
@@ -1813,6 +1893,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			}
 		}
 		ms_host += now_ms() - th0;
+		FSEQ_RANGE_POP();
+		if (!overflow) progress(c, FSEQ_STAGE_MERGE, c->traceback.size(), c->traceback.size());
 		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: traceback + merge %.3f ms\n", now_ms() - th0);
 		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
 		if (!overflow) break;
@@ -1872,6 +1954,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		if (S2m) HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2m * 8, hipMemcpyHostToDevice, st));
 		if (!grp.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
+		progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
+		FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
 		if (grp.empty())
 		{
 		}
@@ -1893,6 +1977,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));
+		FSEQ_RANGE_POP();
+		progress(c, FSEQ_STAGE_SAMPLES, S2, S2);
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); ms_p2 = f;
 		if (sharded)
@@ -1944,12 +2030,12 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	double const t_begin = now_ms();
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nk = nullptr;
 	if ((rc = dev_alloc(c, &d_rank, m))) return rc;
-	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(&d_rank); return rc; }
-	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(&d_rank); dev_free(&d_keyd); return rc; }
+	if ((rc = dev_alloc(c, &d_keyd, m))) { dev_free(c, &d_rank); return rc; }
+	if ((rc = dev_alloc(c, &d_nk, 4))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); return rc; }
 	if (c->use_stream && !c->d_ws)
 	{
 		c->ws_words = (size_t) 4 * m;
-		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
 	}
 	// one block [0, n): ranked in key space (fseq_blockkeys.hpp); FSEQ_PHASE_A_CLASSIC: the per-column sweep
 	if (c->bk_cap_words && !getenv("FSEQ_PHASE_A_CLASSIC"))
@@ -1959,7 +2045,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 			size_t const per = (blockkeys_stream_ws_words(m, (uint32_t) p.n, c->bsh) + 15) & ~size_t(15);
 			if (c->bkws_words < per)
 			{
-				if ((rc = dev_alloc(c, &c->d_bkws, per))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+				if ((rc = dev_alloc(c, &c->d_bkws, per))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
 				c->bkws_words = per;
 			}
 			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
@@ -1970,7 +2056,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 			size_t const per = (blockkeys_scratch_halfwords(m, (uint32_t) p.n, c->bsh) + 7) & ~size_t(7);
 			if (c->bk_per_block != per || c->bk_blocks < 1)
 			{
-				if ((rc = dev_alloc(c, &c->d_bk, per))) { dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk); return rc; }
+				if ((rc = dev_alloc(c, &c->d_bk, per))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
 				c->bk_per_block = per; c->bk_blocks = 1;
 			}
 			launch_blockkeys(c->bk_T, st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr);
@@ -1981,7 +2067,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 		// the 16-bit LDS kernels keep block-relative divergences in 16 bits: one block of 65536 columns or more would wrap
 		if (!c->use_stream && c->ks.cap > 7168u && p.n > 65535u)
 		{
-			dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk);
+			dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk);
 			return fail(c, FSEQ_E_UNSUPPORTED, "short path by column sweep: more than 65535 columns with 16-bit LDS state (unset FSEQ_PHASE_A_CLASSIC)");
 		}
 		launch_rank(c, 1, (uint32_t) p.n, 1, d_rank, d_keyd, d_nk);
@@ -1991,7 +2077,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	hipError_t e1 = hipMemcpyAsync(rank.data(), d_rank, (size_t) m * 4, hipMemcpyDeviceToHost, st);
 	hipError_t e2 = hipMemcpyAsync(&nk, d_nk, 4, hipMemcpyDeviceToHost, st);
 	hipError_t e3 = hipStreamSynchronize(st);
-	dev_free(&d_rank); dev_free(&d_keyd); dev_free(&d_nk);
+	dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk);
 	if (e1 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path copy", e1);
 	if (e2 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path copy", e2);
 	if (e3 != hipSuccess) return fail(c, FSEQ_E_HIP, "short path sync", e3);
@@ -2036,6 +2122,7 @@ char const *fseq_strerror(int code)
 		case FSEQ_E_HIP: return "HIP runtime error";
 		case FSEQ_E_OOM: return "out of device memory";
 		case FSEQ_E_UNSUPPORTED: return "unsupported shape for this build";
+		case FSEQ_E_PEER: return "another rank of the sharded run failed";
 		default: return "unknown";
 	}
 }
@@ -2124,7 +2211,7 @@ static int check_borrowed_codes(fseq_ctx *c)
 		e = hipMemcpyAsync(&mx, d_mx, 4, hipMemcpyDeviceToHost, c->stream);
 	}
 	if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-	dev_free(&d_mx);
+	dev_free(c, &d_mx);
 	if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "checking the borrowed columns", e);
 	if (mx >= c->sigma)
 	{
@@ -2297,7 +2384,7 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 	if (!c->kernels_ready)
 	{
 		int rc = prepare_geometry(c);
-		if (rc) return rc;
+		if (rc) { shard_post_failure(c, rc); return rc; }
 	}
 	// generate_context::calculate_segmentation, generate_context.cc:386-389
 	if (c->p.n < 2 * c->p.segment_length)
@@ -2305,7 +2392,27 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 		if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "the short path (n < 2L) is one sweep and does not shard");
 		return run_short_path(c, res);
 	}
-	return run_long_path(c, res);
+	int const rc = run_long_path(c, res);
+	shard_post_failure(c, rc);                   // sharded: the other ranks learn of it in their next exchange
+	return rc;
+}
+
+/* replaces: nothing in the reference (one process, one address space).  A context that shares its device with other
+ * contexts or ranks plans its pass-2 stride states inside `bytes` of device memory in all (0 = whatever is free). */
+int fseq_set_progress(fseq_ctx *c, fseq_progress_fn fn, void *user)
+{
+	if (!c) return FSEQ_E_ARG;
+	c->progress_fn = fn; c->progress_user = user;
+	return FSEQ_OK;
+}
+uint64_t fseq_step_max(fseq_ctx const *c) { return c ? c->step_max.load(std::memory_order_relaxed) : 0; }
+uint64_t fseq_current_step(fseq_ctx const *c) { return c ? c->current_step.load(std::memory_order_relaxed) : 0; }
+
+int fseq_set_memory_budget(fseq_ctx *c, uint64_t bytes)
+{
+	if (!c) return FSEQ_E_ARG;
+	c->mem_budget = bytes;
+	return FSEQ_OK;
 }
 
 int fseq_run_segmentation_batch(fseq_ctx *const *ctxs, size_t count, fseq_result *results, int *return_codes)

@@ -36,11 +36,17 @@ class ShardTransport:
             return 0
         view = self.buf[offset:offset + count]
         rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+        # (uint32 words travel as int32: sums of one non-zero contribution are exact whatever the sign; maxima are only
+        # taken of small values -- list capacities, flags, presence and status words -- which must stay below 2^31)
         if self.via_host:
             h = view.cpu()
+            if op == 1:
+                assert int(h.min()) >= 0, "a MAX exchange carries a word >= 2^31"
             dist.all_reduce(h, op=rop)
             view.copy_(h)
         else:
+            if op == 1 and count <= 4096:
+                assert int(view.min()) >= 0, "a MAX exchange carries a word >= 2^31"
             dist.all_reduce(view, op=rop)
         torch.cuda.synchronize(self.buf.device)
         return 0

@@ -22,7 +22,9 @@
 extern "C" {
 #endif
 
-#define FSEQ_ABI_VERSION 1
+/* 2: fseq_timings grew (dp_chunks .. reserved), FSEQ_E_PEER, fseq_set_memory_budget, fseq_set_progress /
+ *    fseq_step_max / fseq_current_step; the fseq_debug_* entry points moved to include/fseq_debug.h */
+#define FSEQ_ABI_VERSION 2
 
 enum {
 	FSEQ_OK             = 0,
@@ -30,7 +32,8 @@ enum {
 	FSEQ_E_NO_REDUCTION = 2,   /* max segment size >= m: generate_context.cc:192-200 */
 	FSEQ_E_HIP          = 3,   /* HIP runtime error, see fseq_last_error */
 	FSEQ_E_OOM          = 4,
-	FSEQ_E_UNSUPPORTED  = 5    /* shape outside what this build's kernels cover (fails loudly, no CPU fallback) */
+	FSEQ_E_UNSUPPORTED  = 5,   /* shape outside what this build's kernels cover (fails loudly, no CPU fallback) */
+	FSEQ_E_PEER         = 6    /* sharded run: another rank failed; every rank returns from the same exchange */
 };
 
 typedef struct fseq_ctx fseq_ctx;
@@ -247,28 +250,25 @@ int  fseq_write_segments(fseq_ctx *ctx, uint8_t const *const *rows, int joining,
  * raw input sequences.  path NULL or "-" = stdout. */
 int  fseq_write_founders(fseq_ctx *ctx, uint8_t const *const *rows, uint32_t const *permutations, char const *path);
 
-/* The DP's round schedule (debug / tests of the host logic; no device needed): number of rounds for (L, n),
- * cells per round, and how many leading rounds only need the lists of columns < col_hi (what the host hands
- * to a resumed DP launch while later columns are still being produced). */
-int  fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi, uint32_t *n_rounds, uint32_t *cells_per_round,
-                            uint32_t *rounds_within, int *pipelined);
-/* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
-int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
-/* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */
-int  fseq_debug_block_state(fseq_ctx *ctx, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out);
-/* Per-column divergence list after column c: descending (value,count), up to list_cap+1 entries;
- * *n_entries, *cnt0 (count of value 0) and *complete (list reaches the smallest value). */
-int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_t *counts,
-                            uint32_t *n_entries, uint32_t *cnt0, uint32_t *complete);
-
-/* The restated rmq.hh (rmq<..., 64>, include/founder_sequences/rmq.hh:61-118, quirks included) on caller-supplied
- * keys, straight on the device routines the DP uses (debug / tests): the stack masks and the sparse table are
- * built in closed form from the keys, every query [beg, end) is answered by the HBM path (index_hbm) and, when
- * the array fits the LDS rings (count <= 4096), by the LDS path (index_lds, else 0xFFFFFFFF). */
-int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
-                    uint32_t *index_hbm, uint32_t *index_lds);
-
 int  fseq_get_timings(fseq_ctx const *ctx, fseq_timings *out);
+
+/* replaces: segmentation_lp_context::step_max() / current_step() (segmentation_lp_context.hh:122-127), which the
+ * reference's progress indicator polls from another thread, and the per-stage timestamps of generate_context.cc.
+ * The stages are the reference's: generate_traceback (pass 1 + DP; steps = columns), find_segments_greedy (steps =
+ * traceback entries), update_samples_to_traceback_positions (steps = merged boundaries).  Pass 1 runs as phases over
+ * all columns at once, so current_step moves at the phase boundaries (A, B, C, DP), scaled to columns.  Both counters
+ * may be read from any thread while fseq_run_segmentation runs; the optional callback is made from the calling thread
+ * at the same points (fn == NULL: none).  With the library built against roctx (the default build), every phase is
+ * also an roctx range (rocprofv3 --marker-trace). */
+enum { FSEQ_STAGE_TRACEBACK = 0, FSEQ_STAGE_MERGE = 1, FSEQ_STAGE_SAMPLES = 2 };
+typedef void (*fseq_progress_fn)(void *user, int stage, uint64_t current_step, uint64_t step_max);
+int      fseq_set_progress(fseq_ctx *ctx, fseq_progress_fn fn, void *user);
+uint64_t fseq_step_max(fseq_ctx const *ctx);
+uint64_t fseq_current_step(fseq_ctx const *ctx);
+
+/* A context that shares its device with other contexts or ranks keeps its device allocations -- the pass-2 stride
+ * states are sized from what is free -- inside `bytes` in all (0 = whatever is free on the device, the default). */
+int  fseq_set_memory_budget(fseq_ctx *ctx, uint64_t bytes);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,37 @@
+/* fseq_debug.h -- intermediate state of the HIP segmentation path, for parity tests and diagnostics.
+ * Not part of the drop-in boundary (include/fseq.h): nothing here replaces a call of the reference; the entry points
+ * are exported by the same library. */
+#ifndef FSEQ_DEBUG_H
+#define FSEQ_DEBUG_H
+
+#include "fseq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The DP's round schedule (debug / tests of the host logic; no device needed): number of rounds for (L, n),
+ * cells per round, and how many leading rounds only need the lists of columns < col_hi (what the host hands
+ * to a resumed DP launch while later columns are still being produced). */
+int  fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi, uint32_t *n_rounds, uint32_t *cells_per_round,
+                            uint32_t *rounds_within, int *pipelined);
+/* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
+int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
+/* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */
+int  fseq_debug_block_state(fseq_ctx *ctx, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out);
+/* Per-column divergence list after column c: descending (value,count), up to list_cap+1 entries;
+ * *n_entries, *cnt0 (count of value 0) and *complete (list reaches the smallest value). */
+int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_t *counts,
+                            uint32_t *n_entries, uint32_t *cnt0, uint32_t *complete);
+
+/* The restated rmq.hh (rmq<..., 64>, include/founder_sequences/rmq.hh:61-118, quirks included) on caller-supplied
+ * keys, straight on the device routines the DP uses (debug / tests): the stack masks and the sparse table are
+ * built in closed form from the keys, every query [beg, end) is answered by the HBM path (index_hbm) and, when
+ * the array fits the LDS rings (count <= 4096), by the LDS path (index_lds, else 0xFFFFFFFF). */
+int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
+                    uint32_t *index_hbm, uint32_t *index_lds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -17,21 +17,26 @@ def pkg():
     return importlib.import_module("founder-sequences_amd")
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "fseq.h")).read()
+def _declared_symbols(header="fseq.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fseq_[a-z_0-9]+)\s*\(", text)))
 
 
 def test_header_and_binding_agree(pkg):
-    assert _declared_symbols() == sorted(pkg.EXPORTS)
+    """include/fseq.h is the drop-in boundary, include/fseq_debug.h the intermediate state for tests: the binding names
+    every symbol of both, and nothing of the debug header is declared in the boundary header."""
+    assert sorted(_declared_symbols() + _declared_symbols("fseq_debug.h")) == sorted(pkg.EXPORTS)
+    assert _declared_symbols("fseq_debug.h") == sorted(pkg.DEBUG_EXPORTS)
+    assert not [s for s in _declared_symbols() if s.startswith("fseq_debug")]
 
 
 def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
-    for name in _declared_symbols():
+    for name in _declared_symbols() + _declared_symbols("fseq_debug.h"):
         assert hasattr(lib, name), name
-    assert lib.fseq_abi_version() == 1
+    assert lib.fseq_abi_version() == 2
+    assert lib.fseq_strerror(pkg.FSEQ_E_PEER).decode().startswith("another rank")
     assert lib.fseq_strerror(2).decode().startswith("unable to reduce")
 
 
@@ -48,7 +53,7 @@ def test_struct_layouts_match_header(pkg):
 def test_header_compiles_as_plain_c(tmp_path):
     import subprocess
     src = tmp_path / "t.c"
-    src.write_text('#include "fseq.h"\nint main(void){ fseq_params p; (void)p; return sizeof(fseq_segment) == 24 ? 0 : 1; }\n')
+    src.write_text('#include "fseq.h"\n#include "fseq_debug.h"\nint main(void){ fseq_params p; (void)p; return sizeof(fseq_segment) == 24 ? 0 : 1; }\n')
     exe = tmp_path / "t"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
     assert subprocess.run([str(exe)]).returncode == 0

@@ -151,3 +151,67 @@ def test_too_many_ranks_fail_together(pkg):
     ctx = pkg.SegmentationContext(m, n, L)
     with pytest.raises(pkg.FseqError):
         tw.attach(ctx, 3, "cuda:0")
+
+
+def test_a_failing_rank_fails_every_rank(pkg, monkeypatch):
+    """A rank that fails on its own (injected after phase A, where an out-of-memory would strike) posts its error code
+    in the status word every exchange starts with: it reports its own error, the others FSEQ_E_PEER -- all from matching
+    exchanges, so nobody is left waiting (the harness would hang here otherwise: no barrier is aborted for this)."""
+    monkeypatch.setenv("FSEQ_INJECT_FAILURE_RANK", "1")
+    fdist = importlib.import_module("founder-sequences_amd.dist")
+    m, n, L = 300, 6000, 25
+    msa = fso.synth_msa(fso.synth_spec(51, 8, 200, 2e-3, 0), m, n)
+    world = 3
+    tw = fdist.ThreadWorld(world)
+    ctxs = [pkg.SegmentationContext(m, n, L, block_len=50) for _ in range(world)]
+    codes = [None] * world
+
+    def work(r):
+        tw.attach(ctxs[r], r, "cuda:0")
+        ctxs[r].set_sequences(msa)
+        try:
+            ctxs[r].run()
+            codes[r] = 0
+        except pkg.FseqError as e:
+            codes[r] = e.code
+
+    ths = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ths)
+    assert codes == [pkg.FSEQ_E_PEER, 4, pkg.FSEQ_E_PEER]
+    assert len({c._transport.calls for c in ctxs}) == 1           # the same exchanges on every rank, the failing one included
+
+
+def test_sharded_borrowed_device_columns(pkg):
+    """Borrowed columns under sharding: every rank passes the columns [first, last) fseq_shard_columns reports, column
+    `first` at the base pointer (byte codes and 2-bit packed ones)."""
+    import torch
+    m, n, L, B = 300, 6000, 25, 50
+    msa = fso.synth_msa(fso.synth_spec(51, 8, 200, 2e-3, 0), m, n)
+    alphabet = np.sort(np.unique(msa))
+    lut = np.zeros(256, dtype=np.uint8)
+    lut[alphabet] = np.arange(len(alphabet), dtype=np.uint8)
+    codes = lut[msa]                                               # dense codes in byte order, as the library assigns them
+    for bits in (8, 2):
+        keep = []
+
+        def make_input(c):
+            c0, c1 = c.shard_columns()
+            if bits == 8:
+                ld = (m + 15) // 16 * 16                                                       # column-major, one code per byte
+                colmajor = np.zeros((c1 - c0, ld), dtype=np.uint8)
+                colmajor[:, :m] = codes[:, c0:c1].T
+                t = torch.from_numpy(colmajor).to("cuda:0")
+                keep.append(t)
+                c.set_device_columns(t.data_ptr(), ld, len(alphabet), keepalive=t)
+            else:
+                packed, ld = pkg.pack_columns(codes[:, c0:c1], 2)
+                t = torch.from_numpy(packed).to("cuda:0")
+                keep.append(t)
+                c.set_device_columns_packed(t.data_ptr(), ld, len(alphabet), 2, keepalive=t)
+
+        ctxs = run_world(pkg, 2, make_input, m, n, L, block_len=B)
+        check_against_oracle(pkg, ctxs, msa, L)
