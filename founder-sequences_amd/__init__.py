@@ -73,7 +73,7 @@ EXPORTS = [
     "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
-    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget",
+    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
 DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule"]
@@ -144,6 +144,7 @@ def load_library():
     L.fseq_rowshard_xbuf_words.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
     L.fseq_rowshard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fseq_rowshard_pbwt.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(u64)]
+    L.fseq_write_segments_host.argtypes = [vp, C.POINTER(vp), C.c_int, vp, vp, C.c_char_p]
     L.fseq_set_progress.argtypes = [vp, PROGRESS_FN, vp]
     L.fseq_step_max.restype = u64
     L.fseq_step_max.argtypes = [vp]

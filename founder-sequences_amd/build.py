@@ -46,11 +46,15 @@ CLI_OUT = os.path.join(HERE, "bin", "founder_sequences")
 def build_cli(force=False):
     """Host C++17 front end (same option surface as the reference CLI), linked against the C ABI."""
     build()
-    if not force and os.path.exists(CLI_OUT) and os.path.getmtime(CLI_OUT) >= max(os.path.getmtime(CLI_SRC), os.path.getmtime(OUT)):
+    deps = [CLI_SRC, OUT, os.path.join(HERE, "host", "fseq_shard_rccl.hpp"), os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
+    if not force and os.path.exists(CLI_OUT) and os.path.getmtime(CLI_OUT) >= max(os.path.getmtime(d) for d in deps):
         return CLI_OUT
     os.makedirs(os.path.dirname(CLI_OUT), exist_ok=True)
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-I", os.path.join(os.path.dirname(HERE), "include"), CLI_SRC,
-           "-o", CLI_OUT, "-L", HERE, "-lfseq_hip", "-Wl,-rpath,$ORIGIN/..", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib"]
+    # --gpus N shards one alignment over the node's GPUs: RCCL (ncclCommInitAll / ncclAllReduce) bound to the C ABI's
+    # exchange callback in host/fseq_shard_rccl.hpp, so the front end links librccl and the HIP runtime itself
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", "/opt/rocm/include",
+           CLI_SRC, "-o", CLI_OUT, "-L", HERE, "-lfseq_hip", "-Wl,-rpath,$ORIGIN/..", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
+           "-lrccl", "-lamdhip64", "-lpthread"]
     subprocess.run(cmd, check=True)
     return CLI_OUT
 

@@ -2580,6 +2580,9 @@ int fseq_random_join_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segm
 	return FSEQ_OK;
 }
 
+static int write_segments_impl(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *A_, uint32_t const *D_,
+                               std::vector<JoinSegment> const &segs, char const *path);
+
 int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, char const *path)
 {
 	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
@@ -2591,6 +2594,26 @@ int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, ch
 		int const rc = fetch_boundary_states(c, A, D, segs);
 		if (rc) return rc;
 	}
+	return write_segments_impl(c, rows, joining, A.data(), D.data(), segs, path);
+}
+
+// the same with the boundary states supplied by the caller (a sharded run: collected from their owners)
+int fseq_write_segments_host(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *a, uint32_t const *d, char const *path)
+{
+	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (joining != FSEQ_JOIN_GREEDY && (!rows || !a || !d)) return FSEQ_E_ARG;
+	std::vector<JoinSegment> segs;
+	if (joining != FSEQ_JOIN_GREEDY)
+	{
+		segs.resize(c->segments.size());
+		for (size_t i = 0; i < segs.size(); ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
+	}
+	return write_segments_impl(c, rows, joining, a, d, segs, path);
+}
+
+static int write_segments_impl(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *A_, uint32_t const *D_,
+                               std::vector<JoinSegment> const &segs, char const *path)
+{
 	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
 	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the segments output file");
 	size_t const m = c->p.m, S = segs.size();
@@ -2601,7 +2624,7 @@ int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, ch
 		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE\tSEQUENCES\tCOPIED_FROM\n", f);
 		for (size_t s = 0; s < S; ++s)
 		{
-			uint32_t const *a = A.data() + s * m, *d = D.data() + s * m;
+			uint32_t const *a = A_ + s * m, *d = D_ + s * m;
 			auto const texts = create_segment_texts((uint32_t) m, X, a, prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, true));
 			for (size_t i = 0; i < texts.size(); ++i)
 			{
@@ -2621,7 +2644,7 @@ int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, ch
 		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n", f);
 		for (size_t s = 0; FSEQ_JOIN_RANDOM == joining && s < S; ++s)
 		{
-			uint32_t const *a = A.data() + s * m, *d = D.data() + s * m;
+			uint32_t const *a = A_ + s * m, *d = D_ + s * m;
 			auto const cn = prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, false);
 			uint32_t prev = 0;
 			for (auto const &x : cn)

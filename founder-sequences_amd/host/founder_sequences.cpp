@@ -7,6 +7,7 @@
 // Joining: greedy (greedy_matcher.cc), bipartite-matching (bipartite_matcher.cc; an own Kuhn-Munkres
 // in place of Lemon 1.3.1's MaxWeightedPerfectMatching) and random (join_context.cc:259-289).
 #include <fseq.h>
+#include "fseq_shard_rccl.hpp"
 
 #include <getopt.h>
 
@@ -42,7 +43,8 @@ char const *const USAGE =
 	"  -m, --pbwt-sample-rate=q           On the first pass, store a PBWT sample every q*sqrt(n)-th position. Zero indicates no sampling.  (default=`4')\n"
 	"      --random-seed=LONG             Seed for the random number generator  (default=`0')\n"
 	"      --single-threaded              Use only one worker thread  (default=off)\n"
-	"      --print-invocation             Print the command line arguments to stderr  (default=off)\n";
+	"      --print-invocation             Print the command line arguments to stderr  (default=off)\n"
+	"      --gpus=N                       Shard the alignment over the first N GPUs of this node (RCCL)  (default=`1')\n";
 
 bool read_file(std::string const &path, std::string &out)
 {
@@ -102,6 +104,8 @@ int main(int argc, char **argv)
 	joining join = joining::BIPARTITE_MATCHING;
 	long seg_len = 0, sample_rate = 4, seed = 0;
 	bool seg_len_given = false, single_threaded = false, print_invocation = false;
+	long gpus = 1;
+	bool gpus_given = false;
 
 	static option const longopts[] = {
 		{"help", no_argument, nullptr, 'h'}, {"version", no_argument, nullptr, 'V'},
@@ -110,6 +114,7 @@ int main(int argc, char **argv)
 		{"segment-length-bound", required_argument, nullptr, 's'}, {"segment-joining", required_argument, nullptr, 'j'},
 		{"pbwt-sample-rate", required_argument, nullptr, 'm'}, {"random-seed", required_argument, nullptr, 1000},
 		{"single-threaded", no_argument, nullptr, 1001}, {"print-invocation", no_argument, nullptr, 1002},
+		{"gpus", required_argument, nullptr, 1003},
 		{nullptr, 0, nullptr, 0}};
 	int c;
 	while ((c = getopt_long(argc, argv, "hVi:f:e:o:s:j:m:", longopts, nullptr)) != -1)
@@ -137,6 +142,7 @@ int main(int argc, char **argv)
 			case 1000: seed = strtol(optarg, nullptr, 10); break;
 			case 1001: single_threaded = true; break;
 			case 1002: print_invocation = true; break;
+			case 1003: gpus = strtol(optarg, nullptr, 10); gpus_given = true; break;
 			default: return EXIT_FAILURE;
 		}
 	}
@@ -158,6 +164,7 @@ int main(int argc, char **argv)
 	if (!(0 <= seed && (unsigned long) seed <= std::numeric_limits<std::uint_fast32_t>::max()))
 	{ std::cerr << "Random seed out of bounds." << std::endl; return EXIT_FAILURE; }
 	if (sample_rate <= 0) { std::cerr << "PBWT sample rate multiplier must be non-negative." << std::endl; return EXIT_FAILURE; }
+	if (gpus < 1 || gpus > 64) { std::cerr << "The number of GPUs must be positive." << std::endl; return EXIT_FAILURE; }
 
 	// generate_context.cc:64-106
 	std::cerr << "Loading the input…" << std::flush;
@@ -185,17 +192,53 @@ int main(int argc, char **argv)
 	p.n = seq_length;
 	p.segment_length = (uint64_t) seg_len;
 	p.pbwt_sample_rate = (uint64_t) sample_rate;
-	fseq_ctx *ctx = nullptr;
-	int rc = fseq_create(&p, &ctx);
-	if (FSEQ_OK != rc) { std::cerr << "Unable to initialise the GPU engine: " << fseq_strerror(rc) << std::endl; return EXIT_FAILURE; }
 	std::vector<uint8_t const *> rows(seqs.size());
 	for (size_t i = 0; i < seqs.size(); ++i) rows[i] = reinterpret_cast<uint8_t const *>(seqs[i].data());
-	std::cerr << "Generating a compressed alphabet…" << std::endl;
-	if (FSEQ_OK != (rc = fseq_set_rows(ctx, rows.data()))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
+	bool const sharded = gpus > 1 && p.n >= 2 * p.segment_length;      // (the short path is one sweep: it does not shard)
+	if (gpus > 1 && !sharded) std::cerr << "The sequences are shorter than two segments; using one GPU." << std::endl;
 
+	// One context per rank.  --gpus N: every rank on its own thread and device, RCCL for the exchanges
+	// (fseq_shard_rccl.hpp); the ranks make the same calls in the same order and get the same result.
+	fseq_host::rccl_world world;
+	std::vector<fseq_ctx *> ctxs(sharded ? (size_t) gpus : 1, nullptr);
+	std::vector<fseq_result> results(ctxs.size());
+	int rc = FSEQ_OK;
+	if (sharded || gpus_given)
+	{
+		// (--gpus 1 still makes the communicator and runs the one-word all-reduce: the transport is checked wherever it is asked for)
+		std::string err;
+		if (!world.init(sharded ? (int) gpus : 1, err) || !world.self_test(err)) { std::cerr << err << std::endl; return EXIT_FAILURE; }
+		std::cerr << "RCCL: " << world.world() << " rank(s), self-test passed." << std::endl;
+	}
+	std::cerr << "Generating a compressed alphabet…" << std::endl;
 	std::cerr << "Calculating the segmentation…" << std::endl;
-	fseq_result res{};
-	rc = fseq_run_segmentation(ctx, &res);
+	auto run_rank = [&](int r) -> int {
+		fseq_params pr(p);
+		pr.device = r;
+		int rc_(fseq_create(&pr, &ctxs[r]));
+		if (FSEQ_OK != rc_) return rc_;
+		if (sharded && FSEQ_OK != (rc_ = world.attach(ctxs[r], r))) return rc_;
+		if (FSEQ_OK != (rc_ = fseq_set_rows(ctxs[r], rows.data()))) return rc_;
+		return fseq_run_segmentation(ctxs[r], &results[r]);
+	};
+	if (sharded)
+	{
+		std::vector<int> const rcs(world.run(run_rank));
+		for (size_t r = 0; r < rcs.size(); ++r)
+			if (FSEQ_OK != rcs[r] && FSEQ_E_NO_REDUCTION != rcs[r])
+			{
+				// (a rank that failed on its own reports its error, the others FSEQ_E_PEER: print the cause)
+				if (FSEQ_E_PEER != rcs[r] || FSEQ_OK == rc || FSEQ_E_PEER == rc) rc = rcs[r];
+				std::cerr << "rank " << r << ": " << (ctxs[r] ? fseq_last_error(ctxs[r]) : fseq_strerror(rcs[r])) << std::endl;
+			}
+		if (FSEQ_OK == rc) rc = rcs[0];
+		if (FSEQ_OK != rc && FSEQ_E_NO_REDUCTION != rc) return EXIT_FAILURE;
+	}
+	else
+		rc = run_rank(0);
+	fseq_ctx *ctx = ctxs[0];
+	fseq_result res(results[0]);
+	if (!ctx) { std::cerr << "Unable to initialise the GPU engine: " << fseq_strerror(rc) << std::endl; return EXIT_FAILURE; }
 	if (FSEQ_E_NO_REDUCTION == rc)
 	{
 		// generate_context.cc:192-200
@@ -231,6 +274,31 @@ int main(int argc, char **argv)
 	          << " segments the maximum size of which was " << res.max_segment_size << '.' << std::endl;
 	std::cerr << "Joining the remaining segments…" << std::endl;
 	std::vector<uint32_t> perm((size_t) res.segment_count * res.max_segment_size);
+	std::vector<uint32_t> all_a, all_d;                         // sharded: the boundary states, collected from their owners
+	std::vector<fseq_segment> segments;
+	if (sharded)
+	{
+		size_t const S(res.segment_count), m(p.m);
+		segments.resize(S);
+		if (FSEQ_OK != (rc = fseq_get_segments(ctx, segments.data()))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
+		all_a.resize(S * m); all_d.resize(S * m);
+		std::vector<uint64_t> lbs(S), rbs(S);
+		for (size_t i = 0; i < S; ++i)
+		{
+			lbs[i] = segments[i].lb; rbs[i] = segments[i].rb;
+			uint32_t owner(0);
+			if (FSEQ_OK != (rc = fseq_shard_owner(ctx, segments[i].rb, &owner)) ||
+			    FSEQ_OK != (rc = fseq_boundary_state(ctxs[owner], i, all_a.data() + i * m, all_d.data() + i * m)))
+			{ std::cerr << fseq_last_error(ctxs[owner < ctxs.size() ? owner : 0]) << std::endl; return EXIT_FAILURE; }
+		}
+		switch (join)
+		{
+			case joining::GREEDY: rc = fseq_greedy_match_host(p.m, res.max_segment_size, S, lbs.data(), rbs.data(), all_a.data(), all_d.data(), perm.data()); break;
+			case joining::BIPARTITE_MATCHING: rc = fseq_bipartite_match_host(p.m, res.max_segment_size, S, lbs.data(), rbs.data(), all_a.data(), all_d.data(), perm.data(), nullptr); break;
+			case joining::RANDOM: rc = fseq_random_join_host(p.m, res.max_segment_size, S, lbs.data(), rbs.data(), all_a.data(), all_d.data(), (uint32_t) seed, perm.data()); break;
+		}
+	}
+	else
 	switch (join)                                               // join_context.cc:130-160
 	{
 		case joining::GREEDY: rc = fseq_join_greedy(ctx, perm.data()); break;
@@ -246,9 +314,11 @@ int main(int argc, char **argv)
 		// header is written (join_context.cc:57-61, greedy_matcher.cc:468-476)
 		std::cerr << "Outputting the segments…" << std::endl;
 		int const how = joining::GREEDY == join ? FSEQ_JOIN_GREEDY : (joining::RANDOM == join ? FSEQ_JOIN_RANDOM : FSEQ_JOIN_BIPARTITE);
-		if (FSEQ_OK != (rc = fseq_write_segments(ctx, rows.data(), how, out_segments))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
+		rc = sharded ? fseq_write_segments_host(ctx, rows.data(), how, all_a.data(), all_d.data(), out_segments)
+		             : fseq_write_segments(ctx, rows.data(), how, out_segments);
+		if (FSEQ_OK != rc) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	}
 	std::cerr << "Done." << std::endl;
-	fseq_destroy(ctx);
+	for (fseq_ctx *c_ : ctxs) if (c_) fseq_destroy(c_);
 	return EXIT_SUCCESS;
 }

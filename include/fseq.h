@@ -245,6 +245,9 @@ int  fseq_random_join_host(uint32_t m, uint32_t max_segment_size, uint64_t n_seg
  * number).  path NULL or "-" = stdout. */
 enum { FSEQ_JOIN_GREEDY = 0, FSEQ_JOIN_BIPARTITE = 1, FSEQ_JOIN_RANDOM = 2 };
 int  fseq_write_segments(fseq_ctx *ctx, uint8_t const *const *rows, int joining, char const *path);
+/* The same with the boundary states supplied by the caller (S' x m words each, segment-major): a sharded run, where
+ * they sit on their owner ranks (fseq_shard_owner / fseq_boundary_state) and the host collects them. */
+int  fseq_write_segments_host(fseq_ctx *ctx, uint8_t const *const *rows, int joining, uint32_t const *a, uint32_t const *d, char const *path);
 /* replaces: join_context::output_in_permutation_order (join_context.cc:333-356): max_segment_size
  * lines; line r = concatenation over segments of rows[permutations[s][r]][lb_s, rb_s).  rows = the
  * raw input sequences.  path NULL or "-" = stdout. */

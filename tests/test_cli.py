@@ -163,3 +163,40 @@ def test_founders_cover_every_input_sequence(cli, tmp_path):
         for s in range(m):
             mine = [(int(x[1]), int(x[2])) for x in rows if int(x[0]) == s]
             assert mine[0][0] == 0 and mine[-1][1] == n and all(a[1] == b[0] for a, b in zip(mine, mine[1:]))
+
+
+def _write_fasta(path, msa):
+    with open(path, "wb") as f:
+        for i in range(msa.shape[0]):
+            f.write(b">s%d\n" % i + bytes(msa[i]) + b"\n")
+
+
+@pytest.mark.gpu
+def test_gpus_option_binds_rccl(cli, tmp_path):
+    """--gpus N (host/fseq_shard_rccl.hpp): the C++17 front end makes the RCCL communicator (ncclCommInitAll), proves it
+    with a one-word all-reduce and shards the alignment over N devices.  N = 1 on every box: same outputs as without the
+    option; N = 2 where the node has two GPUs: founders and segments files identical to the one-GPU run for all three
+    joiners (boundary states collected from their owner ranks, host joiners)."""
+    import torch
+    msa = np.ascontiguousarray(fso.synth_msa(fso.synth_spec(51, 8, 200, 2e-3), 300, 6000))
+    fa = tmp_path / "in.fa"
+    _write_fasta(fa, msa)
+    outs = {}
+    for gpus in (0, 1, 2):
+        if gpus == 2 and torch.cuda.device_count() < 2:
+            continue
+        for j in ("greedy", "bipartite-matching", "random"):
+            fo, se = tmp_path / ("f_%d_%s.txt" % (gpus, j)), tmp_path / ("s_%d_%s.txt" % (gpus, j))
+            args = ["-i", str(fa), "-f", "FASTA", "-s", "25", "-j", j, "-o", str(fo), "-e", str(se), "--random-seed", "7"]
+            if gpus:
+                args += ["--gpus", str(gpus)]
+            r = run(cli, *args)
+            assert r.returncode == 0, r.stderr
+            if gpus:
+                assert b"RCCL: %d rank(s), self-test passed." % gpus in r.stderr
+            outs[(gpus, j)] = (fo.read_bytes(), se.read_bytes())
+    assert outs[(0, "greedy")][0] == _expected(msa, 25)
+    for (gpus, j), v in outs.items():
+        assert v == outs[(0, j)], (gpus, j)
+    r = run(cli, "-i", str(fa), "-f", "FASTA", "-s", "25", "--gpus", "63")
+    assert r.returncode == 1 and b"the node has" in r.stderr
