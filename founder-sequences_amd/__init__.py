@@ -61,6 +61,11 @@ class Timings(C.Structure):
                 ("dp_chunks", C.c_uint32), ("dp_sweeps", C.c_uint32), ("phase_a_fallbacks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class JoinProfile(C.Structure):
+    _fields_ = [("ms_d2h", C.c_double), ("ms_classes", C.c_double), ("ms_edges", C.c_double), ("ms_draw", C.c_double), ("ms_total", C.c_double),
+                ("bytes_d2h", C.c_uint64)]
+
+
 SEGMENT_DTYPE = np.dtype([("lb", "<u8"), ("rb", "<u8"), ("segment_size", "<u4"), ("reserved", "<u4")])
 DPARG_DTYPE = np.dtype([("lb", "<u8"), ("rb", "<u8"), ("segment_max_size", "<u4"), ("segment_size", "<u4")])
 
@@ -73,7 +78,7 @@ EXPORTS = [
     "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
-    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host",
+    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
 DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule"]
@@ -145,6 +150,7 @@ def load_library():
     L.fseq_rowshard_rows.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.fseq_rowshard_pbwt.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(u64)]
     L.fseq_write_segments_host.argtypes = [vp, C.POINTER(vp), C.c_int, vp, vp, C.c_char_p]
+    L.fseq_get_join_profile.argtypes = [vp, C.POINTER(JoinProfile)]
     L.fseq_set_progress.argtypes = [vp, PROGRESS_FN, vp]
     L.fseq_step_max.restype = u64
     L.fseq_step_max.argtypes = [vp]
@@ -504,6 +510,12 @@ class SegmentationContext:
         self._check(self.L.fseq_debug_column_list(self.h, col, v.ctypes.data, c.ctypes.data,
                                                   C.byref(ne), C.byref(c0), C.byref(comp)))
         return v[:ne.value].copy(), c[:ne.value].copy(), c0.value, bool(comp.value)
+
+    def join_profile(self):
+        """Host time of the last join_*() call: {ms_d2h, ms_classes, ms_edges, ms_draw, ms_total, bytes_d2h}."""
+        jp = JoinProfile()
+        self._check(self.L.fseq_get_join_profile(self.h, C.byref(jp)))
+        return {k: getattr(jp, k) for k, _ in JoinProfile._fields_}
 
     def timings(self):
         t = Timings()

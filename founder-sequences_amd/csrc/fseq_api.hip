@@ -15,6 +15,7 @@
 #include "fseq_blockkeys.hpp"
 #include "fseq_rowshard.hpp"
 #include "fseq_join.hpp"
+#include "fseq_joinprep.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -292,6 +293,7 @@ struct fseq_ctx {
 	size_t alloc_total = 0;
 	uint64_t mem_budget = 0;                  // fseq_set_memory_budget: 0 = whatever is free on the device
 	std::atomic<uint64_t> step_max{0}, current_step{0};      // fseq_step_max / fseq_current_step (segmentation_lp_context.hh:122-127)
+	fseq_join_profile jp{};                  // the last joiner call (fseq_get_join_profile)
 	fseq_progress_fn progress_fn = nullptr;
 	void *progress_user = nullptr;
 	hipStream_t stream = nullptr;
@@ -2399,6 +2401,13 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 
 /* replaces: nothing in the reference (one process, one address space).  A context that shares its device with other
  * contexts or ranks plans its pass-2 stride states inside `bytes` of device memory in all (0 = whatever is free). */
+int fseq_get_join_profile(fseq_ctx const *c, fseq_join_profile *out)
+{
+	if (!c || !out) return FSEQ_E_ARG;
+	*out = c->jp;
+	return FSEQ_OK;
+}
+
 int fseq_set_progress(fseq_ctx *c, fseq_progress_fn fn, void *user)
 {
 	if (!c) return FSEQ_E_ARG;
@@ -2511,12 +2520,70 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use fseq_greedy_match_host");
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m, S = c->segments.size();
+	double const t0 = now_ms();
+	uint32_t const X = c->res.max_segment_size;
+	if (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !getenv("FSEQ_JOIN_HOST"))
+	{
+		// class tables and co-occurrence edges where the boundary states are (fseq_joinprep.hpp); the host hands out
+		// the copies and draws the edges (the serial part of greedy_matcher.cc)
+		hipStream_t st = c->stream;
+		uint16_t *d_of = nullptr;
+		uint32_t *d_rep = nullptr, *d_size = nullptr, *d_count = nullptr, *d_off = nullptr, *d_ne = nullptr;
+		uint64_t *d_rb = nullptr;
+		uint2 *d_edges = nullptr;
+		unsigned long long *d_cursor = nullptr;
+		uint64_t const cap_total = (uint64_t) (S > 1 ? S - 1 : 0) * std::min<uint64_t>(m, (uint64_t) X * X) + 1;
+		int rc;
+		auto cleanup = [&]() { dev_free(c, &d_of); dev_free(c, &d_rep); dev_free(c, &d_size); dev_free(c, &d_count); dev_free(c, &d_off); dev_free(c, &d_ne);
+		                       dev_free(c, &d_rb); dev_free(c, &d_edges); dev_free(c, &d_cursor); };
+		if ((rc = dev_alloc(c, &d_of, S * m)) || (rc = dev_alloc(c, &d_rep, S * X)) || (rc = dev_alloc(c, &d_size, S * X)) || (rc = dev_alloc(c, &d_count, S)) ||
+		    (rc = dev_alloc(c, &d_off, S)) || (rc = dev_alloc(c, &d_ne, S)) || (rc = dev_alloc(c, &d_rb, S)) || (rc = dev_alloc(c, &d_edges, cap_total)) ||
+		    (rc = dev_alloc(c, &d_cursor, 1)))
+		{ cleanup(); return rc; }
+		std::vector<uint64_t> rbs(S);
+		for (size_t i = 0; i < S; ++i) rbs[i] = c->segments[i].rb;
+		hipError_t e = hipMemcpyAsync(d_rb, rbs.data(), S * 8, hipMemcpyHostToDevice, st);
+		if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, 8, st);
+		if (e == hipSuccess) e = hipMemsetAsync(d_rep, 0, S * X * 4, st);
+		size_t const lds = (size_t) X * X * 4;
+		if (e == hipSuccess) e = allow_lds(k_join_edges, lds);
+		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "join preparation", e); }
+		hipLaunchKernelGGL(k_join_classes, dim3((uint32_t) S), dim3(JP_T), 0, st, c->d_snap_a, c->d_snap_d, d_rb, (uint32_t) m, X, d_of, d_rep, d_size, d_count);
+		if (S > 1)
+			hipLaunchKernelGGL(k_join_edges, dim3((uint32_t) (S - 1)), dim3(JP_T), lds, st, d_of, d_count, (uint32_t) m, d_edges, cap_total, d_off, d_ne, d_cursor);
+		std::vector<uint32_t> count(S), rep(S * X), size(S * X), off(S), ne(S);
+		unsigned long long total = 0;
+		e = hipMemcpyAsync(count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(rep.data(), d_rep, S * X * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(size.data(), d_size, S * X * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && S > 1) e = hipMemcpyAsync(off.data(), d_off, (S - 1) * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess && S > 1) e = hipMemcpyAsync(ne.data(), d_ne, (S - 1) * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, 8, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e == hipSuccess) e = hipGetLastError();
+		std::vector<uint32_t> edge_words(2 * (size_t) total + 2);
+		bool sane = e == hipSuccess && total < cap_total;
+		for (size_t i = 0; sane && i < S; ++i) sane = count[i] >= 1 && count[i] <= X;
+		if (sane && total) e = hipMemcpy(edge_words.data(), d_edges, (size_t) total * 8, hipMemcpyDeviceToHost);
+		cleanup();
+		if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "join preparation", e);
+		if (!sane) return fail(c, FSEQ_E_HIP, "internal: join preparation produced class tables that do not fit max_segment_size");
+		double const t1 = now_ms();
+		JoinProfile prof;
+		greedy_match_prepared(c->p.m, X, S, count.data(), rep.data(), size.data(), edge_words.data(), off.data(), ne.data(), permutations, &prof);
+		c->jp = fseq_join_profile{t1 - t0, prof.ms_classes, prof.ms_edges, prof.ms_draw, now_ms() - t0,
+		                          (uint64_t) S * (2ull * X + 3) * 4 + (uint64_t) total * 8};
+		return FSEQ_OK;
+	}
 	std::vector<uint32_t> A(S * m), D(S * m);
 	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
 	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
+	double const t1 = now_ms();
 	std::vector<JoinSegment> segs(S);
 	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
-	greedy_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations);
+	JoinProfile prof;
+	greedy_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations, &prof);
+	c->jp = fseq_join_profile{t1 - t0, prof.ms_classes, prof.ms_edges, prof.ms_draw, now_ms() - t0, (uint64_t) S * m * 8ull};
 	return FSEQ_OK;
 }
 
@@ -2528,9 +2595,11 @@ static int fetch_boundary_states(fseq_ctx *c, std::vector<uint32_t> &A, std::vec
 	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use the *_match_host entry points");
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m, S = c->segments.size();
+	double const t0 = now_ms();
 	A.resize(S * m); D.resize(S * m);
 	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
 	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
+	c->jp = fseq_join_profile{now_ms() - t0, 0, 0, 0, 0, (uint64_t) S * m * 8ull};
 	segs.resize(S);
 	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
 	return FSEQ_OK;
@@ -2543,7 +2612,9 @@ int fseq_join_bipartite(fseq_ctx *c, uint32_t *permutations)
 	std::vector<JoinSegment> segs;
 	int const rc = fetch_boundary_states(c, A, D, segs);
 	if (rc) return rc;
+	double const t0 = now_ms();
 	bipartite_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations);
+	c->jp.ms_draw = now_ms() - t0; c->jp.ms_total = c->jp.ms_d2h + c->jp.ms_draw;
 	return FSEQ_OK;
 }
 
@@ -2554,7 +2625,9 @@ int fseq_join_random(fseq_ctx *c, uint32_t seed, uint32_t *permutations)
 	std::vector<JoinSegment> segs;
 	int const rc = fetch_boundary_states(c, A, D, segs);
 	if (rc) return rc;
+	double const t0 = now_ms();
 	random_join(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), seed, permutations);
+	c->jp.ms_draw = now_ms() - t0; c->jp.ms_total = c->jp.ms_d2h + c->jp.ms_draw;
 	return FSEQ_OK;
 }
 

@@ -15,6 +15,9 @@
 #include <random>
 #include <utility>
 #include <vector>
+#include <atomic>
+#include <chrono>
+#include <thread>
 #include <algorithm>
 
 namespace fseq {
@@ -104,17 +107,30 @@ struct Edge { uint32_t l, r, rows; };
 
 } // namespace join_detail
 
+// where a joiner's host time goes (fseq_get_join_profile): the class tables (greedy_matcher.cc:31-68), the
+// co-occurrence edges (:295-343), the rounds that draw them (:353-439)
+struct JoinProfile {
+	double ms_classes = 0, ms_edges = 0, ms_draw = 0;
+	static double now()
+	{
+		using namespace std::chrono;
+		return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+	}
+};
+
 // A, D: segment_count x m (input_permutation / input_divergence at each segment's rb).
 // permutations: segment_count x max_segment_size, permutations[s][row] = input row whose substring
 // [lb_s, rb_s) is placed in founder `row`.
 inline void greedy_match(
 	uint32_t const seq_count, uint32_t const max_segment_size, std::vector<JoinSegment> const &segs,
-	uint32_t const *A, uint32_t const *D, uint32_t *permutations)
+	uint32_t const *A, uint32_t const *D, uint32_t *permutations, JoinProfile *prof = nullptr)
 {
 	using namespace join_detail;
 	uint32_t const m = seq_count, X = max_segment_size;
 	if (segs.empty()) return;
 	std::fill(permutations, permutations + segs.size() * (size_t) X, 0u);
+	double t_mark = prof ? JoinProfile::now() : 0;
+	auto lap = [&](double JoinProfile::*field) { if (prof) { double const t = JoinProfile::now(); prof->*field += t - t_mark; t_mark = t; } };
 
 	ClassTable L, R;
 	SlotQueues lq, rq;
@@ -141,8 +157,10 @@ inline void greedy_match(
 	{
 		uint32_t const *a = A + s * (size_t) m, *d = D + s * (size_t) m;
 		uint32_t *perm = permutations + s * (size_t) X;
+		lap(&JoinProfile::ms_draw);
 		R.build(m, seg_start, a, d, X);
 		rq.reset(R.count);
+		lap(&JoinProfile::ms_classes);
 
 		// co-occurrence edges: how many rows go from lhs class l to rhs class r
 		for (uint32_t row = 0; row < m; ++row) keys[row] = ((uint64_t) L.of_row[row] << 32) | R.of_row[row];
@@ -161,6 +179,7 @@ inline void greedy_match(
 		for (uint32_t v = 0; v <= m; ++v) bucket[v + 1] += bucket[v];
 		ordered.resize(edges.size());
 		for (Edge const &e : edges) ordered[bucket[m - e.rows]++] = e;
+		lap(&JoinProfile::ms_edges);
 
 		std::vector<uint32_t> &lhs_left = L.copies;            // copies of an lhs class not yet continued
 		std::vector<uint32_t> rhs_left = R.copies;             // copies of an rhs class not yet placed
@@ -202,6 +221,114 @@ inline void greedy_match(
 		std::swap(L, R);
 		std::swap(lq, rq);
 		seg_start = segs[s].rb;
+	}
+	lap(&JoinProfile::ms_draw);
+}
+
+// The same joiner on class tables and edge lists that were built elsewhere (on the device: fseq_joinprep.hpp).
+// count[s] classes of segment s with rep / size at [s * X + c]; the edges of the pair (s - 1, s) at
+// edges[offset[s - 1] .. + nedges[s - 1]) as {l << 16 | r, rows} in ascending (l, r) order.
+inline void greedy_match_prepared(
+	uint32_t const seq_count, uint32_t const max_segment_size, size_t const S,
+	uint32_t const *count, uint32_t const *rep, uint32_t const *size, uint32_t const *edge_words /* 2 per edge */,
+	uint32_t const *offset, uint32_t const *nedges, uint32_t *permutations, JoinProfile *prof = nullptr)
+{
+	using namespace join_detail;
+	uint32_t const m = seq_count, X = max_segment_size;
+	if (0 == S) return;
+	std::fill(permutations, permutations + S * (size_t) X, 0u);
+	double t_mark = prof ? JoinProfile::now() : 0;
+	auto lap = [&](double JoinProfile::*field) { if (prof) { double const t = JoinProfile::now(); prof->*field += t - t_mark; t_mark = t; } };
+	// copies of every class (ClassTable::build's second half): every class one slot, the spare ones in rounds over the
+	// classes in descending size
+	std::vector<uint32_t> start, order;
+	auto copies_of = [&](size_t s, std::vector<uint32_t> &copies) {
+		uint32_t const cnt = count[s];
+		uint32_t const *sz = size + s * (size_t) X;
+		start.assign(m + 2, 0); order.resize(cnt);
+		for (uint32_t c = 0; c < cnt; ++c) ++start[m - sz[c] + 1];
+		for (uint32_t v = 0; v <= m; ++v) start[v + 1] += start[v];
+		for (uint32_t c = 0; c < cnt; ++c) order[start[m - sz[c]]++] = c;
+		copies.assign(cnt, 1);
+		size_t const spare = X - cnt;
+		size_t left = spare;
+		while (left)
+			for (uint32_t k = 0; k < cnt && left; ++k)
+			{
+				uint32_t const c = order[k];
+				size_t const give = std::min(left, size_t(std::ceil(1.0 * sz[c] / m * spare)));
+				copies[c] += (uint32_t) give;
+				left -= give;
+			}
+	};
+	SlotQueues lq, rq;
+	std::vector<uint32_t> next(X, NIL), lhs_left, rhs_copies, rhs_left, bucket;
+	std::vector<Edge> ordered;
+	copies_of(0, lhs_left);
+	lq.reset(count[0]);
+	{
+		uint32_t slot = 0;
+		for (uint32_t c = 0; c < count[0]; ++c)
+			for (uint32_t k = 0; k < lhs_left[c]; ++k, ++slot)
+			{
+				permutations[slot] = rep[c];
+				lq.push(next, c, slot);
+			}
+	}
+	lap(&JoinProfile::ms_classes);
+	for (size_t s = 1; s < S; ++s)
+	{
+		uint32_t *perm = permutations + s * (size_t) X;
+		uint32_t const LC = count[s - 1], RC = count[s];
+		uint32_t const *rrep = rep + s * (size_t) X;
+		copies_of(s, rhs_copies);
+		rq.reset(RC);
+		lap(&JoinProfile::ms_classes);
+		// edges by descending row count, pairs ascending within a count (they arrive in ascending pair order)
+		uint32_t const ne = nedges[s - 1];
+		uint32_t const *ew = edge_words + 2 * (size_t) offset[s - 1];
+		bucket.assign(m + 2, 0);
+		for (uint32_t i = 0; i < ne; ++i) ++bucket[m - ew[2 * i + 1] + 1];
+		for (uint32_t v = 0; v <= m; ++v) bucket[v + 1] += bucket[v];
+		ordered.resize(ne);
+		for (uint32_t i = 0; i < ne; ++i) ordered[bucket[m - ew[2 * i + 1]]++] = Edge{ew[2 * i] >> 16, ew[2 * i] & 0xFFFFu, ew[2 * i + 1]};
+		lap(&JoinProfile::ms_edges);
+		rhs_left = rhs_copies;
+		auto connect = [&](uint32_t l, uint32_t r) {
+			uint32_t const slot = lq.pop(next, l);
+			rq.push(next, r, slot);
+			perm[slot] = rrep[r];
+			--lhs_left[l];
+			--rhs_left[r];
+		};
+		size_t alive = ordered.size();
+		bool drew = true;
+		while (drew)
+		{
+			drew = false;
+			size_t keep = 0;
+			for (size_t i = 0; i < alive; ++i)
+			{
+				Edge const e = ordered[i];
+				if (lhs_left[e.l] && rhs_left[e.r])
+				{
+					connect(e.l, e.r);
+					ordered[keep++] = e;
+					drew = true;
+				}
+			}
+			alive = keep;
+		}
+		for (uint32_t l = 0, r = 0;;)
+		{
+			while (l < LC && 0 == lhs_left[l]) ++l;
+			while (r < RC && 0 == rhs_left[r]) ++r;
+			if (l == LC || r == RC) break;
+			connect(l, r);
+		}
+		lhs_left.swap(rhs_copies);                             // the rhs classes' copies are the next pair's lhs copies
+		std::swap(lq, rq);
+		lap(&JoinProfile::ms_draw);
 	}
 }
 
@@ -406,12 +533,29 @@ inline void bipartite_match(
 {
 	size_t const X = max_segment_size, S = segs.size();
 	if (0 == S) return;
+	// The segment texts of every segment and the matching of every adjacent pair are independent of each other (the
+	// reference runs them as concurrent tasks too: create_segment_texts_task / merge_segments_task on a dispatch queue);
+	// only the chaining of the permutations is serial.  On BASELINE C3 the 6,150 Kuhn-Munkres solves were 1.27 s of
+	// one host thread against 10 ms of segmentation.
 	std::vector<std::vector<SegmentText>> texts(S);
-	for (size_t s = 0; s < S; ++s)
-	{
+	std::vector<std::vector<uint32_t>> matchings(S);
+	std::vector<int64_t> totals(S, 0);
+	size_t const workers = std::max<size_t>(1, std::min<size_t>({(size_t) std::thread::hardware_concurrency(), (size_t) 32, S}));
+	auto parallel_for = [&](size_t lo, size_t hi, auto &&body) {
+		std::atomic<size_t> next{lo};
+		auto work = [&]() { for (size_t i; (i = next.fetch_add(1)) < hi;) body(i); };
+		std::vector<std::thread> ths;
+		for (size_t t = 1; t < workers; ++t) ths.emplace_back(work);
+		work();
+		for (auto &th : ths) th.join();
+	};
+	parallel_for(0, S, [&](size_t s) {
 		uint32_t const *a = A + s * (size_t) seq_count, *d = D + s * (size_t) seq_count;
 		texts[s] = create_segment_texts(seq_count, max_segment_size, a, prepare_copy_numbers(seq_count, max_segment_size, segs[s].lb, a, d, true));
-	}
+	});
+	parallel_for(1, S, [&](size_t s) {
+		totals[s] = max_weight_perfect_matching(X, intersection_weights(seq_count, texts[s - 1], texts[s]), matchings[s]);
+	});
 	auto representative = [](std::vector<SegmentText> const &tx, size_t const i) {
 		return tx[tx[i].row_number(i)].sequence_indices.front();                   // first_sequence_index of the non-copied text
 	};
@@ -420,11 +564,10 @@ inline void bipartite_match(
 	std::iota(order.begin(), order.end(), 0u);
 	for (size_t i = 0; i < X; ++i) permutations[i] = representative(texts[0], i);
 	if (weights_out) weights_out->clear();
-	std::vector<uint32_t> matching;
 	for (size_t s = 1; s < S; ++s)                                                 // :95-118
 	{
-		int64_t const total = max_weight_perfect_matching(X, intersection_weights(seq_count, texts[s - 1], texts[s]), matching);
-		if (weights_out) weights_out->push_back(total);
+		std::vector<uint32_t> const &matching = matchings[s];
+		if (weights_out) weights_out->push_back(totals[s]);
 		uint32_t *perm = permutations + s * X;
 		for (size_t i = 0; i < X; ++i)
 		{

@@ -255,6 +255,15 @@ int  fseq_write_founders(fseq_ctx *ctx, uint8_t const *const *rows, uint32_t con
 
 int  fseq_get_timings(fseq_ctx const *ctx, fseq_timings *out);
 
+/* Host time of the last fseq_join_* call on this context (wall, milliseconds): the boundary states' way to the host,
+ * then -- greedy joiner -- the class tables (greedy_matcher.cc:31-68), the co-occurrence edges (:295-343) and the rounds
+ * that draw them (:353-439); the other joiners report their matching under ms_draw. */
+typedef struct fseq_join_profile {
+	double ms_d2h, ms_classes, ms_edges, ms_draw, ms_total;
+	uint64_t bytes_d2h;
+} fseq_join_profile;
+int  fseq_get_join_profile(fseq_ctx const *ctx, fseq_join_profile *out);
+
 /* replaces: segmentation_lp_context::step_max() / current_step() (segmentation_lp_context.hh:122-127), which the
  * reference's progress indicator polls from another thread, and the per-stage timestamps of generate_context.cc.
  * The stages are the reference's: generate_traceback (pass 1 + DP; steps = columns), find_segments_greedy (steps =

@@ -63,8 +63,14 @@ def test_single_segment_and_full_copy_numbers(pkg):
 
 
 @pytest.mark.gpu
-def test_founders_through_the_gpu_path(pkg, tmp_path):
-    for (m, n, L, K, Brec, mu, seed) in CASES[:4] + [(300, 2000, 25, 8, 200, 2e-3, 22)]:
+@pytest.mark.parametrize("host_front", [False, True])
+def test_founders_through_the_gpu_path(pkg, tmp_path, monkeypatch, host_front):
+    """fseq_join_greedy: class tables and co-occurrence edges built on the device (fseq_joinprep.hpp), copies and edge
+    drawing on the host -- and, with FSEQ_JOIN_HOST, everything on the host from the boundary states: both equal the
+    independent oracle."""
+    if host_front:
+        monkeypatch.setenv("FSEQ_JOIN_HOST", "1")
+    for (m, n, L, K, Brec, mu, seed) in CASES[:4] + [(300, 2000, 25, 8, 200, 2e-3, 22), (2500, 4000, 50, 16, 2000, 1e-4, 0x5EED0002)]:
         msa, res = _segment(m, n, L, K, Brec, mu, seed)
         ctx = pkg.SegmentationContext(m, n, L)
         ctx.set_sequences(msa)
@@ -176,3 +182,34 @@ def test_nongreedy_joiners_through_the_gpu_path(pkg, tmp_path):
     pg = str(tmp_path / "segments_greedy.txt")
     ctx.write_segments(msa, pkg.JOIN_GREEDY, pg)
     assert open(pg).read() == "SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n"
+
+
+@pytest.mark.gpu
+def test_config_c2_full_size_founders_match_the_oracle():
+    """BASELINE config C2 at full size (m = 2,500 x n = 100,000, L = 50, greedy joining): the founders the library
+    writes are byte for byte what the oracle's segmentation + the independent greedy oracle give (SHA-256 of the file)."""
+    import hashlib
+    import importlib
+    import os
+    import tempfile
+    pkg = importlib.import_module("founder-sequences_amd")
+    c = fso.CONFIGS["C2"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    ctx.run()
+    msa = np.ascontiguousarray(ctx.get_sequences())
+    perm = ctx.join_greedy()
+    with tempfile.NamedTemporaryFile(delete=False) as f:
+        path = f.name
+    ctx.write_founders(msa, perm, path)
+    got = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    os.unlink(path)
+    jp = ctx.join_profile()
+    # (the class tables and the co-occurrence edges come from the device: a fraction of the S' x m x 8 bytes of states)
+    assert 0 < jp["bytes_d2h"] < ctx.result.segment_count * m * 8 // 4 and jp["ms_total"] >= jp["ms_d2h"] > 0
+    ref = fso.segment_long(msa, L, threads=8)
+    segs = [(int(x["lb"]), int(x["rb"])) for x in ref["reduced"]]
+    operm = go.greedy_match(m, ref["max_segment_size"], segs, ref["a"], ref["d"])
+    want = hashlib.sha256(b"".join(x + b"\n" for x in go.founders(msa, segs, operm, ref["max_segment_size"]))).hexdigest()
+    assert got == want

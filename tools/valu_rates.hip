@@ -111,6 +111,17 @@ __device__ __forceinline__ uint64_t memtime()
 #define I_78(R) "v_sad_u32 " R ", " R ", %16, %17\n\t"
 #define I_79(R) "v_med3_u32 " R ", " R ", %16, %17\n\t"
 
+#define I_80(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\tv_add_u32 " R ", " R ", %17\n\tv_add_u32 " R ", " R ", %16\n\t"
+#define I_81(R) "v_cmp_eq_u32 vcc, " R ", %16\n\tv_cndmask_b32 " R ", " R ", %16, vcc\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\t"
+#define I_82(R) "v_cmp_eq_u32 vcc, " R ", %16\n\tv_cndmask_b32 " R ", " R ", %16, vcc\n\tv_max_u32 " R ", " R ", %17\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\t"
+#define I_83(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\tv_max_u32 " R ", " R ", %17\n\t"
+#define I_84(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\tv_cndmask_b32_e64 " R ", " R ", %17, %19\n\t"
+#define I_85(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\ts_nop 0\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\ts_nop 0\n\t"
+#define I_86(R) "v_cndmask_b32 " R ", " R ", %16, vcc\n\tv_cndmask_b32 " R ", " R ", %17, vcc\n\tv_cndmask_b32 " R ", " R ", %16, vcc\n\tv_add_u32 " R ", " R ", %16\n\t"
+#define I_87(R) "v_max_u16 " R ", " R ", %16\n\tv_max_u32 " R ", " R ", %17\n\t"
+#define I_88(R) "v_add_u32 " R ", " R ", %16\n\tv_max_u32 " R ", " R ", %17\n\t"
+#define I_89(R) "v_add_u32 " R ", " R ", %16\n\tv_max_u32_dpp " R ", " R ", " R " row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+
 #define CLASSES(X)                                                                           \
 	X(0, "v_max_u32 (VOP2)", I_0)                                         \
 	X(1, "v_add_u32 (VOP2)", I_1)                                         \
@@ -164,7 +175,12 @@ __device__ __forceinline__ uint64_t memtime()
 	X(66, "v_sub_u32 (VOP2, inline constant)", I_66) X(67, "v_fmac_f32 (VOP2)", I_67) X(68, "v_max_u32_e64 (VOP3 encoding)", I_68) X(69, "v_and_b32_e64 (VOP3 encoding)", I_69) \
 	X(70, "v_cndmask_b32 vcc + v_add_u32 (16 + 16: cost per PAIR)", I_70) X(71, "v_cmp_eq_u32 -> vcc + v_add_u32 (16 + 16: cost per PAIR)", I_71) \
 	X(72, "v_cvt_f32_u32 (VOP1)", I_72) X(73, "v_add_u32_sdwa", I_73) X(74, "v_cndmask_b32_dpp vcc row_shr:1", I_74) X(75, "v_xad_u32 (VOP3)", I_75) \
-	X(76, "v_add_lshl_u32 (VOP3)", I_76) X(77, "v_lshl_or_b32 (VOP3)", I_77) X(78, "v_sad_u32 (VOP3)", I_78) X(79, "v_med3_u32 (VOP3)", I_79)
+	X(76, "v_add_lshl_u32 (VOP3)", I_76) X(77, "v_lshl_or_b32 (VOP3)", I_77) X(78, "v_sad_u32 (VOP3)", I_78) X(79, "v_med3_u32 (VOP3)", I_79) \
+	X(80, "[v_cndmask vcc x2, v_add_u32 x2] (64 instructions: cost per QUAD)", I_80) X(81, "[v_cmp -> vcc, v_cndmask vcc x2] (cost per TRIPLE)", I_81) \
+	X(82, "[v_cmp -> vcc, v_cndmask vcc, v_max_u32, v_cndmask vcc] (cost per QUAD)", I_82) X(83, "[v_cndmask vcc, v_max_u32] (cost per PAIR)", I_83) \
+	X(84, "[v_cndmask vcc, v_cndmask_e64 SGPR pair] (cost per PAIR)", I_84) X(85, "[v_cndmask vcc, s_nop 0] x2 (cost per two cndmask)", I_85) \
+	X(86, "[v_cndmask vcc x3, v_add_u32] (cost per QUAD)", I_86) X(87, "[v_max_u16, v_max_u32] (cost per PAIR)", I_87) X(88, "[v_add_u32, v_max_u32] (cost per PAIR)", I_88) \
+	X(89, "[v_add_u32, v_max_u32_dpp] (cost per PAIR)", I_89)
 
 template <int CLS>
 __global__ __launch_bounds__(1024) void k_rate(uint64_t *ticks, uint32_t *sink, uint32_t seed)
