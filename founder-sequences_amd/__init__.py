@@ -78,10 +78,10 @@ EXPORTS = [
     "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
-    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile",
+    "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile", "fseq_debug_set_tuning",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
-DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule"]
+DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
 
 FSEQ_E_PEER = 6
 STAGE_TRACEBACK, STAGE_MERGE, STAGE_SAMPLES = 0, 1, 2
@@ -151,6 +151,7 @@ def load_library():
     L.fseq_rowshard_pbwt.argtypes = [vp, vp, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_double), C.POINTER(u64)]
     L.fseq_write_segments_host.argtypes = [vp, C.POINTER(vp), C.c_int, vp, vp, C.c_char_p]
     L.fseq_get_join_profile.argtypes = [vp, C.POINTER(JoinProfile)]
+    L.fseq_debug_set_tuning.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.fseq_set_progress.argtypes = [vp, PROGRESS_FN, vp]
     L.fseq_step_max.restype = u64
     L.fseq_step_max.argtypes = [vp]
@@ -510,6 +511,11 @@ class SegmentationContext:
         self._check(self.L.fseq_debug_column_list(self.h, col, v.ctypes.data, c.ctypes.data,
                                                   C.byref(ne), C.byref(c0), C.byref(comp)))
         return v[:ne.value].copy(), c[:ne.value].copy(), c0.value, bool(comp.value)
+
+    def set_tuning(self, name, value="1"):
+        """One of the library's FSEQ_* diagnostic knobs for this context (value None = off); the environment is only
+        read when a context is created."""
+        self._check(self.L.fseq_debug_set_tuning(self.h, name.encode(), None if value is None else str(value).encode()))
 
     def join_profile(self):
         """Host time of the last join_*() call: {ms_d2h, ms_classes, ms_edges, ms_draw, ms_total, bytes_d2h}."""

@@ -148,9 +148,9 @@ void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uin
 		default: break;
 	}
 }
-hipError_t prepare_blockkeys(uint32_t T, size_t lds)
+hipError_t prepare_blockkeys(uint32_t T, size_t lds, bool debug)
 {
-	if (getenv("FSEQ_DEBUG"))
+	if (debug)
 	{
 		int nb = -1;
 		switch (T)
@@ -181,12 +181,12 @@ KernelSet compose_kernels()
 	return k;
 }
 
-bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out)
+bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_wave)
 {
 	if (sigma > 256) return false;
 	// 1024-thread configurations spare wave 0 for the per-column lists when the rows allow it (measured: C5 phase C
 	// 86 -> 75 ms with it, while 512-thread workgroups lose as much to the longer per-thread chunks as they gain)
-	bool const ew_ok = !getenv("FSEQ_NO_EMITTER_WAVE");
+	bool const ew_ok = !no_emitter_wave;
 #define FSEQ_TRY_EW(T_, E_, PK_)                                                               \
 	if (ew_ok && m <= (uint32_t) ((T_) - 64) * (E_))                                           \
 	{                                                                                          \
@@ -273,6 +273,79 @@ double now_ms()
 
 } // namespace
 
+// Diagnostic / test knobs of the library.  They are read from the environment ONCE, when a context is created
+// (fseq_create), and can be set per context with fseq_debug_set_tuning (include/fseq_debug.h); nothing on the run
+// path looks at the environment.  Every knob selects among exact alternatives (results never depend on them).
+struct Tuning {
+	bool debug = false;                  // FSEQ_DEBUG: progress notes on stderr
+	bool host_flags = false, no_host_flags = false;   // FSEQ_HOST_FLAGS / FSEQ_NO_HOST_FLAGS: the serial DP beside phase C, fed by host-visible flags
+	int  c_parts = 0;                    // FSEQ_C_PARTS: phase C in this many launches with the serial DP in between
+	int  dp_chunks = 0;                  // FSEQ_DP_CHUNKS: the serial DP in this many resumed launches
+	bool dp_serial = false;              // FSEQ_DP_SERIAL: the serial DP instead of the speculative sweeps
+	int  dp_spec_win = 0, dp_spec_rounds = 0, dp_spec_max_sweeps = 0;      // FSEQ_DP_SPEC_*: tail window, chunk length, sweep budget
+	bool stream_plain_scan = false;      // FSEQ_STREAM_PLAIN_SCAN: streamed phase C with the has-based scan (first form)
+	bool plain_scan = false;             // FSEQ_PLAIN_SCAN: phase B / pass 2 never scan keys
+	bool phase_a_classic = false;        // FSEQ_PHASE_A_CLASSIC: phase A as a column sweep
+	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
+	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
+	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
+	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
+	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
+	bool ss_unpacked = false;            // FSEQ_SS_UNPACKED: 8-byte stride states in the streamed regime
+	int  snap_stride = 0;                // FSEQ_SNAP_STRIDE: first stride tried for the stride states
+	bool poison_lists = false;           // FSEQ_POISON_LISTS: lists and headers filled with 0xFF before phase C
+	bool no_emitter_wave = false;        // FSEQ_NO_EMITTER_WAVE: phase C without the list wave
+	bool join_host = false;              // FSEQ_JOIN_HOST: the greedy joiner's class tables and edges on the host
+	int  inject_failure_rank = -1;       // FSEQ_INJECT_FAILURE_RANK: this rank of a sharded run fails after phase A
+	std::string sync_phases;             // FSEQ_SYNC_PHASES: "ABC": synchronise after these phases (a fault shows where it happened)
+	bool check_phase_a = false;          // FSEQ_CHECK_PHASE_A: validate the key blocks on the host before phase B
+
+	// returns false for a name it does not know
+	bool set(char const *name, char const *value)
+	{
+		std::string const n(name), v(value ? value : "");
+		bool const on = value != nullptr;
+		int const iv = atoi(v.c_str());
+		if (n == "FSEQ_DEBUG") debug = on;
+		else if (n == "FSEQ_HOST_FLAGS") host_flags = on;
+		else if (n == "FSEQ_NO_HOST_FLAGS") no_host_flags = on;
+		else if (n == "FSEQ_C_PARTS") c_parts = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_DP_CHUNKS") dp_chunks = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_DP_SERIAL") dp_serial = on;
+		else if (n == "FSEQ_DP_SPEC_WIN") dp_spec_win = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_DP_SPEC_ROUNDS") dp_spec_rounds = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_DP_SPEC_MAX_SWEEPS") dp_spec_max_sweeps = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_STREAM_PLAIN_SCAN") stream_plain_scan = on;
+		else if (n == "FSEQ_PLAIN_SCAN") plain_scan = on;
+		else if (n == "FSEQ_PHASE_A_CLASSIC") phase_a_classic = on;
+		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
+		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
+		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
+		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
+		else if (n == "FSEQ_STREAM2") stream2 = v;
+		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
+		else if (n == "FSEQ_SNAP_STRIDE") snap_stride = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_POISON_LISTS") poison_lists = on;
+		else if (n == "FSEQ_NO_EMITTER_WAVE") no_emitter_wave = on;
+		else if (n == "FSEQ_JOIN_HOST") join_host = on;
+		else if (n == "FSEQ_INJECT_FAILURE_RANK") inject_failure_rank = on ? iv : -1;
+		else if (n == "FSEQ_SYNC_PHASES") sync_phases = v;
+		else if (n == "FSEQ_CHECK_PHASE_A") check_phase_a = on;
+		else return false;
+		return true;
+	}
+
+	void from_environment()
+	{
+		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
+			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_PHASE_A_CLASSIC",
+			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
+			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A"};
+		for (char const *nm : names)
+			if (char const *v = getenv(nm)) (void) set(nm, v);
+	}
+};
+
 // One alignment over several ranks (include/fseq.h, fseq_set_shard): which blocks / columns / DP chunks are mine
 struct Shard {
 	bool on = false;
@@ -289,6 +362,7 @@ struct Shard {
 
 struct fseq_ctx {
 	fseq_params p{};
+	Tuning tune;                             // read from the environment once, at fseq_create
 	std::unordered_map<void *, size_t> alloc_sizes;   // device allocations of this context (dev_alloc / dev_free)
 	size_t alloc_total = 0;
 	uint64_t mem_budget = 0;                  // fseq_set_memory_budget: 0 = whatever is free on the device
@@ -529,7 +603,7 @@ void block_geometry(fseq_ctx *c)
 		// blocks a rank needs; (k, q) with the fewest serial steps among those that keep every rank busy.
 		uint32_t const per = (c->nblocks + sh.world - 1) / sh.world;
 		uint32_t F = 4;
-		if (char const *e = getenv("FSEQ_CHAIN_FAN")) F = (uint32_t) std::max(2, atoi(e));
+		if (c->tune.chain_fan) F = (uint32_t) c->tune.chain_fan;
 		uint32_t best_k = 0, best_q = std::max(1u, per), best_cost = ~0u;
 		{
 			uint64_t pw = 1;
@@ -573,8 +647,8 @@ void block_geometry(fseq_ctx *c)
 			if (cost < best_cost) { best_cost = cost; best_g = g; }
 		}
 		if (c->nblocks <= 8) best_g = std::max(1u, c->nblocks);        // one chain
-		if (getenv("FSEQ_TWO_LEVEL_CHAIN")) best_g = std::max(2u, (uint32_t) std::ceil(std::sqrt((double) c->nblocks)));
-		if (char const *e = getenv("FSEQ_CHAIN_FAN")) best_g = (uint32_t) std::max(2, atoi(e));
+		if (c->tune.two_level_chain) best_g = std::max(2u, (uint32_t) std::ceil(std::sqrt((double) c->nblocks)));
+		if (c->tune.chain_fan) best_g = (uint32_t) c->tune.chain_fan;
 		c->chain_fan = best_g;
 		c->chain_G = best_g; c->n_super = (c->nblocks + best_g - 1) / best_g;      // (diagnostics)
 		c->chain_G2 = 0; c->n_hyper = 0;
@@ -595,7 +669,7 @@ int prepare_geometry(fseq_ctx *c)
 		c->npass = (bits + 1) / 2;               // 2-bit digit passes per column
 	}
 	if (c->sigma > 256) return fail(c, FSEQ_E_UNSUPPORTED, "alphabet larger than 256 symbols");
-	c->use_stream = !select_kernels(p.m, c->sigma, &c->ks);
+	c->use_stream = !select_kernels(p.m, c->sigma, &c->ks, c->tune.no_emitter_wave);
 	if (c->use_stream)
 	{
 		// rows beyond the LDS-resident configurations: the order streams through HBM / L2
@@ -614,9 +688,8 @@ int prepare_geometry(fseq_ctx *c)
 		c->s2 = Stream2Config{};
 		{
 			uint32_t T2 = 512, E2 = 8, P2 = 1;
-			char const *e = getenv("FSEQ_STREAM2");
-			bool off = getenv("FSEQ_STREAM_PLAIN_SCAN") != nullptr;
-			if (e && sscanf(e, "%u,%u,%u", &T2, &E2, &P2) < 2) off = true;
+			bool off = c->tune.stream_plain_scan;
+			if (!c->tune.stream2.empty() && sscanf(c->tune.stream2.c_str(), "%u,%u,%u", &T2, &E2, &P2) < 2) off = true;
 			Stream2Config cfg;
 			if (!off && select_stream2(T2, E2, P2, &cfg) && (uint64_t) p.m + c->B < (1ull << cfg.key_shift) && c->stream_staged)
 			{
@@ -631,7 +704,7 @@ int prepare_geometry(fseq_ctx *c)
 		}
 		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
 		c->bk_cap_words = 12288;                               // two bitmaps + 32-bit prefix counts: 12 B per word
-		if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) c->bk_cap_words = (uint32_t) std::max(2048, atoi(e));
+		if (c->tune.blockkeys_cap) c->bk_cap_words = (uint32_t) c->tune.blockkeys_cap;
 		c->bk_lds = blockkeys_stream_lds_bytes(c->bk_cap_words, 1024);
 		// (bk_merge slices a merge by whole `hi` values: one hi value's Dlo <= m keys must fit the bitmap -- with more rows
 		// than bitmap bits a diverse block could overrun it, so such inputs take the column sweep k_colblock_stream<MODE_RANK>)
@@ -656,11 +729,11 @@ int prepare_geometry(fseq_ctx *c)
 			if (arrays + 16 * 2560 > budget) budget = LDS_LIMIT - 1024;
 			size_t cap = budget > arrays ? (budget - arrays) / 16 : 0;     // two maps of 8-byte {bits, prefix} entries
 			cap = std::min<size_t>(cap & ~size_t(63), 32768);
-			if (char const *e = getenv("FSEQ_BLOCKKEYS_CAP")) cap = (size_t) std::max(2048, atoi(e));     // tests: force the sliced merges
+			if (c->tune.blockkeys_cap) cap = (size_t) c->tune.blockkeys_cap;     // tests: force the sliced merges
 			c->bk_cap_words = (uint32_t) cap;
 			c->bk_lds = blockkeys_lds_bytes(p.m, c->bk_cap_words, (int) c->bk_T, c->ld, c->bsh);
 			// (a leaf's columns are staged with two 16-byte pieces per thread)
-			if (cap >= 2048 && c->bk_lds <= LDS_LIMIT && (size_t) (8u >> (2u - c->bsh)) * c->ld <= (size_t) c->bk_T * 32) HIP_TRY(c, prepare_blockkeys(c->bk_T, c->bk_lds));
+			if (cap >= 2048 && c->bk_lds <= LDS_LIMIT && (size_t) (8u >> (2u - c->bsh)) * c->ld <= (size_t) c->bk_T * 32) HIP_TRY(c, prepare_blockkeys(c->bk_T, c->bk_lds, c->tune.debug));
 			else c->bk_cap_words = 0;
 		}
 	}
@@ -792,7 +865,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		}
 		// streamed rows: 5 bytes per row when a row id and a column number fit 40 bits together (fseq_stream.hpp)
 		c->ss_pack = 0;
-		if (c->use_stream && !getenv("FSEQ_SS_UNPACKED"))
+		if (c->use_stream && !c->tune.ss_unpacked)
 		{
 			uint32_t abits = 1, dbits = 1;
 			while ((1ull << abits) < m) ++abits;
@@ -801,12 +874,12 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		}
 		uint64_t const state_bytes = c->ss_pack ? (uint64_t) m * 4ull + ss_high_stride(p.m) : (uint64_t) m * 8ull;
 		uint64_t st_ = 16;
-		if (char const *e = getenv("FSEQ_SNAP_STRIDE")) st_ = (uint64_t) std::max(1, atoi(e));     // (experiments: first stride tried)
+		if (c->tune.snap_stride) st_ = (uint64_t) c->tune.snap_stride;     // (experiments: first stride tried)
 		// the smallest stride >= 16 whose states fit (any number, not a power of two: pass 2 costs ~stride / 2 columns per boundary)
 		if ((k_cnt / st_ + 2) * state_bytes > budget) st_ = std::max<uint64_t>(st_, (k_cnt * state_bytes + budget - 1) / std::max<uint64_t>(1, budget - 2 * state_bytes));
 		while ((k_cnt / st_ + 2) * state_bytes > budget) ++st_;
 		c->snap_stride = (uint32_t) st_;
-		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB, %llu bytes per state)\n", (unsigned long long) st_, budget / 1073741824.0, (unsigned long long) state_bytes);
+		if (c->tune.debug) fprintf(stderr, "[fseq] stride states every %llu columns (budget %.1f GiB, %llu bytes per state)\n", (unsigned long long) st_, budget / 1073741824.0, (unsigned long long) state_bytes);
 		uint64_t const q_lo = k_lo / st_, q_hi = held_hi(c) / st_;
 		if ((rc = dev_alloc(c, &c->d_ss_a_alloc, (size_t) (q_hi - q_lo + 1) * m))) return rc;
 		c->d_ss_a = c->d_ss_a_alloc - (size_t) q_lo * m;         // state at column q * snap_stride at d_ss_* + q * m
@@ -1017,7 +1090,7 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 // the configuration's key shift (FSEQ_PLAIN_SCAN: never)
 uint32_t scan_keyed(fseq_ctx const *c)
 {
-	return (!c->use_stream && c->p.n < (1ull << c->ks.scan_shift) && !getenv("FSEQ_PLAIN_SCAN")) ? 1u : 0u;
+	return (!c->use_stream && c->p.n < (1ull << c->ks.scan_shift) && !c->tune.plain_scan) ? 1u : 0u;
 }
 
 void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0)
@@ -1121,7 +1194,7 @@ SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
 	if (!c->sh.on) return P;                 // the diagnostic builds instrument the serial kernel
 #endif
-	if (getenv("FSEQ_DP_SERIAL") && !c->sh.on) return P;
+	if (c->tune.dp_serial && !c->sh.on) return P;
 	int ncu = 0;
 	(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
 	if (ncu < 1) ncu = 1;
@@ -1129,7 +1202,7 @@ SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 	// chunks are cheaper but more of them are needed)
 	uint32_t const min_entries = std::max<uint32_t>(1024u, 8u * S.L);
 	uint32_t forced = 0;
-	if (char const *e = getenv("FSEQ_DP_SPEC_ROUNDS")) forced = (uint32_t) std::max(1, atoi(e));   // tests: any chunk length
+	if (c->tune.dp_spec_rounds) forced = (uint32_t) c->tune.dp_spec_rounds;   // tests: any chunk length
 	auto cut = [&](uint32_t lo, uint32_t hi) {
 		// rounds [lo, hi) of one rank into chunks
 		if (hi <= lo) return;
@@ -1220,7 +1293,7 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	G.NR = n - 2u * L + 1u;
 	G.t_final = n - L;
 	G.win = std::max<uint32_t>(256u, 4u * L);
-	if (char const *e = getenv("FSEQ_DP_SPEC_WIN")) G.win = (uint32_t) std::max(1, atoi(e));
+	if (c->tune.dp_spec_win) G.win = (uint32_t) c->tune.dp_spec_win;
 	uint32_t const ncomplete = G.NR / 64u;
 	uint32_t const grid_c = (uint32_t) ((c->dp_size + 255) / 256);          // 4 blocks of 64 entries per workgroup, incl. the final cell's
 
@@ -1246,7 +1319,7 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		hipLaunchKernelGGL(k_spec_table, dim3((ncomplete + 255u) / 256u), dim3(256), 0, st, c->dp, ncomplete, d_ctl);
 	};
 	uint32_t max_sweeps = 12;
-	if (char const *e = getenv("FSEQ_DP_SPEC_MAX_SWEEPS")) max_sweeps = (uint32_t) std::max(1, atoi(e));
+	if (c->tune.dp_spec_max_sweeps) max_sweeps = (uint32_t) c->tune.dp_spec_max_sweeps;
 	SpecCtl h{};
 	sweep(true);
 	uint32_t done_sweeps = 1;
@@ -1318,7 +1391,7 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		uint32_t o = fl[0] & 1u;
 		for (uint32_t k = P.mine_lo; k < P.mine_hi && k <= h.first_changed; ++k) o |= ovf[k] ? 1u : 0u;
 		*overflow = o;
-		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] speculative DP: not converged after %u sweeps, serial from round %u\n", done_sweeps, r0);
+		if (c->tune.debug) fprintf(stderr, "[fseq] speculative DP: not converged after %u sweeps, serial from round %u\n", done_sweeps, r0);
 	}
 	else
 	{
@@ -1346,38 +1419,45 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		*overflow = o;
 	}
 	if (sweeps_out) *sweeps_out = h.done ? h.sweeps : done_sweeps + 1000u;
-	if (getenv("FSEQ_DEBUG"))
+	if (c->tune.debug)
 		fprintf(stderr, "[fseq] speculative DP: %u chunks (mine %u..%u), %u sweeps compared, done=%u\n", nch, P.mine_lo, P.mine_hi, h.sweeps, h.done);
 	return FSEQ_OK;
 }
 
-int run_long_path(fseq_ctx *c, fseq_result *res)
+// what the phases of one long-path run share (run_long_path)
+struct LongRun {
+	uint32_t X = 0, retries = 0;
+	double ms_c = 0, ms_dp = 0, ms_host = 0, ms_p2 = 0;
+	uint64_t pass2_cells = 0;
+	bool keyspace = false;
+};
+
+// the aliases every phase uses
+#define FSEQ_LONG_LOCALS(c)                                                                           \
+	fseq_params const &p = (c)->p;                                                                    \
+	uint32_t const m = p.m;                                                                           \
+	uint64_t const n = p.n;                                                                           \
+	uint64_t const L = p.segment_length;                                                              \
+	hipStream_t st = (c)->stream;                                                                     \
+	KernelSet const &ks = (c)->ks;                                                                    \
+	Shard const &sh = (c)->sh;                                                                        \
+	bool const sharded = sh.on;                                                                       \
+	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : (c)->nblocks;            \
+	uint32_t const my_blocks = b_hi - b_lo;                                                           \
+	int rc = FSEQ_OK;                                                                                 \
+	(void) m; (void) n; (void) L; (void) st; (void) ks; (void) sharded; (void) b_lo; (void) my_blocks; (void) rc
+
+// diagnostic ("ABC" in FSEQ_SYNC_PHASES): synchronise behind a phase, so that a fault shows up at the phase that caused it
+bool sync_at(fseq_ctx const *c, char ph) { return c->tune.sync_phases.find(ph) != std::string::npos; }
+
+// ---- phase A: the key blocks of my column blocks (independent of the list capacity)
+int long_phase_a(fseq_ctx *c, LongRun &R)
 {
-	fseq_params const &p = c->p;
-	uint32_t const m = p.m;
-	uint64_t const n = p.n;
-	uint64_t const L = p.segment_length;
-	hipStream_t st = c->stream;
-	KernelSet const &ks = c->ks;
-	int rc;
-
-	uint32_t X = p.list_cap ? p.list_cap : std::max(FSEQ_X_FLOOR, c->X_hint);
-	c->tm = fseq_timings{};
-	c->tm.block_len = c->B;
-	c->tm.n_blocks = c->nblocks;
-	double const t_begin = now_ms();
-
-	if ((rc = ensure_work_buffers(c, 0))) return rc;
-
-	// ---- phase A + B (independent of X)
-	Shard const &sh = c->sh;
-	bool const sharded = sh.on;
-	uint32_t const b_lo = sharded ? sh.b_lo : 0u, b_hi = sharded ? sh.b_hi : c->nblocks;     // my blocks
-	uint32_t const my_blocks = b_hi - b_lo;
+	FSEQ_LONG_LOCALS(c);
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
 	progress(c, FSEQ_STAGE_TRACEBACK, 0, n);
 	FSEQ_RANGE_PUSH("fseq pass 1: phases A + B (block keys, boundary states)");
-	bool const keyspace = c->bk_cap_words && my_blocks && !getenv("FSEQ_PHASE_A_CLASSIC");
+	bool const keyspace = R.keyspace = c->bk_cap_words && my_blocks && !c->tune.phase_a_classic;
 	if (keyspace && c->use_stream)
 	{
 		// phase A in key space, streamed rows: one workgroup per CU with its own workspace, blocks round-robin
@@ -1393,7 +1473,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
 		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
 		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, getenv("FSEQ_BLOCKKEYS_WIDE") ? 1u : 0u);
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, c->tune.blockkeys_wide ? 1u : 0u);
 	}
 	else if (keyspace)
 	{
@@ -1411,12 +1491,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	else
 		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
-	if (char const *e = getenv("FSEQ_INJECT_FAILURE_RANK"))
-		if (sharded && (uint32_t) atoi(e) == sh.rank) return fail(c, FSEQ_E_OOM, "injected failure (FSEQ_INJECT_FAILURE_RANK)");
-	char const *const sync_env = getenv("FSEQ_SYNC_PHASES");             // diagnostic ("ABC"): a fault shows up at the phase that caused it
-	auto sync_at = [&](char ph) { return sync_env && strchr(sync_env, ph); };
-	if (sync_at('A')) { fprintf(stderr, "[fseq] phase A queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase A done\n"); }
-	if (getenv("FSEQ_CHECK_PHASE_A"))
+	if (sharded && c->tune.inject_failure_rank >= 0 && (uint32_t) c->tune.inject_failure_rank == sh.rank)
+		return fail(c, FSEQ_E_OOM, "injected failure (FSEQ_INJECT_FAILURE_RANK)");
+	if (sync_at(c, 'A')) { fprintf(stderr, "[fseq] phase A queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase A done\n"); }
+	if (c->tune.check_phase_a)
 	{
 		// diagnostic: the key blocks must be well-formed before anything indexes with them (ranks < nkeys <= m, the
 		// divergence in front of a key inside the block's columns)
@@ -1441,6 +1519,14 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			}
 		}
 	}
+	return FSEQ_OK;
+}
+
+// ---- phase B: the exact boundary state of every block
+int long_phase_b(fseq_ctx *c, LongRun &R)
+{
+	FSEQ_LONG_LOCALS(c);
+	(void) R;
 	if (!sharded)
 	{
 		// phase B: up the levels -- compose groups of G key blocks of a level into one key block of the next
@@ -1525,7 +1611,15 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	HIP_TRY(c, hipGetLastError());
 	FSEQ_RANGE_POP();
 	progress(c, FSEQ_STAGE_TRACEBACK, n / 5, n);                  // (phases A and B queued: about a fifth of pass 1)
-	if (sync_at('B')) { fprintf(stderr, "[fseq] phase B queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase B done\n"); }
+	if (sync_at(c, 'B')) { fprintf(stderr, "[fseq] phase B queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase B done\n"); }
+	return FSEQ_OK;
+}
+
+// ---- the list capacity X: what the caller asked for, what worked last time, or an estimate from the boundary states
+int long_list_capacity(fseq_ctx *c, LongRun &R)
+{
+	FSEQ_LONG_LOCALS(c);
+	uint32_t &X = R.X;
 	if (!p.list_cap && !c->X_hint)
 	{
 		// first run on this input: size the lists from the block boundary states (k_boundary_recent)
@@ -1546,7 +1640,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 			// 5,000,000 x (X + 3) x 8 bytes, and what they do not take goes to the stride states of pass 2)
 			uint64_t const want = med + med / 4;
 			if (X < want) X = (uint32_t) (((want + 63) & ~63ull) - 1);
-			if (getenv("FSEQ_DEBUG"))
+			if (c->tune.debug)
 				fprintf(stderr, "[fseq] list capacity estimate: %zu boundaries, median recent count %llu -> X = %u\n",
 				        recent.size(), (unsigned long long) med, X);
 		}
@@ -1559,359 +1653,375 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	}
 	if (X >= m) X = m;
 
-	double ms_c = 0, ms_dp = 0, ms_host = 0;
-	uint32_t retries = 0;
-	std::vector<uint2> h_gent;
-	std::vector<uint4> h_ghdr;
-	while (true)
+	return FSEQ_OK;
+}
+
+// ---- one attempt with list capacity R.X: phase C (column updates + lists), phase D (the DP), traceback, merge walk.
+// *overflow_out: some DP cell or merge threshold needed more of a list than X entries hold (the caller retries).
+// ---- follow_traceback and find_segments_greedy for one attempt (the lists held their own so far): the traceback on
+// the device, the merge walk over one threshold per traceback boundary on the host.  *overflow: a threshold or a merged
+// size needed more of a list than it holds.
+int long_traceback_and_merge(fseq_ctx *c, LongRun &R, double th0, bool *overflow_out)
+{
+	FSEQ_LONG_LOCALS(c);
+	(void) R;
+	bool overflow = false;
+	if (!overflow)
 	{
-		if ((rc = ensure_work_buffers(c, X))) return rc;
-		// ---- phase C + D
-#if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
-		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 1024, st));
-#else
-		HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
-#endif
-		if (getenv("FSEQ_POISON_LISTS"))
-		{
-			// tests of the DP-beside-phase-C forms: a list read before it is written must not look right by accident
-			HIP_TRY(c, hipMemsetAsync(c->d_ent_alloc, 0xFF, ((size_t) (held_hi(c) - held_lo(c)) * c->stride + 256) * sizeof(uint2), st));
-			HIP_TRY(c, hipMemsetAsync(c->d_hdr, 0xFF, (size_t) n * sizeof(uint4), st));
-		}
-		// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
-		// rounds whose lists are complete, on a second stream: the DP of a column prefix runs while later
-		// columns are still being produced.  Only where one workgroup of the column kernel fills a CU (16-bit
-		// and streamed state) and a launch has several waves of them anyway: a part is then ncu - 1
-		// workgroups per wave, which leaves the DP (a whole CU's LDS) a CU of its own.  FSEQ_C_PARTS forces a count.
-		DpSchedule const S = dp_schedule((uint32_t) L, (uint32_t) n);
-		// default: the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp);
-		// the forms that run the serial DP beside phase C remain for FSEQ_DP_SERIAL and the forced test schedules
-		SpecPlan const spec = spec_plan(c, S);
-		bool const use_spec = sharded || (spec.nchunks() > 0 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_HOST_FLAGS") && !getenv("FSEQ_DP_CHUNKS"));
-		if (sharded && spec.nchunks() < 1) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: no DP chunk plan");
-		// columns phase C covers here: all, or my blocks plus the halo block's first columns (the lists my last DP round reads)
-		uint64_t const n_c = sharded ? sh.c_end : n;
-		uint32_t spec_overflow = 0, spec_sweeps = 0;
-		uint32_t parts = 1, part_blocks = c->nblocks;
-		if (!use_spec)
-		{
-			int ncu = 0;
-			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
-			uint32_t const per_cu = c->use_stream ? 1u : ks.columns_resident(c->lds_columns);
-			if (per_cu == 1u && ncu > 1 && c->nblocks >= 2u * (uint32_t) ncu)
-			{
-				uint32_t const wave_blocks = (uint32_t) ncu - 1u;
-				uint32_t const waves = (c->nblocks + wave_blocks - 1) / wave_blocks;
-				part_blocks = wave_blocks * ((waves + 7u) / 8u);
-				parts = (c->nblocks + part_blocks - 1) / part_blocks;
-			}
-			if (char const *e = getenv("FSEQ_C_PARTS"))
-			{
-				parts = (uint32_t) std::min<long>(16, std::max<long>(1, atol(e)));
-				parts = std::min(parts, c->nblocks);
-				part_blocks = (c->nblocks + parts - 1) / parts;
-				parts = (c->nblocks + part_blocks - 1) / part_blocks;
-			}
-		}
-		HIP_TRY(c, hipEventRecord(c->ev[3], st));
-		FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
-		auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
-			if (c->use_stream && c->s2.T)
-			{
-				uint32_t pack_abits = 0;
-				if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
-				hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
-				c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
-				             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
-			}
-			else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !getenv("FSEQ_STREAM_PLAIN_SCAN"))
-				hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
-			else if (c->use_stream)
-				hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
-				                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
-			else
-				ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
-				           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
-		};
-		// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
-		// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
-		// launches on the second stream).  Phase C keeps its efficiency (no drain between parts).
-		bool const host_flags = (parts > 1 && !getenv("FSEQ_C_PARTS") && !getenv("FSEQ_NO_HOST_FLAGS")) || getenv("FSEQ_HOST_FLAGS");
-		if (host_flags)
-		{
-			if (c->done_cap < c->nblocks)
-			{
-				if (c->h_done) (void) hipHostFree(c->h_done);
-				c->h_done = nullptr;
-				HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_done), (size_t) c->nblocks * 4, hipHostMallocMapped | hipHostMallocCoherent));
-				HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0));
-				memset(c->h_done, 0, (size_t) c->nblocks * 4);
-				c->done_cap = c->nblocks;
-				c->epoch = 0;
-			}
-			uint32_t const epoch = ++c->epoch;
-			hipStream_t const st2 = c->stream2;
-			launch_columns(0, c->nblocks, c->d_done, epoch);
-			HIP_TRY(c, hipEventRecord(c->ev[4], st));
-			HIP_TRY(c, hipGetLastError());
-			// the host follows the completed block prefix and hands the DP the rounds whose lists are complete
-			uint32_t prefix = 0, r_done = 0;
-			uint32_t const min_rounds = getenv("FSEQ_HOST_FLAGS") ? 1u : std::max(64u, S.nrounds / 12u);   // forced (tests): as many resumed launches as possible
-			bool dp_started = false;
-			double const t_wait0 = now_ms();
-			while (r_done < S.nrounds)
-			{
-				while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
-				uint32_t const r1 = (prefix == c->nblocks) ? S.nrounds : dp_rounds_within(S, std::min<uint64_t>(n, (uint64_t) prefix * c->B));
-				if (r1 > r_done && (r1 - r_done >= min_rounds || prefix == c->nblocks))
-				{
-					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-					hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-					                   c->d_flags, r_done, r1, DpSpecArgs{});
-					r_done = r1;
-					continue;
-				}
-				hipError_t const q = hipStreamQuery(st);
-				if (q != hipErrorNotReady && prefix < c->nblocks)
-				{
-					// phase C is over: either it failed (report that, not a time-out) or every flag is there
-					if (q != hipSuccess) return fail(c, FSEQ_E_HIP, "phase C failed", q);
-					while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
-					if (prefix < c->nblocks) return fail(c, FSEQ_E_HIP, "internal: phase C finished without flagging every block");
-					continue;
-				}
-				if (now_ms() - t_wait0 > 600e3) return fail(c, FSEQ_E_HIP, "timed out waiting for phase C");
-				if (now_ms() - t_wait0 > 50.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
-			}
-			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
-			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
-		}
-		else if (parts <= 1)
-		{
-			if (use_spec)
-			{
-				// the arrays the speculative DP starts from are reset on the second stream while phase C runs
-				if ((rc = dp_spec_reset(c, spec, c->stream2))) return rc;
-				HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
-			}
-			if (!sharded) launch_columns(0, c->nblocks);
-			if (sync_at('C')) { fprintf(stderr, "[fseq] phase C queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase C done\n"); }
-			if (sharded && my_blocks)
-			{
-				// my blocks, and the block behind them for as far as the halo reaches (k_columns stops at n_c)
-				uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
-				launch_columns(b_lo, nb);
-			}
-			HIP_TRY(c, hipEventRecord(c->ev[4], st));
-			// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
-			// each resuming from the arrays the one before it flushed
-			uint32_t chunks = 1;
-			if (char const *e = getenv("FSEQ_DP_CHUNKS")) chunks = (uint32_t) std::max(1, atoi(e));
-			chunks = std::min(chunks, S.nrounds);
-			HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
-			if (use_spec)
-			{
-				HIP_TRY(c, hipStreamWaitEvent(st, c->ev_part[15], 0));      // the DP arrays were reset beside phase C
-				if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps, true))) return rc;
-			}
-			else if (chunks <= 1)
-				hipLaunchKernelGGL(k_dp<DP_WHOLE>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, 0u, S.nrounds, DpSpecArgs{});
-			for (uint32_t k = 0; !use_spec && chunks > 1 && k < chunks; ++k)
-			{
-				uint32_t const r0 = (uint32_t) ((uint64_t) S.nrounds * k / chunks), r1 = (uint32_t) ((uint64_t) S.nrounds * (k + 1) / chunks);
-				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, r0, r1, DpSpecArgs{});
-			}
-			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
-		}
-		else
-		{
-			hipStream_t const st2 = c->stream2;
-			uint32_t r_done = 0;
-			bool dp_started = false;
-			for (uint32_t k = 0; k < parts; ++k)
-			{
-				uint32_t const b0 = k * part_blocks, nb = std::min(part_blocks, c->nblocks - b0);
-				launch_columns(b0, nb);
-				HIP_TRY(c, hipEventRecord(c->ev_part[k], st));
-				uint64_t const col_hi = std::min<uint64_t>(n, (uint64_t) (b0 + nb) * c->B);
-				uint32_t const r1 = (k + 1 == parts) ? S.nrounds : dp_rounds_within(S, col_hi);
-				if (r1 > r_done)
-				{
-					HIP_TRY(c, hipStreamWaitEvent(st2, c->ev_part[k], 0));
-					if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-					hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-					                   c->d_flags, r_done, r1, DpSpecArgs{});
-					r_done = r1;
-				}
-			}
-			HIP_TRY(c, hipEventRecord(c->ev[4], st));
-			HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
-			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
-		}
-		HIP_TRY(c, hipEventRecord(c->ev[5], st));
-		HIP_TRY(c, hipGetLastError());
+		if ((rc = follow_traceback(c, st))) return rc;
+		if (c->tune.debug) fprintf(stderr, "[fseq] host: traceback walk + gather %.3f ms\n", now_ms() - th0);
+		uint32_t const max_seg = c->traceback.back().segment_max_size;
+		c->res.max_segment_size = max_seg;
+		c->res.dp_segment_count = c->traceback.size();
+		c->res.short_path = 0;
+		size_t const S = c->traceback.size();
 
-		uint32_t h_flags[4] = {0, 0, 0, 0};
-		HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
-		if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
-		HIP_TRY(c, hipStreamSynchronize(st));
+		// ---- find_segments_greedy (lp.cc:335-390).  Its test #{d_rb > current_lb} <= max_segment_size (:363-364)
+		// holds exactly for current_lb >= tau_rb; tau comes from the list of column rb - 1 where that list lives
+		// (k_seg_tau: one number per traceback boundary instead of the lists; sharded: every rank for its columns).
+		c->segments.clear();
+		if (max_seg < m)
 		{
-			float f = 0;
-			HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
-			HIP_TRY(c, hipEventElapsedTime(&f, c->ev_dp[0], c->ev_dp[1])); ms_dp += f;     // overlaps phase C when that runs in parts
-		}
-#ifdef FSEQ_DP_STAMPS
-		{
-			unsigned long long stamps[96];
-			HIP_TRY(c, hipMemcpy(stamps, c->d_flags + 8, sizeof(stamps), hipMemcpyDeviceToHost));
-			for (int w = 0; w < 16; ++w)
+			uint64_t const own_lo = held_lo(c), own_hi = sharded ? sh.c_hi : n;      // columns whose lists I answer for
+			std::vector<uint2> tau(S);
+			if (S > 1 && c->tau_host.size() == S)
+				tau = c->tau_host;                                          // came back with the traceback
+			else if (S > 1)
 			{
-				unsigned long long const *q = stamps + 48 + 3 * w;
-				double const nr = (double) (stamps[3 * w + 2] ? stamps[3 * w + 2] : 1);
-				fprintf(stderr, "[dp stamps] wave %2d cycles/round: barrier 1 = %.0f, update = %.0f, barrier 2 = %.0f\n", w, q[0] / nr, q[1] / nr, q[2] / nr);
-			}
-			for (int w = 0; w < 16; ++w)
-			{
-				unsigned long long const *q = stamps + 3 * w;
-				double const nr = (double) (q[2] ? q[2] : 1);
-				fprintf(stderr, "[dp stamps] wave %2d rounds=%llu cycles/round: work=%.0f waits=%.0f\n", w, q[2], q[0] / nr, q[1] / nr);
-			}
-		}
-#endif
-#ifdef FSEQ_DP_STATS
-		{
-			uint32_t hist[34];
-			HIP_TRY(c, hipMemcpy(hist, c->d_flags + 128, sizeof(hist), hipMemcpyDeviceToHost));
-			fprintf(stderr, "[dp stats] list entries a cell needed (cell-pair path; last = more than 32):");
-			for (int i = 0; i < 34; ++i) fprintf(stderr, " %u", hist[i]);
-			fprintf(stderr, "\n");
-		}
-#endif
-		FSEQ_RANGE_POP();
-		progress(c, FSEQ_STAGE_TRACEBACK, n, n);
-		FSEQ_RANGE_PUSH("fseq traceback + find_segments_greedy");
-		double const th0 = now_ms();
-		bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
-		c->tm.dp_sweeps = spec_sweeps;
-		c->tm.dp_chunks = use_spec ? spec.nchunks() : 0u;
-
-		if (!overflow)
-		{
-			if ((rc = follow_traceback(c, st))) return rc;
-			if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: traceback walk + gather %.3f ms\n", now_ms() - th0);
-			uint32_t const max_seg = c->traceback.back().segment_max_size;
-			c->res.max_segment_size = max_seg;
-			c->res.dp_segment_count = c->traceback.size();
-			c->res.short_path = 0;
-			size_t const S = c->traceback.size();
-
-			// ---- find_segments_greedy (lp.cc:335-390).  Its test #{d_rb > current_lb} <= max_segment_size (:363-364)
-			// holds exactly for current_lb >= tau_rb; tau comes from the list of column rb - 1 where that list lives
-			// (k_seg_tau: one number per traceback boundary instead of the lists; sharded: every rank for its columns).
-			c->segments.clear();
-			if (max_seg < m)
-			{
-				uint64_t const own_lo = held_lo(c), own_hi = sharded ? sh.c_hi : n;      // columns whose lists I answer for
-				std::vector<uint2> tau(S);
-				if (S > 1 && c->tau_host.size() == S)
-					tau = c->tau_host;                                          // came back with the traceback
-				else if (S > 1)
+				if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
+				if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
+				std::vector<uint64_t> cols(S);
+				for (size_t j = 0; j < S; ++j) cols[j] = c->traceback[j].rb - 1;
+				HIP_TRY(c, hipMemcpyAsync(c->d_cols, cols.data(), S * 8, hipMemcpyHostToDevice, st));
+				hipLaunchKernelGGL(k_seg_tau, dim3((uint32_t) S), dim3(64), 0, st, c->d_cols, own_lo, own_hi, max_seg, c->stride, c->d_ent, c->d_hdr, c->d_tau);
+				if (sharded)
 				{
-					if (c->cols_cap < 2 * S) { if ((rc = dev_alloc(c, &c->d_cols, 2 * S))) return rc; c->cols_cap = 2 * S; }
-					if (c->tau_cap < S) { if ((rc = dev_alloc(c, &c->d_tau, S))) return rc; c->tau_cap = S; }
-					std::vector<uint64_t> cols(S);
-					for (size_t j = 0; j < S; ++j) cols[j] = c->traceback[j].rb - 1;
-					HIP_TRY(c, hipMemcpyAsync(c->d_cols, cols.data(), S * 8, hipMemcpyHostToDevice, st));
-					hipLaunchKernelGGL(k_seg_tau, dim3((uint32_t) S), dim3(64), 0, st, c->d_cols, own_lo, own_hi, max_seg, c->stride, c->d_ent, c->d_hdr, c->d_tau);
-					if (sharded)
-					{
-						HIP_TRY(c, hipMemcpyAsync(sh.xbuf, c->d_tau, S * 8, hipMemcpyDeviceToDevice, st));
-						if ((rc = shard_exchange(c, 2 * S, 0))) return rc;
-						HIP_TRY(c, hipMemcpyAsync(tau.data(), sh.xbuf, S * 8, hipMemcpyDeviceToHost, st));
-					}
-					else
-						HIP_TRY(c, hipMemcpyAsync(tau.data(), c->d_tau, S * 8, hipMemcpyDeviceToHost, st));
-					HIP_TRY(c, hipStreamSynchronize(st));
-					HIP_TRY(c, hipGetLastError());
+					HIP_TRY(c, hipMemcpyAsync(sh.xbuf, c->d_tau, S * 8, hipMemcpyDeviceToDevice, st));
+					if ((rc = shard_exchange(c, 2 * S, 0))) return rc;
+					HIP_TRY(c, hipMemcpyAsync(tau.data(), sh.xbuf, S * 8, hipMemcpyDeviceToHost, st));
 				}
-				// the walk itself; a merged segment's size is the count at its last boundary (:366), asked for afterwards
-				struct Pending { size_t seg; uint64_t col, lb; };
-				std::vector<Pending> ask;
-				uint64_t current_lb = 0;
-				uint64_t prev_size = c->traceback[0].segment_size;
-				bool prev_size_pending = false;
-				size_t prev = 0;
-				auto emit = [&]() {
-					fseq_segment sg{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
-					if (prev_size_pending) ask.push_back(Pending{c->segments.size(), c->traceback[prev].rb - 1, current_lb});
-					c->segments.push_back(sg);
-				};
-				for (size_t j = 1; j < S && !overflow; ++j)
-				{
-					uint2 const t = tau[j];
-					bool const fits = t.y != SEG_TAU_NEVER && current_lb >= t.x;
-					if (!fits && t.y == SEG_TAU_OPEN) { overflow = true; break; }     // the list ended before it could tell
-					if (fits)
-						prev_size_pending = true;                                       // prev_size = the count at boundary j (:366)
-					else
-					{
-						emit();
-						prev_size = c->traceback[j].segment_size;
-						prev_size_pending = false;
-						current_lb = c->traceback[prev].rb;
-					}
-					prev = j;
-				}
-				if (!overflow)
+				else
+					HIP_TRY(c, hipMemcpyAsync(tau.data(), c->d_tau, S * 8, hipMemcpyDeviceToHost, st));
+				HIP_TRY(c, hipStreamSynchronize(st));
+				HIP_TRY(c, hipGetLastError());
+			}
+			// the walk itself; a merged segment's size is the count at its last boundary (:366), asked for afterwards
+			struct Pending { size_t seg; uint64_t col, lb; };
+			std::vector<Pending> ask;
+			uint64_t current_lb = 0;
+			uint64_t prev_size = c->traceback[0].segment_size;
+			bool prev_size_pending = false;
+			size_t prev = 0;
+			auto emit = [&]() {
+				fseq_segment sg{current_lb, c->traceback[prev].rb, (uint32_t) prev_size, 0};
+				if (prev_size_pending) ask.push_back(Pending{c->segments.size(), c->traceback[prev].rb - 1, current_lb});
+				c->segments.push_back(sg);
+			};
+			for (size_t j = 1; j < S && !overflow; ++j)
+			{
+				uint2 const t = tau[j];
+				bool const fits = t.y != SEG_TAU_NEVER && current_lb >= t.x;
+				if (!fits && t.y == SEG_TAU_OPEN) { overflow = true; break; }     // the list ended before it could tell
+				if (fits)
+					prev_size_pending = true;                                       // prev_size = the count at boundary j (:366)
+				else
 				{
 					emit();
-					if (!ask.empty())
+					prev_size = c->traceback[j].segment_size;
+					prev_size_pending = false;
+					current_lb = c->traceback[prev].rb;
+				}
+				prev = j;
+			}
+			if (!overflow)
+			{
+				emit();
+				if (!ask.empty())
+				{
+					size_t const Q = ask.size();
+					std::vector<uint64_t> qc(2 * Q);
+					for (size_t i = 0; i < Q; ++i) { qc[i] = ask[i].col; qc[Q + i] = ask[i].lb; }
+					std::vector<uint32_t> cnt(Q);
+					if (c->cols_cap < 2 * Q) { if ((rc = dev_alloc(c, &c->d_cols, 2 * Q))) return rc; c->cols_cap = 2 * Q; }
+					if (c->tau_cap < Q) { if ((rc = dev_alloc(c, &c->d_tau, Q))) return rc; c->tau_cap = Q; }
+					HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc.data(), 2 * Q * 8, hipMemcpyHostToDevice, st));
+					uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->d_tau);
+					hipLaunchKernelGGL(k_seg_count, dim3((uint32_t) Q), dim3(64), 0, st, c->d_cols, c->d_cols + Q, own_lo, own_hi, c->stride, c->d_ent, c->d_hdr, d_cnt);
+					if (sharded)
 					{
-						size_t const Q = ask.size();
-						std::vector<uint64_t> qc(2 * Q);
-						for (size_t i = 0; i < Q; ++i) { qc[i] = ask[i].col; qc[Q + i] = ask[i].lb; }
-						std::vector<uint32_t> cnt(Q);
-						if (c->cols_cap < 2 * Q) { if ((rc = dev_alloc(c, &c->d_cols, 2 * Q))) return rc; c->cols_cap = 2 * Q; }
-						if (c->tau_cap < Q) { if ((rc = dev_alloc(c, &c->d_tau, Q))) return rc; c->tau_cap = Q; }
-						HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc.data(), 2 * Q * 8, hipMemcpyHostToDevice, st));
-						uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->d_tau);
-						hipLaunchKernelGGL(k_seg_count, dim3((uint32_t) Q), dim3(64), 0, st, c->d_cols, c->d_cols + Q, own_lo, own_hi, c->stride, c->d_ent, c->d_hdr, d_cnt);
-						if (sharded)
-						{
-							HIP_TRY(c, hipMemcpyAsync(sh.xbuf, d_cnt, Q * 4, hipMemcpyDeviceToDevice, st));
-							if ((rc = shard_exchange(c, Q, 0))) return rc;
-							HIP_TRY(c, hipMemcpyAsync(cnt.data(), sh.xbuf, Q * 4, hipMemcpyDeviceToHost, st));
-						}
-						else
-							HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, Q * 4, hipMemcpyDeviceToHost, st));
-						HIP_TRY(c, hipStreamSynchronize(st));
-						HIP_TRY(c, hipGetLastError());
-						for (size_t i = 0; i < Q; ++i) c->segments[ask[i].seg].segment_size = cnt[i];
+						HIP_TRY(c, hipMemcpyAsync(sh.xbuf, d_cnt, Q * 4, hipMemcpyDeviceToDevice, st));
+						if ((rc = shard_exchange(c, Q, 0))) return rc;
+						HIP_TRY(c, hipMemcpyAsync(cnt.data(), sh.xbuf, Q * 4, hipMemcpyDeviceToHost, st));
 					}
+					else
+						HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, Q * 4, hipMemcpyDeviceToHost, st));
+					HIP_TRY(c, hipStreamSynchronize(st));
+					HIP_TRY(c, hipGetLastError());
+					for (size_t i = 0; i < Q; ++i) c->segments[ask[i].seg].segment_size = cnt[i];
 				}
 			}
 		}
-		ms_host += now_ms() - th0;
-		FSEQ_RANGE_POP();
-		if (!overflow) progress(c, FSEQ_STAGE_MERGE, c->traceback.size(), c->traceback.size());
-		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] host: traceback + merge %.3f ms\n", now_ms() - th0);
-		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
-		if (!overflow) break;
-		if (X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
-		X = (uint32_t) std::min<uint64_t>(m, (uint64_t) X * 2 + 1);
-		++retries;
-		if (getenv("FSEQ_DEBUG")) fprintf(stderr, "[fseq] divergence lists too short, retry %u with X = %u\n", retries, X);
 	}
-	c->X_hint = X;                           // later runs on this context start with the capacity that worked
-	c->res.segment_count = c->segments.size();
+	*overflow_out = overflow;
+	return FSEQ_OK;
+}
 
-	// ---- pass 2: (a,d) at the merged boundaries (update_pbwt_task.cc:13-35)
-	uint64_t pass2_cells = 0;
-	double ms_p2 = 0;
+int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
+{
+	FSEQ_LONG_LOCALS(c);
+	uint32_t &X = R.X;
+	double &ms_c = R.ms_c, &ms_dp = R.ms_dp, &ms_host = R.ms_host;
+	bool const keyspace = R.keyspace;
+	if ((rc = ensure_work_buffers(c, X))) return rc;
+	// ---- phase C + D
+#if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
+	HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 1024, st));
+#else
+	HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 16, st));
+#endif
+	if (c->tune.poison_lists)
+	{
+		// tests of the DP-beside-phase-C forms: a list read before it is written must not look right by accident
+		HIP_TRY(c, hipMemsetAsync(c->d_ent_alloc, 0xFF, ((size_t) (held_hi(c) - held_lo(c)) * c->stride + 256) * sizeof(uint2), st));
+		HIP_TRY(c, hipMemsetAsync(c->d_hdr, 0xFF, (size_t) n * sizeof(uint4), st));
+	}
+	// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
+	// rounds whose lists are complete, on a second stream: the DP of a column prefix runs while later
+	// columns are still being produced.  Only where one workgroup of the column kernel fills a CU (16-bit
+	// and streamed state) and a launch has several waves of them anyway: a part is then ncu - 1
+	// workgroups per wave, which leaves the DP (a whole CU's LDS) a CU of its own.  FSEQ_C_PARTS forces a count.
+	DpSchedule const S = dp_schedule((uint32_t) L, (uint32_t) n);
+	// default: the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp);
+	// the forms that run the serial DP beside phase C remain for FSEQ_DP_SERIAL and the forced test schedules
+	SpecPlan const spec = spec_plan(c, S);
+	bool const use_spec = sharded || (spec.nchunks() > 0 && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks);
+	if (sharded && spec.nchunks() < 1) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: no DP chunk plan");
+	// columns phase C covers here: all, or my blocks plus the halo block's first columns (the lists my last DP round reads)
+	uint64_t const n_c = sharded ? sh.c_end : n;
+	uint32_t spec_overflow = 0, spec_sweeps = 0;
+	uint32_t parts = 1, part_blocks = c->nblocks;
+	if (!use_spec)
+	{
+		int ncu = 0;
+		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+		uint32_t const per_cu = c->use_stream ? 1u : ks.columns_resident(c->lds_columns);
+		if (per_cu == 1u && ncu > 1 && c->nblocks >= 2u * (uint32_t) ncu)
+		{
+			uint32_t const wave_blocks = (uint32_t) ncu - 1u;
+			uint32_t const waves = (c->nblocks + wave_blocks - 1) / wave_blocks;
+			part_blocks = wave_blocks * ((waves + 7u) / 8u);
+			parts = (c->nblocks + part_blocks - 1) / part_blocks;
+		}
+		if (c->tune.c_parts)
+		{
+			parts = (uint32_t) std::min<long>(16, std::max<long>(1, c->tune.c_parts));
+			parts = std::min(parts, c->nblocks);
+			part_blocks = (c->nblocks + parts - 1) / parts;
+			parts = (c->nblocks + part_blocks - 1) / part_blocks;
+		}
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[3], st));
+	FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
+	auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
+		if (c->use_stream && c->s2.T)
+		{
+			uint32_t pack_abits = 0;
+			if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
+			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
+			c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
+			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
+		}
+		else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !c->tune.stream_plain_scan)
+			hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
+		else if (c->use_stream)
+			hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
+		else
+			ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
+			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+	};
+	// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
+	// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
+	// launches on the second stream).  Phase C keeps its efficiency (no drain between parts).
+	bool const host_flags = (parts > 1 && !c->tune.c_parts && !c->tune.no_host_flags) || c->tune.host_flags;
+	if (host_flags)
+	{
+		if (c->done_cap < c->nblocks)
+		{
+			if (c->h_done) (void) hipHostFree(c->h_done);
+			c->h_done = nullptr;
+			HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_done), (size_t) c->nblocks * 4, hipHostMallocMapped | hipHostMallocCoherent));
+			HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0));
+			memset(c->h_done, 0, (size_t) c->nblocks * 4);
+			c->done_cap = c->nblocks;
+			c->epoch = 0;
+		}
+		uint32_t const epoch = ++c->epoch;
+		hipStream_t const st2 = c->stream2;
+		launch_columns(0, c->nblocks, c->d_done, epoch);
+		HIP_TRY(c, hipEventRecord(c->ev[4], st));
+		HIP_TRY(c, hipGetLastError());
+		// the host follows the completed block prefix and hands the DP the rounds whose lists are complete
+		uint32_t prefix = 0, r_done = 0;
+		uint32_t const min_rounds = c->tune.host_flags ? 1u : std::max(64u, S.nrounds / 12u);   // forced (tests): as many resumed launches as possible
+		bool dp_started = false;
+		double const t_wait0 = now_ms();
+		while (r_done < S.nrounds)
+		{
+			while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
+			uint32_t const r1 = (prefix == c->nblocks) ? S.nrounds : dp_rounds_within(S, std::min<uint64_t>(n, (uint64_t) prefix * c->B));
+			if (r1 > r_done && (r1 - r_done >= min_rounds || prefix == c->nblocks))
+			{
+				if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
+				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, r_done, r1, DpSpecArgs{});
+				r_done = r1;
+				continue;
+			}
+			hipError_t const q = hipStreamQuery(st);
+			if (q != hipErrorNotReady && prefix < c->nblocks)
+			{
+				// phase C is over: either it failed (report that, not a time-out) or every flag is there
+				if (q != hipSuccess) return fail(c, FSEQ_E_HIP, "phase C failed", q);
+				while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
+				if (prefix < c->nblocks) return fail(c, FSEQ_E_HIP, "internal: phase C finished without flagging every block");
+				continue;
+			}
+			if (now_ms() - t_wait0 > 600e3) return fail(c, FSEQ_E_HIP, "timed out waiting for phase C");
+			if (now_ms() - t_wait0 > 50.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
+		HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
+	}
+	else if (parts <= 1)
+	{
+		if (use_spec)
+		{
+			// the arrays the speculative DP starts from are reset on the second stream while phase C runs
+			if ((rc = dp_spec_reset(c, spec, c->stream2))) return rc;
+			HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
+		}
+		if (!sharded) launch_columns(0, c->nblocks);
+		if (sync_at(c, 'C')) { fprintf(stderr, "[fseq] phase C queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase C done\n"); }
+		if (sharded && my_blocks)
+		{
+			// my blocks, and the block behind them for as far as the halo reaches (k_columns stops at n_c)
+			uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
+			launch_columns(b_lo, nb);
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[4], st));
+		// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
+		// each resuming from the arrays the one before it flushed
+		uint32_t chunks = 1;
+		if (c->tune.dp_chunks) chunks = (uint32_t) c->tune.dp_chunks;
+		chunks = std::min(chunks, S.nrounds);
+		HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
+		if (use_spec)
+		{
+			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_part[15], 0));      // the DP arrays were reset beside phase C
+			if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps, true))) return rc;
+		}
+		else if (chunks <= 1)
+			hipLaunchKernelGGL(k_dp<DP_WHOLE>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+			                   c->d_flags, 0u, S.nrounds, DpSpecArgs{});
+		for (uint32_t k = 0; !use_spec && chunks > 1 && k < chunks; ++k)
+		{
+			uint32_t const r0 = (uint32_t) ((uint64_t) S.nrounds * k / chunks), r1 = (uint32_t) ((uint64_t) S.nrounds * (k + 1) / chunks);
+			hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+			                   c->d_flags, r0, r1, DpSpecArgs{});
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
+	}
+	else
+	{
+		hipStream_t const st2 = c->stream2;
+		uint32_t r_done = 0;
+		bool dp_started = false;
+		for (uint32_t k = 0; k < parts; ++k)
+		{
+			uint32_t const b0 = k * part_blocks, nb = std::min(part_blocks, c->nblocks - b0);
+			launch_columns(b0, nb);
+			HIP_TRY(c, hipEventRecord(c->ev_part[k], st));
+			uint64_t const col_hi = std::min<uint64_t>(n, (uint64_t) (b0 + nb) * c->B);
+			uint32_t const r1 = (k + 1 == parts) ? S.nrounds : dp_rounds_within(S, col_hi);
+			if (r1 > r_done)
+			{
+				HIP_TRY(c, hipStreamWaitEvent(st2, c->ev_part[k], 0));
+				if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
+				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
+				                   c->d_flags, r_done, r1, DpSpecArgs{});
+				r_done = r1;
+			}
+		}
+		HIP_TRY(c, hipEventRecord(c->ev[4], st));
+		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
+		HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[5], st));
+	HIP_TRY(c, hipGetLastError());
+
+	uint32_t h_flags[4] = {0, 0, 0, 0};
+	HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
+	if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	{
+		float f = 0;
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev_dp[0], c->ev_dp[1])); ms_dp += f;     // overlaps phase C when that runs in parts
+	}
+#ifdef FSEQ_DP_STAMPS
+	{
+		unsigned long long stamps[96];
+		HIP_TRY(c, hipMemcpy(stamps, c->d_flags + 8, sizeof(stamps), hipMemcpyDeviceToHost));
+		for (int w = 0; w < 16; ++w)
+		{
+			unsigned long long const *q = stamps + 48 + 3 * w;
+			double const nr = (double) (stamps[3 * w + 2] ? stamps[3 * w + 2] : 1);
+			fprintf(stderr, "[dp stamps] wave %2d cycles/round: barrier 1 = %.0f, update = %.0f, barrier 2 = %.0f\n", w, q[0] / nr, q[1] / nr, q[2] / nr);
+		}
+		for (int w = 0; w < 16; ++w)
+		{
+			unsigned long long const *q = stamps + 3 * w;
+			double const nr = (double) (q[2] ? q[2] : 1);
+			fprintf(stderr, "[dp stamps] wave %2d rounds=%llu cycles/round: work=%.0f waits=%.0f\n", w, q[2], q[0] / nr, q[1] / nr);
+		}
+	}
+#endif
+#ifdef FSEQ_DP_STATS
+	{
+		uint32_t hist[34];
+		HIP_TRY(c, hipMemcpy(hist, c->d_flags + 128, sizeof(hist), hipMemcpyDeviceToHost));
+		fprintf(stderr, "[dp stats] list entries a cell needed (cell-pair path; last = more than 32):");
+		for (int i = 0; i < 34; ++i) fprintf(stderr, " %u", hist[i]);
+		fprintf(stderr, "\n");
+	}
+#endif
+	FSEQ_RANGE_POP();
+	progress(c, FSEQ_STAGE_TRACEBACK, n, n);
+	FSEQ_RANGE_PUSH("fseq traceback + find_segments_greedy");
+	double const th0 = now_ms();
+	bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
+	c->tm.dp_sweeps = spec_sweeps;
+	c->tm.dp_chunks = use_spec ? spec.nchunks() : 0u;
+
+	if (!overflow && (rc = long_traceback_and_merge(c, R, th0, &overflow))) return rc;
+	ms_host += now_ms() - th0;
+	FSEQ_RANGE_POP();
+	if (!overflow) progress(c, FSEQ_STAGE_MERGE, c->traceback.size(), c->traceback.size());
+	if (c->tune.debug) fprintf(stderr, "[fseq] host: traceback + merge %.3f ms\n", now_ms() - th0);
+	*overflow_out = overflow;
+	return FSEQ_OK;
+}
+
+// ---- pass 2: (a, d) at the merged boundaries
+int long_pass2(fseq_ctx *c, LongRun &R)
+{
+	FSEQ_LONG_LOCALS(c);
+	uint64_t &pass2_cells = R.pass2_cells;
+	double &ms_p2 = R.ms_p2;
 	size_t const S2 = c->segments.size();
+	// ---- pass 2: (a,d) at the merged boundaries (update_pbwt_task.cc:13-35)
 	if (S2)
 	{
 		if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
@@ -1997,6 +2107,41 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 		}
 	}
 
+	return FSEQ_OK;
+}
+
+int run_long_path(fseq_ctx *c, fseq_result *res)
+{
+	FSEQ_LONG_LOCALS(c);
+	LongRun R;
+	R.X = p.list_cap ? p.list_cap : std::max(FSEQ_X_FLOOR, c->X_hint);
+	c->tm = fseq_timings{};
+	c->tm.block_len = c->B;
+	c->tm.n_blocks = c->nblocks;
+	double const t_begin = now_ms();
+
+	if ((rc = ensure_work_buffers(c, 0))) return rc;
+	if ((rc = long_phase_a(c, R))) return rc;
+	if ((rc = long_phase_b(c, R))) return rc;
+	if ((rc = long_list_capacity(c, R))) return rc;
+	while (true)
+	{
+		bool overflow = false;
+		if ((rc = long_attempt(c, R, &overflow))) return rc;
+		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
+		if (!overflow) break;
+		if (R.X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
+		R.X = (uint32_t) std::min<uint64_t>(m, (uint64_t) R.X * 2 + 1);
+		++R.retries;
+		if (c->tune.debug) fprintf(stderr, "[fseq] divergence lists too short, retry %u with X = %u\n", R.retries, R.X);
+	}
+	c->X_hint = R.X;                         // later runs on this context start with the capacity that worked
+	c->res.segment_count = c->segments.size();
+	if ((rc = long_pass2(c, R))) return rc;
+	uint32_t const X = R.X, retries = R.retries;
+	double const ms_c = R.ms_c, ms_dp = R.ms_dp, ms_host = R.ms_host, ms_p2 = R.ms_p2;
+	uint64_t const pass2_cells = R.pass2_cells;
+	size_t const S2 = c->segments.size();
 	{
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[0], c->ev[1])); c->tm.ms_phase_a = f;
@@ -2040,7 +2185,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
 	}
 	// one block [0, n): ranked in key space (fseq_blockkeys.hpp); FSEQ_PHASE_A_CLASSIC: the per-column sweep
-	if (c->bk_cap_words && !getenv("FSEQ_PHASE_A_CLASSIC"))
+	if (c->bk_cap_words && !c->tune.phase_a_classic)
 	{
 		if (c->use_stream)
 		{
@@ -2051,7 +2196,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				c->bkws_words = per;
 			}
 			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
-			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, getenv("FSEQ_BLOCKKEYS_WIDE") ? 1u : 0u);
+			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, c->tune.blockkeys_wide ? 1u : 0u);
 		}
 		else
 		{
@@ -2141,6 +2286,7 @@ int fseq_create(fseq_params const *params, fseq_ctx **out)
 	if (hipSetDevice(params->device) != hipSuccess) return FSEQ_E_HIP;
 	fseq_ctx *c = new fseq_ctx();
 	c->p = *params;
+	c->tune.from_environment();                  // the only look at the environment: fseq_debug_set_tuning changes a knob afterwards
 	if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	if (hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess) { fseq_destroy(c); return FSEQ_E_HIP; }
 	for (auto &e : c->ev_part)
@@ -2401,6 +2547,14 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 
 /* replaces: nothing in the reference (one process, one address space).  A context that shares its device with other
  * contexts or ranks plans its pass-2 stride states inside `bytes` of device memory in all (0 = whatever is free). */
+int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
+{
+	if (!c || !name) return FSEQ_E_ARG;
+	if (!c->tune.set(name, value)) return fail(c, FSEQ_E_ARG, "unknown tuning knob");
+	c->kernels_ready = false;                    // (the geometry and the kernel choice may depend on it)
+	return FSEQ_OK;
+}
+
 int fseq_get_join_profile(fseq_ctx const *c, fseq_join_profile *out)
 {
 	if (!c || !out) return FSEQ_E_ARG;
@@ -2522,7 +2676,7 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 	size_t const m = c->p.m, S = c->segments.size();
 	double const t0 = now_ms();
 	uint32_t const X = c->res.max_segment_size;
-	if (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !getenv("FSEQ_JOIN_HOST"))
+	if (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !c->tune.join_host)
 	{
 		// class tables and co-occurrence edges where the boundary states are (fseq_joinprep.hpp); the host hands out
 		// the copies and draws the edges (the serial part of greedy_matcher.cc)

@@ -31,6 +31,11 @@ int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_
 int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
                     uint32_t *index_hbm, uint32_t *index_lds);
 
+/* The library's diagnostic knobs (FSEQ_* names, listed in csrc/fseq_api.hip `struct Tuning`): a context reads them
+ * from the environment once, at fseq_create; this sets one afterwards (value NULL = off).  Every knob selects among
+ * exact alternatives; results never depend on them.  Call before the first fseq_run_segmentation. */
+int  fseq_debug_set_tuning(fseq_ctx *ctx, char const *name, char const *value);
+
 #ifdef __cplusplus
 }
 #endif
