@@ -229,10 +229,16 @@ struct TileCarry {
 // the maximum over the threads to the left picks the threads behind the last x (equal counts) and among them the
 // largest value; a thread that holds x itself restarts with its own tail maximum.  The key's upper half is at the
 // same time the exclusive bucket count and the "seen before" test.  ~250 -> ~100 instructions per step.
-template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0>
+// PW ("pairwise"; four symbols, KS != 0): the thread's own rows without the four running maxima.  A row's value is the
+// maximum since the nearest earlier row of the thread with its symbol -- E (E - 1) / 2 compares and selects over the
+// chain maxima max d(j, e] -- and the tail maximum behind the LAST row of every symbol, which the scan needs, is a
+// dynamically indexed store: the rows write their suffix maxima into runs[symbol][thread] (LDS, [5][T] words,
+// conflict-free: lanes differ in thread mod 64), later rows over earlier ones.  ~16 instead of ~22 vector instructions
+// per row at E = 6 (every one of them 4.2 cycles of a SIMD: profiles/r03_valu_rates.txt).
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
-	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr)
+	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr, uint32_t *runs = nullptr)
 {
 	if (IDLE0 && wave_id() == 0)
 	{
@@ -268,6 +274,49 @@ __device__ __forceinline__ void partition_step(
 	using LcpT = std::conditional_t<SIGMA == 4, uint32_t, uint64_t>;
 	LcpT lcp = 0;
 	uint32_t lidx[E];
+	if constexpr (PW)
+	{
+		static_assert(!PW || (SIGMA == 4 && KS != 0), "pairwise local pass: four symbols, keyed scan");
+		// chain[e][j] = max d(j, e] for j < e (chain[e][e-1] = d[e]); pre[e] = max d[0 .. e]
+		uint32_t pre[E];
+		pre[0] = d[0];
+#pragma unroll
+		for (int e = 1; e < E; ++e) pre[e] = max(pre[e - 1], d[e]);
+		uint32_t suf[E];                                       // suf[j] = max d(j, E-1] = chain[E-1][j]; suf[E-1] = 0
+		suf[E - 1] = 0u;
+#pragma unroll
+		for (int j = E - 2; j >= 0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			uint32_t o = pre[e];                                 // no earlier row of this thread has the symbol: the whole prefix
+			uint32_t ch[E];
+			if (e >= 1)
+			{
+				ch[e - 1] = d[e];
+#pragma unroll
+				for (int j = e - 2; j >= 0; --j) ch[j] = (e == E - 1) ? suf[j] : max(ch[j + 1], d[j + 1]);
+#pragma unroll
+				for (int j = 0; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
+			}
+			dnew[e] = o;
+			asm volatile("" : "+v"(dnew[e]));
+			uint32_t const sh = s[e] * 4u;
+			lidx[e] = (uint32_t) (lcp >> sh) & 15u;
+			pend |= ((s[e] < 4u) && lidx[e] == 0u) ? (1u << e) : 0u;
+			lcp += (LcpT) 1u << sh;
+		}
+		// tail maximum per symbol: the whole thread if the symbol does not occur, else what follows its last row
+		uint32_t const t_ = threadIdx.x;
+#pragma unroll
+		for (int x = 0; x < 4; ++x) runs[x * T + t_] = pre[E - 1];
+#pragma unroll
+		for (int e = 0; e < E; ++e) runs[s[e] * (uint32_t) T + t_] = suf[e];
+#pragma unroll
+		for (int x = 0; x < 4; ++x) run[x] = runs[x * T + t_];
+	}
+	else
+	{
 #pragma unroll
 	for (int e = 0; e < E; ++e)
 	{
@@ -302,6 +351,7 @@ __device__ __forceinline__ void partition_step(
 			lcp += act ? ((LcpT) 1u << sh) : (LcpT) 0u;
 			has |= act ? (1u << (c & 15u)) : 0u;
 		}
+	}
 	}
 	if constexpr (SIGMA == 4)
 		has = ((lcp & 0xFu) ? 1u : 0u) | ((lcp & 0xF0u) ? 2u : 0u) | ((lcp & 0xF00u) ? 4u : 0u) | ((lcp & 0xF000u) ? 8u : 0u);
