@@ -289,6 +289,7 @@ struct Tuning {
 	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
 	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
+	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
 	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
 	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
 	bool ss_unpacked = false;            // FSEQ_SS_UNPACKED: 8-byte stride states in the streamed regime
@@ -321,6 +322,7 @@ struct Tuning {
 		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
 		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
 		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
+		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
 		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
@@ -339,7 +341,7 @@ struct Tuning {
 	{
 		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_PHASE_A_CLASSIC",
-			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
+			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
@@ -1473,7 +1475,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
 		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
 		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, c->tune.blockkeys_wide ? 1u : 0u);
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u));
 	}
 	else if (keyspace)
 	{
@@ -2196,7 +2198,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				c->bkws_words = per;
 			}
 			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
-			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, c->tune.blockkeys_wide ? 1u : 0u);
+			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u));
 		}
 		else
 		{

@@ -603,6 +603,165 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m,
 	return base;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Pair leaf (2-bit symbols): the dense rank of the 32-bit key of SIXTEEN columns in one go.  A leaf (8 columns) used to
+// cost a word build (2 B per row written), its rank (read, read, write) and half a merge with its neighbour (two reads of
+// two id arrays, one write): ~15 B per row and leaf through L2 / HBM, which is what bounds the streamed tree.  Here the
+// two leaf words of a row are rebuilt from the packed columns in every pass (a 16 x 8 transpose of 2-bit symbols in
+// registers: byte permutes + two delta swaps per 4 x 4 tile) instead of being kept in memory:
+//   pass 1  both words -> one bit each in two 65,536-bit maps (first bitmap);             prefix popcounts of both
+//   pass 2  both ranks (id_lo < D_lo, id_hi < D_hi) -> bit id_hi * D_lo + id_lo (second bitmap);   prefix popcounts
+//   pass 3  the rank of that bit -> out[row]
+// 3 x 4 B of columns + 2 B of ids per row and pair = 7 B per row and leaf.  Returns the number of distinct keys, or
+// BK_PAIR_NO (uniformly, bitmaps clean) when D_lo * D_hi does not fit the part of the maps that is left -- the caller
+// then takes the two leaves one by one.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t BK_PAIR_NO = 0xFFFFFFFFu;
+
+// cw[c] = the 16 rows' symbols of column c (row j at bits 2j) -> out[i] = word(row 2i) | word(row 2i + 1) << 16,
+// word(row) = column c at bits 2c
+__device__ __forceinline__ void bk_words8(uint32_t const (&cw)[8], uint32_t (&out)[8])
+{
+#pragma unroll
+	for (uint32_t b = 0; b < 4; ++b)
+	{
+		uint32_t const sel = b | ((4u + b) << 8) | 0x0C0C0000u;                       // byte b of S1, byte b of S0, 0, 0
+		uint32_t const p01 = __builtin_amdgcn_perm(cw[1], cw[0], sel), p23 = __builtin_amdgcn_perm(cw[3], cw[2], sel);
+		uint32_t const p45 = __builtin_amdgcn_perm(cw[5], cw[4], sel), p67 = __builtin_amdgcn_perm(cw[7], cw[6], sel);
+		uint32_t x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                    // byte c = rows 4b .. 4b+3 of column c
+		uint32_t y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);                    // ... of column 4 + c
+		// 4 x 4 transpose of 2-bit elements: (c, r) at bit 8c + 2r -> (r, c) at bit 8r + 2c
+		uint32_t t;
+		t = ((x >> 6) ^ x) & 0x00CC00CCu; x ^= t ^ (t << 6);
+		t = ((x >> 12) ^ x) & 0x0000F0F0u; x ^= t ^ (t << 12);
+		t = ((y >> 6) ^ y) & 0x00CC00CCu; y ^= t ^ (t << 6);
+		t = ((y >> 12) ^ y) & 0x0000F0F0u; y ^= t ^ (t << 12);
+		out[2 * b] = __builtin_amdgcn_perm(y, x, 0x05010400u);                        // rows 4b, 4b + 1: {x0, y0, x1, y1}
+		out[2 * b + 1] = __builtin_amdgcn_perm(y, x, 0x07030602u);                    // rows 4b + 2, 4b + 3
+	}
+}
+
+// exclusive prefix popcounts of the words bm[0 .. nW) into pref[0 .. nW); returns the total.  Three barriers; the last
+// one makes pref visible.
+template <int T, typename PrefT>
+__device__ __forceinline__ uint32_t bk_prefix_words(uint32_t const *bm, PrefT *pref, uint32_t nW, uint32_t *scr)
+{
+	constexpr uint32_t NW = T / WAVE;
+	uint32_t const tid = threadIdx.x;
+	uint32_t const per = (nW + T - 1) / T, w0 = tid * per;
+	uint32_t s = 0;
+	for (uint32_t q = 0; q < per; ++q)
+		if (w0 + q < nW) s += (uint32_t) __popc(bm[w0 + q]);
+	uint32_t const inc = wave_incl_add(s);
+	__syncthreads();                                           // (the scratch may still be read by the call before)
+	if (lane_id() == 63) scr[wave_id()] = inc;
+	__syncthreads();
+	uint32_t pre = 0, total = 0;
+#pragma unroll
+	for (uint32_t w = 0; w < NW; ++w)
+	{
+		uint32_t const x = scr[w];
+		if (w < wave_id()) pre += x;
+		total += x;
+	}
+	uint32_t run = pre + inc - s;
+	for (uint32_t q = 0; q < per; ++q)
+		if (w0 + q < nW) { pref[w0 + q] = (PrefT) run; run += (uint32_t) __popc(bm[w0 + q]); }
+	__syncthreads();
+	return total;
+}
+
+template <int T, typename IdT, typename PrefT>
+__device__ __forceinline__ uint32_t bk_pair_leaf(BkState<IdT, PrefT> &S, uint32_t m, uint8_t const *__restrict__ msa, size_t ld, uint64_t kc, uint32_t nc,
+                                                 IdT *__restrict__ out)
+{
+	constexpr uint32_t LW = BK_LEAF_BITS / 32u;                // words of one leaf map
+	uint32_t const tid = threadIdx.x;
+	uint32_t *const bmA = S.bm0, *const bmB = S.bm0 + S.cap_words;
+	// both bitmaps clean (a rank operation leaves its own bitmap to the next one to clear)
+	for (uint32_t w = tid; w < S.used_a; w += T) bmA[w] = 0u;
+	for (uint32_t w = tid; w < S.used_b; w += T) bmB[w] = 0u;
+	S.used_a = S.used_b = 0u;
+	__syncthreads();
+	uint32_t const nq = (m + 15u) / 16u;                       // row groups: 16 rows share a 32-bit word of a packed column
+	auto load_words = [&](uint32_t q, uint32_t (&lo)[8], uint32_t (&hi)[8]) {
+		uint32_t cl_[8], ch_[8];
+#pragma unroll
+		for (uint32_t c = 0; c < 8; ++c)
+		{
+			cl_[c] = (c < nc) ? *reinterpret_cast<uint32_t const *>(msa + (kc + c) * ld + (size_t) q * 4u) : 0u;
+			ch_[c] = (8u + c < nc) ? *reinterpret_cast<uint32_t const *>(msa + (kc + 8u + c) * ld + (size_t) q * 4u) : 0u;
+		}
+		bk_words8(cl_, lo);
+		bk_words8(ch_, hi);
+	};
+	// ---- pass 1
+	for (uint32_t q = tid; q < nq; q += T)
+	{
+		uint32_t lo[8], hi[8];
+		load_words(q, lo, hi);
+#pragma unroll
+		for (uint32_t j = 0; j < 16; ++j)
+			if (q * 16u + j < m)
+			{
+				uint32_t const wl = (lo[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu, wh = (hi[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu;
+				uint32_t const bl = 1u << (wl & 31u), bh = 1u << (wh & 31u);
+				if (!(bmA[wl >> 5] & bl)) atomicOr(&bmA[wl >> 5], bl);
+				if (!(bmA[LW + (wh >> 5)] & bh)) atomicOr(&bmA[LW + (wh >> 5)], bh);
+			}
+	}
+	__syncthreads();
+	uint32_t const both = bk_prefix_words<T, PrefT>(bmA, S.pref, 2u * LW, S.sscr);
+	uint32_t const Dlo = (uint32_t) S.pref[LW], Dhi = both - Dlo;
+	uint32_t const W = (uint32_t) (((uint64_t) Dlo * Dhi + 31u) >> 5);
+	if ((uint64_t) Dlo * Dhi > (uint64_t) (S.cap_words - 2u * LW) * 32u || S.cap_words < 2u * LW + 64u)
+	{
+		for (uint32_t w = tid; w < 2u * LW; w += T) bmA[w] = 0u;
+		__syncthreads();
+		return BK_PAIR_NO;
+	}
+	PrefT *const prefM = S.pref + 2u * LW;
+	auto ids_of = [&](uint32_t wl, uint32_t wh) -> uint32_t {
+		uint32_t const il = (uint32_t) S.pref[wl >> 5] + (uint32_t) __popc(bmA[wl >> 5] & ((1u << (wl & 31u)) - 1u));
+		uint32_t const ih = (uint32_t) S.pref[LW + (wh >> 5)] + (uint32_t) __popc(bmA[LW + (wh >> 5)] & ((1u << (wh & 31u)) - 1u)) - Dlo;
+		return ih * Dlo + il;
+	};
+	// ---- pass 2
+	for (uint32_t q = tid; q < nq; q += T)
+	{
+		uint32_t lo[8], hi[8];
+		load_words(q, lo, hi);
+#pragma unroll
+		for (uint32_t j = 0; j < 16; ++j)
+			if (q * 16u + j < m)
+			{
+				uint32_t const k = ids_of((lo[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu, (hi[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu);
+				uint32_t const bit = 1u << (k & 31u);
+				if (!(bmB[k >> 5] & bit)) atomicOr(&bmB[k >> 5], bit);
+			}
+	}
+	__syncthreads();
+	uint32_t const D = bk_prefix_words<T, PrefT>(bmB, prefM, W, S.sscr);
+	// ---- pass 3
+	for (uint32_t q = tid; q < nq; q += T)
+	{
+		uint32_t lo[8], hi[8];
+		load_words(q, lo, hi);
+#pragma unroll
+		for (uint32_t j = 0; j < 16; ++j)
+			if (q * 16u + j < m)
+			{
+				uint32_t const k = ids_of((lo[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu, (hi[j >> 1] >> (16u * (j & 1u))) & 0xFFFFu);
+				out[q * 16u + j] = (IdT) ((uint32_t) prefM[k >> 5] + (uint32_t) __popc(bmB[k >> 5] & ((1u << (k & 31u)) - 1u)));
+			}
+	}
+	__syncthreads();
+	for (uint32_t w = tid; w < 2u * LW; w += T) bmA[w] = 0u;
+	for (uint32_t w = tid; w < W; w += T) bmB[w] = 0u;
+	__syncthreads();
+	return D;
+}
+
 // dst[r] = src[r] (and dst2[r], if given) for the rows of this thread, several loads in flight
 template <int T, typename IdT>
 __device__ __forceinline__ void bk_copy(uint32_t m, IdT const *__restrict__ src, IdT *__restrict__ dst, IdT *__restrict__ dst2 = nullptr)
@@ -635,7 +794,8 @@ constexpr uint32_t BK_WIDE = 0xFFFFFFFFu;
 template <typename IdT>
 __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
-	uint32_t *__restrict__ ws_words, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
+	uint32_t *__restrict__ ws_words, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out,
+	bool pair_leaves)
 {
 	constexpr int T = 1024;
 	constexpr bool NARROW = sizeof(IdT) == 2;
@@ -663,6 +823,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.bm0[w] = 0u;
 	__syncthreads();
 	uint32_t Dacc = 0, sliced = 0;
+	bool const pairs = bsh == 2u && pair_leaves;
 
 	for (uint32_t g = 0; g < ngrp; ++g)
 	{
@@ -675,6 +836,27 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			uint64_t const kc = k0 + (uint64_t) l * cl;
 			uint32_t const nc = (uint32_t) min<uint64_t>(cl, kend - kc);
 			IdT *const top = S.stk(sp);
+			// two leaves at once where the symbols are 2 bits wide and the group has both (bk_pair_leaf)
+			if (pairs && ((l - l0) & 1u) == 0u && l + 1 < l1)
+			{
+				uint32_t const nc2 = (uint32_t) min<uint64_t>(2u * cl, kend - kc);
+				__syncthreads();                                      // (`top` may still be read by the look-ups of the merge before)
+				uint32_t const Dp = bk_pair_leaf<T, IdT, PrefT>(S, m, msa, ld, kc, nc2, top);
+				if (Dp != BK_PAIR_NO)
+				{
+					if (NARROW && Dp > 65536u) { __syncthreads(); return BK_WIDE; }
+					D[sp] = Dp; sz[sp] = 2;
+					++sp; ++l;
+					while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
+					{
+						D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced);
+						if (NARROW && D[sp - 2] > 65536u) { __syncthreads(); return BK_WIDE; }
+						sz[sp - 2] += sz[sp - 1];
+						--sp;
+					}
+					continue;
+				}
+			}
 			// The word build writes `top` by row GROUPS (the rows that share a word of the packed column), the rank
 			// operations read and write their arrays by single rows: a thread that is done with the last look-up must not
 			// overwrite a row another thread has still to read there (bk_merge does not end with a barrier).
@@ -791,7 +973,9 @@ __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
 	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide)
 {
-	// wide != 0: 32-bit ids from the start (tests; else a block is tried with halfword ids first)
+	// wide bit 0: 32-bit ids from the start (tests; else a block is tried with halfword ids first); bit 1: leaves one by one
+	bool const pair_leaves = !(wide & 2u);
+	wide &= 1u;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x)
 	{
@@ -799,10 +983,10 @@ __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		size_t const ob = (size_t) b * m;
 		uint32_t ns = wide ? BK_WIDE : blockkeys_tree_stream<uint16_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-		                                                               rank + ob, keyd + ob, nkeys + b);
+		                                                               rank + ob, keyd + ob, nkeys + b, pair_leaves);
 		if (ns == BK_WIDE)
 			ns = blockkeys_tree_stream<uint32_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-			                                     rank + ob, keyd + ob, nkeys + b);
+			                                     rank + ob, keyd + ob, nkeys + b, pair_leaves);
 		if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 	}
 }

@@ -145,6 +145,21 @@ def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
     compare_long(pkg, msa, 8, block_len=40)
 
 
+def test_streamed_phase_a_leaves_one_by_one(pkg, monkeypatch):
+    """The streamed key-space tree ranks two leaves (16 columns of 2-bit symbols) at once from the packed columns
+    (bk_pair_leaf); FSEQ_BLOCKKEYS_SINGLE keeps the leaves one by one, which is also what a pair falls back to when its
+    D_lo x D_hi bitmap does not fit (random rows: 4^8 distinct words per leaf) and what wider symbols use."""
+    monkeypatch.setenv("FSEQ_BLOCKKEYS_SINGLE", "1")
+    msa = fso.synth_msa(fso.synth_spec(48, 20, 64, 1e-4, 0), 30000, 200)
+    compare_long(pkg, msa, 8, block_len=72)
+    monkeypatch.delenv("FSEQ_BLOCKKEYS_SINGLE")
+    rng = np.random.default_rng(13)
+    msa = (rng.integers(0, 4, size=(30000, 80)) + 65).astype(np.uint8)             # every pair falls back
+    compare_long(pkg, msa, 8, block_len=40)
+    msa = fso.synth_msa(fso.synth_spec(49, 20, 64, 1e-4, 0), 30000, 100)            # odd leaf counts, a last leaf of 4 columns
+    compare_long(pkg, msa, 8, block_len=44)
+
+
 def test_streamed_phase_a_with_more_rows_than_bitmap_bits(pkg, monkeypatch):
     """A merge of the streamed key-space tree is sliced by whole `hi` values, so one value's Dlo <= m keys must fit the
     LDS bitmap: with a forced small bitmap (2048 words = 65,536 bits) and 70,000 all-distinct rows phase A must take the
