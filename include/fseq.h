@@ -120,7 +120,8 @@ int  fseq_set_matrix(fseq_ctx *ctx, uint8_t const *base, size_t row_stride, size
 /* Input already resident in HBM: column-major dense codes, one per byte, column c at d_codes + c*ld,
  * ld >= m.  sigma = number of codes (codes are < sigma: checked with one pass over the columns, FSEQ_E_ARG if a
  * larger code is found).  The buffer is borrowed, not copied (and not repacked: inputs the library uploads itself
- * are stored at 2 / 4 / 8 bits per cell by sigma). */
+ * are stored at 2 / 4 / 8 bits per cell by sigma).  The code check is one pass over the columns plus a stream
+ * synchronisation per call, and only when sigma is below what the code width can hold (sigma = 2^bits: no pass). */
 int  fseq_set_device_columns(fseq_ctx *ctx, void const *d_codes, size_t ld, uint32_t sigma);
 /* The same for columns that are already packed the way the library stores them: bits = 2, 4 or 8 per
  * code (codes < sigma <= 2^bits), row r of a column in byte r / (8 / bits) at bit (r mod (8 / bits)) * bits,

@@ -952,3 +952,51 @@ def test_host_flag_overlap_under_load(pkg, monkeypatch):
     finally:
         stop.append(1)
         th.join()
+
+
+def test_progress_counters_and_callback(pkg):
+    """fseq_set_progress / fseq_step_max / fseq_current_step (segmentation_lp_context.hh:122-127): the stages come in the
+    reference's order -- generate_traceback (steps = columns), find_segments_greedy (traceback entries),
+    update_samples_to_traceback_positions (merged boundaries) -- every stage ends at its step_max, and the counters read
+    what the last callback reported."""
+    m, n, L = 300, 6000, 25
+    msa = fso.synth_msa(fso.synth_spec(51, 8, 200, 2e-3, 0), m, n)
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.set_sequences(msa)
+    seen = []
+    ctx.set_progress(lambda stage, cur, mx: seen.append((stage, cur, mx)))
+    ctx.run()
+    stages = [s for s, _, _ in seen]
+    assert stages == sorted(stages) and set(stages) == {pkg.STAGE_TRACEBACK, pkg.STAGE_MERGE, pkg.STAGE_SAMPLES}
+    assert all(cur <= mx for _, cur, mx in seen)
+    last = {s: (cur, mx) for s, cur, mx in seen}
+    assert last[pkg.STAGE_TRACEBACK] == (n, n)
+    assert last[pkg.STAGE_MERGE] == (ctx.result.dp_segment_count, ctx.result.dp_segment_count)
+    assert last[pkg.STAGE_SAMPLES] == (ctx.result.segment_count, ctx.result.segment_count)
+    assert (ctx.current_step(), ctx.step_max()) == (seen[-1][1], seen[-1][2])
+    ctx.set_progress(None)
+    ctx.run()
+    assert len(seen) == len(stages)
+
+
+def test_tuning_is_per_context_and_read_once(pkg, monkeypatch):
+    """The FSEQ_* knobs are read from the environment when a context is created (never on the run path) and can be
+    set per context: a context created under FSEQ_PHASE_A_CLASSIC keeps the column sweep after the variable is gone,
+    another one gets it through set_tuning; unknown names are refused."""
+    m, n, L = 12000, 600, 12
+    msa = fso.synth_msa(fso.synth_spec(53, 12, 120, 3e-4, 0), m, n)
+    ref = fso.segment_long(msa, L, threads=4)
+    monkeypatch.setenv("FSEQ_BLOCKKEYS_CAP", "2048")              # (a bitmap so small that the key-space tree has to slice: phase_a_fallbacks > 0)
+    a = pkg.SegmentationContext(m, n, L, block_len=64)
+    monkeypatch.delenv("FSEQ_BLOCKKEYS_CAP")
+    b = pkg.SegmentationContext(m, n, L, block_len=64)
+    c = pkg.SegmentationContext(m, n, L, block_len=64)
+    c.set_tuning("FSEQ_PHASE_A_CLASSIC")
+    with pytest.raises(pkg.FseqError):
+        c.set_tuning("FSEQ_NO_SUCH_KNOB")
+    for ctx in (a, b, c):
+        ctx.set_sequences(msa)
+        ctx.run()
+        assert np.array_equal(ctx.reduced_traceback()["rb"], ref["reduced"]["rb"])
+    ta, tb, tc = a.timings(), b.timings(), c.timings()
+    assert tb["phase_a_fallbacks"] == 0 and tc["phase_a_fallbacks"] == 0
