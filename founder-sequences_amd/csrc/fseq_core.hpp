@@ -205,6 +205,10 @@ struct StepScratch {
 	uint32_t cnt[NW][NC];
 	uint32_t val[NW][SIGMA];
 	uint32_t has[NW];
+	// IDLE0 with the keyed scan: the idle wave scans the wave totals for everybody; pre[w] = {counts in key position (4),
+	// keys (4)} of the waves in front of wave w
+	alignas(16) uint32_t pre[NW + 1][8];
+	alignas(16) uint32_t glob[8];           // {bucket starts (4), (start << 16) + first_val (4)}
 };
 
 // Running state of a partition that is fed tile by tile (orders too long for LDS): what all the tiles
@@ -235,12 +239,67 @@ struct TileCarry {
 // dynamically indexed store: the rows write their suffix maxima into runs[symbol][thread] (LDS, [5][T] words,
 // conflict-free: lanes differ in thread mod 64), later rows over earlier ones.  ~16 instead of ~22 vector instructions
 // per row at E = 6 (every one of them 4.2 cycles of a SIMD: profiles/r03_valu_rates.txt).
-template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false>
+// FM (runs: at least 4 * T words): first_val is >= every value of the order (phase C: the id of the new column), so a bucket nobody has
+// seen needs no select -- its prefix maximum IS first_val --, and the per-row choice among the four buckets' {start,
+// prefix maximum} words is a read of the run slots (the words written there once the tail maxima have been read).
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false, bool FM = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
 	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr, uint32_t *runs = nullptr)
 {
-	if (IDLE0 && wave_id() == 0)
+	// the idle wave has nothing to do between the step's barrier and the caller's: it runs the second level of the scan
+	// (the wave totals) and hands every wave its prefix through LDS -- ~35 instructions less in every row wave, one more barrier
+	constexpr bool SCAN0 = IDLE0 && KS != 0 && SIGMA == 4 && !TILE;
+	if constexpr (SCAN0)
+	{
+		if (wave_id() == 0)
+		{
+			constexpr int NW_ = T / WAVE;
+			static_assert(NW_ <= 16, "wave totals fit one DPP row");
+			uint32_t const l = lane_id();
+#pragma unroll
+			for (int e = 0; e < E; ++e) { dst[e] = 0; dnew[e] = 0; }
+			__syncthreads();
+			bool const in = l >= 1u && l < (uint32_t) NW_;       // lane l = wave l; wave 0 has no rows
+			uint32_t wc[2], wk[4];
+#pragma unroll
+			for (int i = 0; i < 2; ++i) wc[i] = in ? scr.cnt[l & (NW_ - 1)][i] : 0u;
+#pragma unroll
+			for (int x = 0; x < 4; ++x) wk[x] = in ? scr.val[l & (NW_ - 1)][x] : 0u;
+#pragma unroll
+			for (int i = 0; i < 2; ++i)
+			{
+				wc[i] += dpp_mov<DPP_ROW_SHR1, 0xF>(0u, wc[i]);
+				if (NW_ > 2) wc[i] += dpp_mov<DPP_ROW_SHR2, 0xF>(0u, wc[i]);
+				if (NW_ > 4) wc[i] += dpp_mov<DPP_ROW_SHR4, 0xF>(0u, wc[i]);
+				if (NW_ > 8) wc[i] += dpp_mov<DPP_ROW_SHR8, 0xF>(0u, wc[i]);
+			}
+#pragma unroll
+			for (int x = 0; x < 4; ++x)
+			{
+				uint32_t k = ((x & 1) ? ((wc[x >> 1] >> 16) << KS) : ((wc[x >> 1] & 0xFFFFu) << KS)) | wk[x];
+				k = max(k, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, k));
+				if (NW_ > 2) k = max(k, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, k));
+				if (NW_ > 4) k = max(k, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, k));
+				if (NW_ > 8) k = max(k, dpp_mov<DPP_ROW_SHR8, 0xF>(0u, k));
+				wk[x] = k;
+			}
+			if (l < (uint32_t) NW_ - 1u)                           // inclusive over waves 0 .. l = exclusive of wave l + 1
+			{
+				*reinterpret_cast<uint4 *>(&scr.pre[l + 1][0]) = make_uint4((wc[0] & 0xFFFFu) << KS, (wc[0] >> 16) << KS, (wc[1] & 0xFFFFu) << KS, (wc[1] >> 16) << KS);
+				*reinterpret_cast<uint4 *>(&scr.pre[l + 1][4]) = make_uint4(wk[0], wk[1], wk[2], wk[3]);
+			}
+			if (l == (uint32_t) NW_ - 1u)                          // the totals: bucket starts
+			{
+				uint32_t const s1 = wc[0] & 0xFFFFu, s2 = s1 + (wc[0] >> 16), s3 = s2 + (wc[1] & 0xFFFFu);
+				*reinterpret_cast<uint4 *>(&scr.glob[0]) = make_uint4(0u, s1, s2, s3);
+				*reinterpret_cast<uint4 *>(&scr.glob[4]) = make_uint4(first_val, (s1 << 16) + first_val, (s2 << 16) + first_val, (s3 << 16) + first_val);
+			}
+			__syncthreads();
+			return;
+		}
+	}
+	else if (IDLE0 && wave_id() == 0)
 	{
 		static_assert(!IDLE0 || (T / WAVE > 1 && !TILE), "an idle wave needs other waves");
 		if (lane_id() == 63)
@@ -274,6 +333,31 @@ __device__ __forceinline__ void partition_step(
 	using LcpT = std::conditional_t<SIGMA == 4, uint32_t, uint64_t>;
 	LcpT lcp = 0;
 	uint32_t lidx[E];
+	// pairwise local pass, the values: dnew[e] = max d(j, e] for the nearest earlier row j of this thread with the symbol of
+	// row e, the whole prefix max d[0 .. e] when there is none.  Nothing in the scan needs them: with the idle wave running
+	// the second level (SCAN0) the row waves compute them while they wait for it.
+	auto pw_chain = [&]() {
+		uint32_t pre[E];
+		pre[0] = d[0];
+#pragma unroll
+		for (int e = 1; e < E; ++e) pre[e] = max(pre[e - 1], d[e]);
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			uint32_t o = pre[e];
+			uint32_t ch[E];                                      // ch[j] = max d(j, e]
+			if (e >= 1)
+			{
+				ch[e - 1] = d[e];
+#pragma unroll
+				for (int j = e - 2; j >= 0; --j) ch[j] = max(ch[j + 1], d[j + 1]);
+#pragma unroll
+				for (int j = 0; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
+			}
+			dnew[e] = o;
+			asm volatile("" : "+v"(dnew[e]));
+		}
+	};
 	if constexpr (PW)
 	{
 		static_assert(!PW || (SIGMA == 4 && KS != 0), "pairwise local pass: four symbols, keyed scan");
@@ -286,21 +370,10 @@ __device__ __forceinline__ void partition_step(
 		suf[E - 1] = 0u;
 #pragma unroll
 		for (int j = E - 2; j >= 0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
+		if constexpr (!SCAN0) pw_chain();
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
-			uint32_t o = pre[e];                                 // no earlier row of this thread has the symbol: the whole prefix
-			uint32_t ch[E];
-			if (e >= 1)
-			{
-				ch[e - 1] = d[e];
-#pragma unroll
-				for (int j = e - 2; j >= 0; --j) ch[j] = (e == E - 1) ? suf[j] : max(ch[j + 1], d[j + 1]);
-#pragma unroll
-				for (int j = 0; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
-			}
-			dnew[e] = o;
-			asm volatile("" : "+v"(dnew[e]));
 			uint32_t const sh = s[e] * 4u;
 			lidx[e] = (uint32_t) (lcp >> sh) & 15u;
 			pend |= ((s[e] < 4u) && lidx[e] == 0u) ? (1u << e) : 0u;
@@ -393,8 +466,50 @@ __device__ __forceinline__ void partition_step(
 		for (int i = 0; i < NC; ++i) pc[i] = 0;
 #pragma unroll
 		for (int x = 0; x < SIGMA; ++x) pk[x] = 0;
+		uint32_t base[SIGMA], cval[SIGMA], seen = 0;
 		__syncthreads();
-		if (NW == 1)
+		if constexpr (SCAN0)
+		{
+			if constexpr (PW) pw_chain();
+			__syncthreads();
+			uint4 const q0 = *reinterpret_cast<uint4 const *>(&scr.pre[wave][0]);
+			uint4 const q1 = *reinterpret_cast<uint4 const *>(&scr.pre[wave][4]);
+			uint4 const g0 = *reinterpret_cast<uint4 const *>(&scr.glob[0]);
+			uint32_t const pck[4] = {q0.x, q0.y, q0.z, q0.w}, pkk[4] = {q1.x, q1.y, q1.z, q1.w}, st[4] = {g0.x, g0.y, g0.z, g0.w};
+			if constexpr (KS == 16 && FM)
+			{
+				// {bucket start + rows in front, prefix maximum} in one word per bucket, chosen per row by a read of the run slots
+				uint4 const g1 = *reinterpret_cast<uint4 const *>(&scr.glob[4]);
+				uint32_t const alt[4] = {g1.x, g1.y, g1.z, g1.w};
+				uint32_t const t_ = threadIdx.x;
+#pragma unroll
+				for (int x = 0; x < 4; ++x)
+				{
+					uint32_t const k = max(pkk[x], ek[x] + pck[x]);
+					runs[x * T + t_] = (k >> 16) ? (st[x] << 16) + k : alt[x];
+				}
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					uint32_t const sel = runs[s[e] * (uint32_t) T + t_];
+					if ((pend >> e) & 1u) dnew[e] = max(sel & 0xFFFFu, dnew[e]);
+					dst[e] = (sel >> 16) + lidx[e];
+				}
+				return;
+			}
+			else
+			{
+#pragma unroll
+				for (int x = 0; x < SIGMA; ++x)
+				{
+					uint32_t const k = max(pkk[x & 3], ek[x] + pck[x & 3]);
+					base[x] = st[x & 3] + (k >> KS);
+					cval[x] = k & VMASK;
+					seen |= (k >> KS) ? (1u << x) : 0u;
+				}
+			}
+		}
+		else if (NW == 1)
 		{
 #pragma unroll
 			for (int i = 0; i < NC; ++i) totc[i] = readlane_u32(ic[i], 63);
@@ -443,7 +558,7 @@ __device__ __forceinline__ void partition_step(
 		}
 		// ---- this thread's prefix: key of the waves to the left against the lanes to the left (whose counts are
 		// wave-local: lifted by the count of the waves to the left); its upper part = rows of bucket x in front
-		uint32_t base[SIGMA], cval[SIGMA], seen = 0;
+		if constexpr (!SCAN0)
 		{
 			uint32_t acc = 0;
 #pragma unroll
@@ -482,6 +597,20 @@ __device__ __forceinline__ void partition_step(
 		{
 			// bucket start (< 65536 rows) and prefix maximum (< 65536) of a symbol share a word: one 4-way select per row,
 			// as a tree over the two bits of the symbol (an unused position, s = 4, reads entry 0; nothing uses it)
+			if constexpr (FM)
+			{
+				uint32_t const t_ = threadIdx.x;
+#pragma unroll
+				for (int x = 0; x < 4; ++x) runs[x * T + t_] = (base[x] << 16) | (((seen >> x) & 1u) ? cval[x] : first_val);
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					uint32_t const sel = runs[s[e] * (uint32_t) T + t_];
+					if ((pend >> e) & 1u) dnew[e] = max(sel & 0xFFFFu, dnew[e]);
+					dst[e] = (sel >> 16) + lidx[e];
+				}
+				return;
+			}
 			uint32_t pv[4];
 #pragma unroll
 			for (int x = 0; x < 4; ++x) pv[x] = (base[x] << 16) | cval[x];

@@ -609,12 +609,16 @@ __global__ __launch_bounds__(T) void k_chain(
 // (not the 1024 x 7 configuration: its 20 KiB of run slots would push the largest block lengths past the 160 KiB of a CU)
 __host__ __device__ constexpr bool columns_pairwise(int T, int E, int SIGMA) { return SIGMA == 4 && E >= 2 && E <= FSEQ_PW_MAX_E && !(T >= 1024 && E >= 7); }
 
+// the resolve of a step as a read of per-thread run slots (partition_step's FM): wherever 4 * T more words of LDS are to be had
+__host__ __device__ constexpr bool columns_lookup(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA) || (SIGMA == 4 && PK && T * E <= 10240); }
+__host__ __device__ constexpr size_t columns_run_words(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA) ? 5 * (size_t) T : columns_lookup(T, E, SIGMA, PK) ? 4 * (size_t) T : 0; }
+
 template <int T, int E, int SIGMA, bool PK>
 __host__ __device__ inline size_t columns_lds_bytes(uint32_t B)
 {
 	constexpr size_t CAP = (size_t) T * E;
 	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(PK ? (CAP + B + 1) / 2 : CAP + B, 4) + carve_bytes(CAP, 4)
-	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4) + (columns_pairwise(T, E, SIGMA) ? carve_bytes(5 * (size_t) T, 4) : 0);
+	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4) + (columns_run_words(T, E, SIGMA, PK) ? carve_bytes(columns_run_words(T, E, SIGMA, PK), 4) : 0);
 }
 
 // divergence-value histogram: one counter per id; PK: two 16-bit counters per word, updated with
@@ -681,7 +685,8 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
 	constexpr bool PW = columns_pairwise(T, E, SIGMA);
-	uint32_t *runs = PW ? cv.take<uint32_t>(5 * (size_t) T) : nullptr;
+	constexpr bool LU = columns_lookup(T, E, SIGMA, PK);
+	uint32_t *runs = LU ? cv.take<uint32_t>(columns_run_words(T, E, SIGMA, PK)) : nullptr;
 
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = EW ? (tid >= 64u ? (tid - 64u) * E : 0x7FFF0000u) : tid * E;     // 0x7FFF0000: owns nothing (every p0 + e >= m)
@@ -795,7 +800,7 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
 			// (value ids: D0 + nb <= m + B < 65536 -- the LDS of the id histogram bounds B long before -- so the keyed scan)
-			partition_step<T, E, SIGMA, false, EW, 16, PW>(d, s, D0 + j, scr, dst, dnew, nullptr, runs);
+			partition_step<T, E, SIGMA, false, EW, 16, PW, LU>(d, s, D0 + j, scr, dst, dnew, nullptr, runs);
 
 #pragma unroll
 			for (int e = 0; e < E; ++e)

@@ -64,6 +64,7 @@ struct S2Lds {
 	uint32_t cnt[T / WAVE][2];
 	uint32_t val[T / WAVE][4];
 	uint32_t red[4 * (T / WAVE) + 8];
+	uint32_t sel[4][T];                     // per thread: the four buckets' {slot, prefix maximum} words, read back per row
 };
 
 // PACK: a row of the order is 5 bytes in the workspace instead of 8 -- a word a | d << abits (abits = bits of a row id)
@@ -342,12 +343,11 @@ __device__ __forceinline__ void s2_tile_step(
 		}
 	}
 #pragma unroll
+	for (int x = 0; x < 4; ++x) L.sel[x][threadIdx.x] = pv[x];
+#pragma unroll
 	for (int e = 0; e < E; ++e)
 	{
-		uint32_t const c = s[e];
-		bool const b0 = c & 1u, b1 = c & 2u;
-		uint32_t const lo2 = b0 ? pv[1] : pv[0], hi2 = b0 ? pv[3] : pv[2];
-		uint32_t const sel = b1 ? hi2 : lo2;
+		uint32_t const sel = L.sel[s[e] & 3u][threadIdx.x];     // (a position without a row, s = 4, reads entry 0; nothing uses it)
 		lp[e] = (sel >> KS) + lidx[e];
 		if ((pend >> e) & 1u) dnew[e] = max(sel & VMASK, dnew[e]);
 	}
