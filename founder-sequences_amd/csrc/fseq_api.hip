@@ -465,6 +465,8 @@ struct fseq_ctx {
 	hipStream_t stream2 = nullptr;           // the DP, while phase C is still producing lists for later columns
 	hipEvent_t ev_part[16]{};                // part c of phase C done
 	hipEvent_t ev_dp[2]{};                   // DP begin / end on stream2
+	uint8_t *h_pin = nullptr;                // pinned host staging of a step's small transfers (pin_reserve / pin_take)
+	size_t pin_cap = 0, pin_used = 0;
 	uint32_t *h_done = nullptr, *d_done = nullptr;   // per-block "lists are in memory" flags in host-coherent memory (host / device view)
 	uint32_t done_cap = 0, epoch = 0;
 };
@@ -526,6 +528,29 @@ int dev_alloc(fseq_ctx *c, U **p, size_t count)
 	c->alloc_sizes[static_cast<void *>(*p)] = bytes;
 	c->alloc_total += bytes;
 	return FSEQ_OK;
+}
+
+// Pinned host staging.  A copy between the device and pageable host memory is staged by the runtime -- one blocking round
+// trip of 20-50 microseconds each, and a step had a dozen of them (flags, counts, the traceback, thresholds: a fifth of a
+// BASELINE C2 step).  pin_reserve(bytes) opens a stage (what the previous one handed out is dead), pin_take carves it.
+int pin_reserve(fseq_ctx *c, size_t bytes)
+{
+	c->pin_used = 0;
+	if (c->pin_cap >= bytes) return FSEQ_OK;
+	if (c->h_pin) (void) hipHostFree(c->h_pin);
+	c->h_pin = nullptr; c->pin_cap = 0;
+	size_t const cap = std::max<size_t>((bytes + 4095) & ~size_t(4095), size_t(1) << 20);
+	hipError_t const e = hipHostMalloc(reinterpret_cast<void **>(&c->h_pin), cap, hipHostMallocDefault);
+	if (e != hipSuccess) { c->h_pin = nullptr; return fail(c, FSEQ_E_OOM, "hipHostMalloc of the staging buffer", e); }
+	c->pin_cap = cap;
+	return FSEQ_OK;
+}
+template <typename U>
+U *pin_take(fseq_ctx *c, size_t count)
+{
+	size_t const at = (c->pin_used + 15) & ~size_t(15);
+	c->pin_used = at + count * sizeof(U);
+	return c->pin_used <= c->pin_cap ? reinterpret_cast<U *>(c->h_pin + at) : nullptr;      // (nullptr: the stage was reserved too small -- a bug)
 }
 
 void free_msa(fseq_ctx *c)
@@ -1046,9 +1071,12 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 	hipLaunchKernelGGL(k_tb_emit, dim3(nwin), dim3(256), 0, st, c->dp.LB, c->dp.M, c->dp.SZ, dp_size, L, d_head, d_count, c->d_tb, (uint32_t) cap);
 	// the count and -- in the same round trip -- as many entries as the last run of this context had (a second copy
 	// only when there are more this time)
-	uint32_t cnt[4] = {0, 0, 0, 0};
 	size_t const guess = std::min(cap, c->tb_guess ? c->tb_guess + 16 : (size_t) 4096);
-	std::vector<uint4> h(guess);
+	if ((rc = pin_reserve(c, guess * (sizeof(uint4) + sizeof(uint2)) + 256))) return rc;
+	uint32_t *const cnt = pin_take<uint32_t>(c, 4);
+	uint4 *const hp = pin_take<uint4>(c, guess);
+	uint2 *const taup = pin_take<uint2>(c, guess);
+	std::vector<uint4> h;
 	// not sharded: the merge thresholds of the traceback boundaries (k_seg_tau_tb) ride along -- one workgroup per
 	// POSSIBLE entry, those behind the count return at once
 	c->tau_host.clear();
@@ -1056,13 +1084,14 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 	{
 		if (c->tau_cap < cap) { if ((rc = dev_alloc(c, &c->d_tau, cap))) return rc; c->tau_cap = cap; }
 		hipLaunchKernelGGL(k_seg_tau_tb, dim3((uint32_t) cap), dim3(64), 0, st, reinterpret_cast<uint4 const *>(c->d_tb), d_count, L, c->stride, c->d_ent, c->d_hdr, c->d_tau);
-		c->tau_host.resize(guess);
-		HIP_TRY(c, hipMemcpyAsync(c->tau_host.data(), c->d_tau, guess * sizeof(uint2), hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(taup, c->d_tau, guess * sizeof(uint2), hipMemcpyDeviceToHost, st));
 	}
 	HIP_TRY(c, hipMemcpyAsync(cnt, d_count, 16, hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipMemcpyAsync(h.data(), c->d_tb, guess * sizeof(uint4), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(hp, c->d_tb, guess * sizeof(uint4), hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	HIP_TRY(c, hipGetLastError());
+	h.assign(hp, hp + std::min<size_t>(guess, cnt[0]));
+	if (!c->sh.on) c->tau_host.assign(taup, taup + std::min<size_t>(guess, cnt[0]));
 	if (cnt[1] != 1u || cnt[0] == 0 || cnt[0] > cap) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend to lb == 0");
 	size_t const S = cnt[0];
 	if (S > guess)
@@ -1342,12 +1371,16 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 				++done_sweeps;
 			}
 			compare(done_sweeps == 1);
-			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+			if ((rc = pin_reserve(c, sizeof(h) + (size_t) nch * 4 + 64))) return rc;
+			auto *const hpin = pin_take<std::remove_reference_t<decltype(h)>>(c, 1);
+			uint32_t *const opin = pin_take<uint32_t>(c, nch);
+			HIP_TRY(c, hipMemcpyAsync(hpin, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
 			// (the chunks' "list too short" words in the same round trip: final if the iteration has converged)
-			ovf_early.resize(nch);
-			HIP_TRY(c, hipMemcpyAsync(ovf_early.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipMemcpyAsync(opin, d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
 			HIP_TRY(c, hipStreamSynchronize(st));
 			HIP_TRY(c, hipGetLastError());
+			h = *hpin;
+			ovf_early.assign(opin, opin + nch);
 			if (h.done || done_sweeps >= max_sweeps) break;
 			// the compare just queued has already chosen the next sweep's active set and lifts
 			rebuild();
@@ -1741,22 +1774,23 @@ int long_traceback_and_merge(fseq_ctx *c, LongRun &R, double th0, bool *overflow
 				if (!ask.empty())
 				{
 					size_t const Q = ask.size();
-					std::vector<uint64_t> qc(2 * Q);
+					if ((rc = pin_reserve(c, Q * 20 + 64))) return rc;
+					uint64_t *const qc = pin_take<uint64_t>(c, 2 * Q);
 					for (size_t i = 0; i < Q; ++i) { qc[i] = ask[i].col; qc[Q + i] = ask[i].lb; }
-					std::vector<uint32_t> cnt(Q);
+					uint32_t *const cnt = pin_take<uint32_t>(c, Q);
 					if (c->cols_cap < 2 * Q) { if ((rc = dev_alloc(c, &c->d_cols, 2 * Q))) return rc; c->cols_cap = 2 * Q; }
 					if (c->tau_cap < Q) { if ((rc = dev_alloc(c, &c->d_tau, Q))) return rc; c->tau_cap = Q; }
-					HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc.data(), 2 * Q * 8, hipMemcpyHostToDevice, st));
+					HIP_TRY(c, hipMemcpyAsync(c->d_cols, qc, 2 * Q * 8, hipMemcpyHostToDevice, st));
 					uint32_t *d_cnt = reinterpret_cast<uint32_t *>(c->d_tau);
 					hipLaunchKernelGGL(k_seg_count, dim3((uint32_t) Q), dim3(64), 0, st, c->d_cols, c->d_cols + Q, own_lo, own_hi, c->stride, c->d_ent, c->d_hdr, d_cnt);
 					if (sharded)
 					{
 						HIP_TRY(c, hipMemcpyAsync(sh.xbuf, d_cnt, Q * 4, hipMemcpyDeviceToDevice, st));
 						if ((rc = shard_exchange(c, Q, 0))) return rc;
-						HIP_TRY(c, hipMemcpyAsync(cnt.data(), sh.xbuf, Q * 4, hipMemcpyDeviceToHost, st));
+						HIP_TRY(c, hipMemcpyAsync(cnt, sh.xbuf, Q * 4, hipMemcpyDeviceToHost, st));
 					}
 					else
-						HIP_TRY(c, hipMemcpyAsync(cnt.data(), d_cnt, Q * 4, hipMemcpyDeviceToHost, st));
+						HIP_TRY(c, hipMemcpyAsync(cnt, d_cnt, Q * 4, hipMemcpyDeviceToHost, st));
 					HIP_TRY(c, hipStreamSynchronize(st));
 					HIP_TRY(c, hipGetLastError());
 					for (size_t i = 0; i < Q; ++i) c->segments[ask[i].seg].segment_size = cnt[i];
@@ -1963,10 +1997,13 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	HIP_TRY(c, hipEventRecord(c->ev[5], st));
 	HIP_TRY(c, hipGetLastError());
 
-	uint32_t h_flags[4] = {0, 0, 0, 0};
+	if ((rc = pin_reserve(c, 64))) return rc;
+	uint32_t *const h_flags = pin_take<uint32_t>(c, 8);
+	h_flags[4] = 0;
 	HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
-	if (keyspace) HIP_TRY(c, hipMemcpyAsync(&c->tm.phase_a_fallbacks, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
+	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
+	if (keyspace) c->tm.phase_a_fallbacks = h_flags[4];
 	{
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
@@ -2063,10 +2100,20 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 			c->snap_cap = S2m;
 		}
 		if (c->src_cap < srcs.size()) { if ((rc = dev_alloc(c, &c->d_src, srcs.size()))) return rc; c->src_cap = srcs.size(); }
-		HIP_TRY(c, hipMemcpyAsync(c->d_src, srcs.data(), srcs.size() * 8, hipMemcpyHostToDevice, st));
 		if (c->grp_cap < grp.size()) { if ((rc = dev_alloc(c, &c->d_grp, grp.size()))) return rc; c->grp_cap = grp.size(); }
-		if (S2m) HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2m * 8, hipMemcpyHostToDevice, st));
-		if (!grp.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_grp, grp.data(), grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+		{
+			// (through the pinned stage: it stays untouched until the synchronisation behind the kernel)
+			if ((rc = pin_reserve(c, (srcs.size() + S2m + grp.size()) * 8 + 256))) return rc;
+			uint64_t *const psrc = pin_take<uint64_t>(c, srcs.size());
+			uint64_t *const prb = pin_take<uint64_t>(c, S2m);
+			uint2 *const pgrp = pin_take<uint2>(c, grp.size());
+			std::copy(srcs.begin(), srcs.end(), psrc);
+			std::copy(rbs.begin(), rbs.end(), prb);
+			std::copy(grp.begin(), grp.end(), pgrp);
+			if (!srcs.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_src, psrc, srcs.size() * 8, hipMemcpyHostToDevice, st));
+			if (S2m) HIP_TRY(c, hipMemcpyAsync(c->d_cols, prb, S2m * 8, hipMemcpyHostToDevice, st));
+			if (!grp.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_grp, pgrp, grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+		}
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
 		progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
 		FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
@@ -2311,6 +2358,7 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
+	if (c->h_pin) (void) hipHostFree(c->h_pin);
 	if (c->h_done) (void) hipHostFree(c->h_done);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);

@@ -198,6 +198,15 @@ constexpr int scan_shift_for(int T, int E)
 	return 32 - bits > 25 ? 25 : 32 - bits;
 }
 
+// One dword per lane from `g` into LDS at lds_addr + 4 * lane (LDS-DMA: no destination register, so nothing waits for
+// it and nothing can be clobbered by it): used to pull the NEXT tile's lines into L2 while this tile is computed.
+__device__ __forceinline__ void stream_touch(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
 template <int T, int SIGMA>
 struct StepScratch {
 	static constexpr int NW = T / WAVE;

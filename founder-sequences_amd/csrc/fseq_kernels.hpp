@@ -415,7 +415,7 @@ template <int T, int E, bool PK>
 __host__ __device__ inline size_t chain_lds_bytes()
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 4>)) + carve_bytes(T / WAVE + 1, 4);
+	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 4) + carve_bytes(1, sizeof(StepScratch<T, 4>)) + carve_bytes(T / WAVE + 1, 4) + carve_bytes(WAVE, 4);
 }
 
 __device__ __forceinline__ uint32_t rank_digits(uint32_t D)
@@ -457,6 +457,7 @@ __global__ __launch_bounds__(T) void k_chain(
 	uint32_t *kd = cv.take<uint32_t>(CAP);
 	StepScratch<T, 4> &scr = *cv.take<StepScratch<T, 4>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
+	uint32_t *sink = cv.take<uint32_t>(WAVE);                  // where the L2-warming loads land (never read)
 
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = tid * E;
@@ -494,17 +495,34 @@ __global__ __launch_bounds__(T) void k_chain(
 			}
 		}
 		// (2) prefetch the next block's rank / keyd into registers
+		// (16-bit configurations, 9+ rows per thread at 128 registers: the 2 E prefetched words were spilled to scratch
+		// across the digit passes -- there the loads only warm L2 now and are issued again in (5))
+		constexpr bool PREF = !PK;
 		uint32_t pr[E], pk[E], D_next = 0;
 		bool const more = b + 1 < b1;
 		if (more)
 		{
 			size_t const nbase = (size_t) (b + 1) * m;
-#pragma unroll
-			for (int i = 0; i < E; ++i)
+			if constexpr (PREF)
 			{
-				uint32_t const idx = tid + i * T;
-				pr[i] = idx < m ? rank[nbase + idx] : 0u;
-				pk[i] = idx < m ? keyd[nbase + idx] : 0u;
+#pragma unroll
+				for (int i = 0; i < E; ++i)
+				{
+					uint32_t const idx = tid + i * T;
+					pr[i] = idx < m ? rank[nbase + idx] : 0u;
+					pk[i] = idx < m ? keyd[nbase + idx] : 0u;
+				}
+			}
+			else
+			{
+				uint32_t const sink_addr = __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) sink);
+#pragma unroll
+				for (int i = 0; i < E; ++i)
+				{
+					uint32_t const idx = min(tid + i * T, m - 1u);
+					stream_touch(rank + nbase + idx, sink_addr);
+					stream_touch(keyd + nbase + idx, sink_addr);
+				}
 			}
 			D_next = nkeys[b + 1];
 		}
@@ -546,10 +564,16 @@ __global__ __launch_bounds__(T) void k_chain(
 		__syncthreads();
 		if (more)
 		{
+			size_t const nbase = (size_t) (b + 1) * m;
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
 				uint32_t const idx = tid + i * T;
+				if constexpr (!PREF)
+				{
+					pr[i] = idx < m ? rank[nbase + idx] : 0u;
+					pk[i] = idx < m ? keyd[nbase + idx] : 0u;
+				}
 				rk[idx] = (AT) pr[i];
 				kd[idx] = pk[i];
 			}

@@ -27,15 +27,6 @@ struct StreamLds {
 	uint32_t sink[WAVE];                             // where stream_touch's loads land (never read)
 };
 
-// One dword per lane from `g` into LDS at lds_addr + 4 * lane (LDS-DMA: no destination register, so nothing waits for
-// it and nothing can be clobbered by it): used to pull the NEXT tile's lines into L2 while this tile is computed.
-__device__ __forceinline__ void stream_touch(void const *g, uint32_t lds_addr)
-{
-	uint32_t keep;
-	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
-}
-
 // staged: plus the 2 x SCAP words in which stream_pass lays a tile out in output order
 __host__ __device__ inline size_t stream_lds_bytes(uint32_t colbytes, bool staged)
 {
