@@ -707,9 +707,12 @@ int prepare_geometry(fseq_ctx *c)
 		size_t const lds = stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged);
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK>, lds));
 		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP>, lds));
+		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_RANK, true>, lds));
+		HIP_TRY(c, allow_lds(k_colblock_stream<MODE_SNAP, true>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream<19>, lds));
 		HIP_TRY(c, allow_lds(k_columns_stream<0>, lds));
-		HIP_TRY(c, allow_lds(k_chain_stream, stream_lds_bytes(0, true)));
+		HIP_TRY(c, allow_lds(k_chain_stream<false>, stream_lds_bytes(0, true)));
+		HIP_TRY(c, allow_lds(k_chain_stream<true>, stream_lds_bytes(0, true)));
 		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
 		// (FSEQ_STREAM2=T,E[,0] picks another configuration [8-byte rows], FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
 		c->s2 = Stream2Config{};
@@ -1121,15 +1124,19 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 // the configuration's key shift (FSEQ_PLAIN_SCAN: never)
 uint32_t scan_keyed(fseq_ctx const *c)
 {
-	return (!c->use_stream && c->p.n < (1ull << c->ks.scan_shift) && !c->tune.plain_scan) ? 1u : 0u;
+	if (c->use_stream || c->tune.plain_scan) return 0u;
+	return c->p.n < (1ull << c->ks.scan_shift) ? 1u : c->p.n < (1ull << 25) ? 2u : 0u;       // row-count keys, occurrence keys, has-based scan
 }
+
+// streamed rows: occurrence keys while every column number fits 25 bits (FSEQ_PLAIN_SCAN: the has-based scan)
+bool stream_keyed(fseq_ctx const *c) { return c->p.n < (1ull << 25) && !c->tune.plain_scan; }
 
 void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0)
 {
 	fseq_params const &p = c->p;
 	if (!grid) return;
 	if (c->use_stream)
-		hipLaunchKernelGGL(k_colblock_stream<MODE_RANK>, dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
+		hipLaunchKernelGGL((stream_keyed(c) ? k_colblock_stream<MODE_RANK, true> : k_colblock_stream<MODE_RANK, false>), dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
 		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0, 0u);
@@ -1144,7 +1151,7 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 {
 	if (!grid) return;
 	if (c->use_stream)
-		hipLaunchKernelGGL(k_chain_stream, dim3(grid), dim3(ST), stream_lds_bytes(0, true), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
+		hipLaunchKernelGGL((stream_keyed(c) ? k_chain_stream<true> : k_chain_stream<false>), dim3(grid), dim3(ST), stream_lds_bytes(0, true), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
 		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	else
 		c->ks.chain(c->stream, grid, c->ks.lds_chain, rank, keyd, nkeys, c->p.m, nb_total, G, cols_per_block, start_a, start_d, out_a, out_d,
@@ -2127,7 +2134,7 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 			for (size_t g0 = 0; g0 < grp.size(); g0 += cap)
 			{
 				size_t const cnt = std::min(cap, grp.size() - g0);
-				hipLaunchKernelGGL(k_colblock_stream<MODE_SNAP>, dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
+				hipLaunchKernelGGL((stream_keyed(c) ? k_colblock_stream<MODE_SNAP, true> : k_colblock_stream<MODE_SNAP, false>), dim3((uint32_t) cnt), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
 				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
 				                   c->d_cols, c->d_grp + g0, c->d_snap_a, c->d_snap_d, c->d_src + g0, c->snap_stride, c->d_ss_a, c->d_ss_d, (uint64_t) 0, c->ss_pack);
 			}

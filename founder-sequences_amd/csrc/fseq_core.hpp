@@ -251,7 +251,11 @@ struct TileCarry {
 // FM (runs: at least 4 * T words): first_val is >= every value of the order (phase C: the id of the new column), so a bucket nobody has
 // seen needs no select -- its prefix maximum IS first_val --, and the per-row choice among the four buckets' {start,
 // prefix maximum} words is a read of the run slots (the words written there once the tail maxima have been read).
-template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false, bool FM = false>
+// KO (KS = 25): the count part of a key counts OCCURRENCES instead of rows -- lanes of the wave that hold the bucket, then
+// waves of the workgroup that do (at most 64 + 16: 7 bits) -- so the values may be anything below 2^25 whatever T * E is
+// (phase B and pass 2 scan absolute column numbers: C5's (1024, 10) had 18 bits for them, the streamed rows none).  All a
+// key's count has to do is grow wherever the bucket occurs; the rows in front of a thread come from the count scan.
+template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false, bool FM = false, bool KO = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
 	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr, uint32_t *runs = nullptr)
@@ -442,23 +446,32 @@ __device__ __forceinline__ void partition_step(
 	{
 		constexpr uint32_t VMASK = (1u << KS) - 1u;
 		static_assert(KS >= 16 && KS <= 25, "key = count << KS | value: counts of one step below 2^(32 - KS)");
-		static_assert((uint64_t) T * E < (1ull << (32 - KS)), "counts of one step must fit the key");
+		static_assert(KO || (uint64_t) T * E < (1ull << (32 - KS)), "counts of one step must fit the key");
+		static_assert(!KO || (SIGMA == 4 && KS == 25 && !IDLE0 && !PW && !FM), "occurrence keys: four buckets, 7 bits of count");
 		// ---- bucket counts: inclusive over the lanes (two 16-bit counts per word: at most T * E <= 65535 rows)
-		uint32_t ic[NC];
+		uint32_t ic[NC], own[NC];
 #pragma unroll
 		for (int i = 0; i < NC; ++i)
 		{
 			uint32_t const lo = (uint32_t) (lcp >> (8 * i)) & 15u;
 			uint32_t const hi = (uint32_t) (lcp >> (8 * i + 4)) & 15u;
-			ic[i] = wave_incl_add(lo | (hi << 16));
+			own[i] = lo | (hi << 16);
+			ic[i] = wave_incl_add(own[i]);
 		}
 		auto occ_key = [](uint32_t const (&c)[NC], int x) -> uint32_t {        // count of x, in key position
 			return (x & 1) ? ((c[x >> 1] >> 16) << KS) : ((c[x >> 1] & 0xFFFFu) << KS);
 		};
+		auto field = [](uint32_t const (&c)[NC], int x) -> uint32_t { return (x & 1) ? (c[x >> 1] >> 16) : (c[x >> 1] & 0xFFFFu); };
+		// KO: inclusive number of lanes (waves, in the second level) up to this one that hold the bucket, in key position
+		auto occurrences = [](bool h) -> uint32_t {
+			uint64_t const b = __ballot(h);
+			return (__builtin_amdgcn_mbcnt_hi((uint32_t) (b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) b, 0u)) + (h ? 1u : 0u)) << KS;
+		};
 		// ---- keys, inclusive max-scan
 		uint32_t key[SIGMA];
 #pragma unroll
-		for (int x = 0; x < SIGMA; ++x) key[x] = wave_incl_max(occ_key(ic, x) | run[x]);
+		for (int x = 0; x < SIGMA; ++x)
+			key[x] = wave_incl_max((KO ? occurrences(((uint32_t) (lcp >> (4 * x)) & 15u) != 0u) : occ_key(ic, x)) | run[x]);
 		if (NW > 1 && lane == 63)
 		{
 #pragma unroll
@@ -534,6 +547,9 @@ __device__ __forceinline__ void partition_step(
 			for (int i = 0; i < NC; ++i) wc[i] = lane < (uint32_t) NW ? scr.cnt[lane][i] : 0u;
 #pragma unroll
 			for (int x = 0; x < SIGMA; ++x) wk[x] = lane < (uint32_t) NW ? scr.val[lane][x] : 0u;
+			uint32_t wocc[SIGMA];                                  // (KO) waves up to this lane's that hold the bucket
+#pragma unroll
+			for (int x = 0; x < SIGMA; ++x) wocc[x] = KO ? occurrences(field(wc, x) != 0u) : 0u;
 #pragma unroll
 			for (int i = 0; i < NC; ++i)
 			{
@@ -545,7 +561,7 @@ __device__ __forceinline__ void partition_step(
 #pragma unroll
 			for (int x = 0; x < SIGMA; ++x)
 			{
-				uint32_t k = occ_key(wc, x) | wk[x];
+				uint32_t k = (KO ? wocc[x] : occ_key(wc, x)) | wk[x];
 				k = max(k, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, k));
 				if (NW > 2) k = max(k, dpp_mov<DPP_ROW_SHR2, 0xF>(0u, k));
 				if (NW > 4) k = max(k, dpp_mov<DPP_ROW_SHR4, 0xF>(0u, k));
@@ -573,18 +589,28 @@ __device__ __forceinline__ void partition_step(
 #pragma unroll
 			for (int x = 0; x < SIGMA; ++x)
 			{
-				uint32_t const k = max(pk[x], ek[x] + occ_key(pc, x));
+				// (KO: the count part of pk[x] IS what the waves to the left add to a wave-local count)
+				uint32_t const k = max(pk[x], ek[x] + (KO ? (pk[x] & ~VMASK) : occ_key(pc, x)));
 				uint32_t const tot = (totc[x >> 1] >> ((x & 1) * 16)) & 0xFFFFu;
+				// rows of the bucket in front of this thread (inside the tile)
+				uint32_t front = k >> KS;
+				if constexpr (KO)
+				{
+					uint32_t ex[NC];
+#pragma unroll
+					for (int i = 0; i < NC; ++i) ex[i] = ic[i] - own[i] + pc[i];      // (16-bit fields: no borrow, no carry)
+					front = field(ex, x);
+				}
 				if (TILE)
 				{
 					// (tiles to the left) (+) (threads to the left in this tile); then the carry moves past this tile
-					base[x] = tc->start[x & 3] + tc->cnt[x & 3] + (k >> KS);
+					base[x] = tc->start[x & 3] + tc->cnt[x & 3] + front;
 					cval[x] = (k >> KS) ? (k & VMASK) : max(tc->val[x & 3], k & VMASK);
 					seen |= ((k >> KS) || ((tc->has >> x) & 1u)) ? (1u << x) : 0u;
 				}
 				else
 				{
-					base[x] = acc + (k >> KS);
+					base[x] = acc + front;
 					cval[x] = k & VMASK;
 					seen |= (k >> KS) ? (1u << x) : 0u;
 					acc += tot;

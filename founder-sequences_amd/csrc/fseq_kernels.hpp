@@ -352,7 +352,9 @@ __device__ __forceinline__ void colblock_body(char *smem,
 #pragma unroll
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
-			if (keyed) partition_step<T, E, SIGMA, false, false, scan_shift_for(T, E)>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
+			// keyed: 1 = row counts in the keys (values below 2^scan_shift_for(T, E)), 2 = occurrence counts (below 2^25), 0 = has-based scan
+			if (keyed == 1u) partition_step<T, E, SIGMA, false, false, scan_shift_for(T, E)>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
+			else if (SIGMA == 4 && keyed == 2u) partition_step<T, E, 4, false, false, 25, false, false, true>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 			else partition_step<T, E, SIGMA>(d, s, (uint32_t) (k0 + j + 1) - dbase, scr, dst, dnew);
 
 #pragma unroll
@@ -445,7 +447,7 @@ __global__ __launch_bounds__(T) void k_chain(
 	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
 	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0, uint32_t keyed)
 {
-	// keyed != 0: all divergences are below 2^scan_shift_for(T, E) (n is): the partition steps scan keys
+	// keyed: 1 = all divergences are below 2^scan_shift_for(T, E) (n is), 2 = below 2^25: the partition steps scan keys
 	// workgroup i of the launch is chain grp = grp0 + i (a rank of a sharded run owns a contiguous range of chains)
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -537,7 +539,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 			for (int e = 0; e < E; ++e)
 				s[e] = (p0 + e < m) ? (((uint32_t) rk[a[e]] >> (2u * p)) & 3u) : 4u;
-			if (keyed) partition_step<T, E, 4, false, false, scan_shift_for(T, E)>(d, s, 0u, scr, dst, dnew);
+			if (keyed == 1u) partition_step<T, E, 4, false, false, scan_shift_for(T, E)>(d, s, 0u, scr, dst, dnew);
+			else if (keyed == 2u) partition_step<T, E, 4, false, false, 25, false, false, true>(d, s, 0u, scr, dst, dnew);
 			else partition_step<T, E, 4>(d, s, 0u, scr, dst, dnew);
 #pragma unroll
 			for (int e = 0; e < E; ++e)

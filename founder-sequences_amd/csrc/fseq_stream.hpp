@@ -95,7 +95,7 @@ __device__ __forceinline__ void column_digit_counts(uint8_t const *sym, uint32_t
 // One stable 4-bucket partition pass over an order of m rows held in global memory:
 // (a_src, d_src) -> (a_dst, d_dst).  KEYS: sort keys only (no divergences).  pre_cnt: bucket sizes if the
 // caller already knows them (column passes), else a counting sweep comes first.  Ends with a barrier.
-template <bool KEYS, int KS = 0, typename DF, typename HOOK>
+template <bool KEYS, int KS = 0, bool KO = false, typename DF, typename HOOK>
 __device__ __forceinline__ void stream_pass(
 	uint32_t m, uint32_t const *a_src, uint32_t const *d_src, uint32_t *a_dst, uint32_t *d_dst,
 	uint32_t first_val, DF const digit, HOOK const hook, StreamLds &L, uint32_t const *pre_cnt = nullptr, uint32_t *stage = nullptr)
@@ -165,7 +165,7 @@ __device__ __forceinline__ void stream_pass(
 		uint32_t gs[4];
 #pragma unroll
 		for (int x = 0; x < 4; ++x) gs[x] = tc.start[x] + tc.cnt[x];       // where this tile's rows of bucket x go
-		partition_step<ST, SE, 4, true, false, KS>(d, s, first_val, L.scr, dst, dnew, &tc);
+		partition_step<ST, SE, 4, true, false, KS, false, false, KO>(d, s, first_val, L.scr, dst, dnew, &tc);
 		if (stage)
 		{
 			// tile-local start of every bucket run, and what turns a global destination into a tile-local one
@@ -272,7 +272,8 @@ __device__ __forceinline__ void stream_emit_ranks(
 // ------------------------------------------------------------------------------------------------
 // phase A (MODE_RANK) and pass 2 (MODE_SNAP), streamed.  ws: [gridDim.x][4][m] words (a0, d0, a1, d1).
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+// KO: every divergence is below 2^25 (n is): the partition steps scan occurrence keys (fseq_core.hpp) instead of {has, value}
+template <int MODE, bool KO = false>
 __global__ __launch_bounds__(ST) void k_colblock_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
@@ -342,8 +343,8 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 		{
 			uint32_t cnt4[4];
 			column_digit_counts(sym, m, bsh, pass, cnt4, L.red);
-			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], (uint32_t) (k + 1),
-			                   DigitColumn{sym, bsh, pass}, NoHook{}, L, cnt4, stage);
+			stream_pass<false, KO ? 25 : 0, KO>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], (uint32_t) (k + 1),
+			                                    DigitColumn{sym, bsh, pass}, NoHook{}, L, cnt4, stage);
 			cur ^= 1u;
 		}
 		snapshot_if_requested(k + 1);
@@ -356,6 +357,7 @@ __global__ __launch_bounds__(ST) void k_colblock_stream(
 // ------------------------------------------------------------------------------------------------
 // phase B, streamed (same contract as k_chain).  ws: [gridDim.x][4][m] words.
 // ------------------------------------------------------------------------------------------------
+template <bool KO = false>
 __global__ __launch_bounds__(ST) void k_chain_stream(
 	uint32_t const *__restrict__ rank, uint32_t const *__restrict__ keyd, uint32_t const *__restrict__ nkeys,
 	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t *ws, uint32_t staged,
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(ST) void k_chain_stream(
 		uint32_t const nd = rank_digits(nkeys[b]);
 		for (uint32_t p = 0; p < nd; ++p)
 		{
-			stream_pass<false>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], 0u, DigitRank{rk, 2u * p}, NoHook{}, L, nullptr, stage);
+			stream_pass<false, KO ? 25 : 0, KO>(m, buf[cur][0], buf[cur][1], buf[cur ^ 1u][0], buf[cur ^ 1u][1], 0u, DigitRank{rk, 2u * p}, NoHook{}, L, nullptr, stage);
 			cur ^= 1u;
 		}
 		// rows that start a new block key take the in-block divergence of that key
