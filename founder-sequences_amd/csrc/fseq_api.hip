@@ -285,6 +285,7 @@ struct Tuning {
 	int  dp_spec_win = 0, dp_spec_rounds = 0, dp_spec_max_sweeps = 0;      // FSEQ_DP_SPEC_*: tail window, chunk length, sweep budget
 	bool stream_plain_scan = false;      // FSEQ_STREAM_PLAIN_SCAN: streamed phase C with the has-based scan (first form)
 	bool plain_scan = false;             // FSEQ_PLAIN_SCAN: phase B / pass 2 never scan keys
+	bool occurrence_keys = false;        // FSEQ_OCCURRENCE_KEYS: ... scan occurrence keys even where row counts fit the keys
 	bool phase_a_classic = false;        // FSEQ_PHASE_A_CLASSIC: phase A as a column sweep
 	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
 	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
@@ -318,6 +319,7 @@ struct Tuning {
 		else if (n == "FSEQ_DP_SPEC_MAX_SWEEPS") dp_spec_max_sweeps = on ? std::max(1, iv) : 0;
 		else if (n == "FSEQ_STREAM_PLAIN_SCAN") stream_plain_scan = on;
 		else if (n == "FSEQ_PLAIN_SCAN") plain_scan = on;
+		else if (n == "FSEQ_OCCURRENCE_KEYS") occurrence_keys = on;
 		else if (n == "FSEQ_PHASE_A_CLASSIC") phase_a_classic = on;
 		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
 		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
@@ -340,7 +342,7 @@ struct Tuning {
 	void from_environment()
 	{
 		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
-			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_PHASE_A_CLASSIC",
+			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A"};
 		for (char const *nm : names)
@@ -1125,7 +1127,7 @@ int follow_traceback(fseq_ctx *c, hipStream_t st)
 uint32_t scan_keyed(fseq_ctx const *c)
 {
 	if (c->use_stream || c->tune.plain_scan) return 0u;
-	return c->p.n < (1ull << c->ks.scan_shift) ? 1u : c->p.n < (1ull << 25) ? 2u : 0u;       // row-count keys, occurrence keys, has-based scan
+	return (c->p.n < (1ull << c->ks.scan_shift) && !c->tune.occurrence_keys) ? 1u : c->p.n < (1ull << 25) ? 2u : 0u;       // row-count keys, occurrence keys, has-based scan
 }
 
 // streamed rows: occurrence keys while every column number fits 25 bits (FSEQ_PLAIN_SCAN: the has-based scan)

@@ -202,6 +202,24 @@ def test_phase_b_and_pass_2_with_the_plain_scan(pkg, monkeypatch):
         compare_long(pkg, msa, L, block_len=B)
 
 
+def test_phase_b_and_pass_2_with_occurrence_keys(pkg, monkeypatch):
+    """n >= 2^shift (BASELINE C5: n = 10^6 on the 1024 x 10 kernels, 18 bits) takes keys whose count part counts lanes and
+    waves that hold a bucket instead of rows (partition_step KO, any n < 2^25); forced here on shapes of every kernel
+    family, one-wave workgroups included.  The streamed kernels always take them: their has-based scan under
+    FSEQ_PLAIN_SCAN is the second half."""
+    shapes = SPEC_SHAPES[:2] + [(2500, 3000, 30, 16, 500, 1e-3, 91, 0, 100), (9000, 1200, 40, 16, 400, 2e-4, 27, 0, 128),
+                                (5000, 700, 20, 9, 100, 1e-3, 92, 1, 64), (60, 900, 12, 5, 50, 2e-3, 93, 0, 32), (400, 800, 16, 7, 80, 1e-3, 94, 0, 40)]
+    monkeypatch.setenv("FSEQ_OCCURRENCE_KEYS", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in shapes:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, block_len=B)
+    monkeypatch.delenv("FSEQ_OCCURRENCE_KEYS")
+    monkeypatch.setenv("FSEQ_PLAIN_SCAN", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(12000, 500, 20, 12, 120, 3e-4, 41, 0, 64), (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, block_len=B)
+
+
 def test_streamed_phase_c_with_the_plain_scan(pkg, monkeypatch):
     """The streamed tiles scan their running maxima as keys (count << 19 | value id) when the ids allow it; the
     has-based scan they fall back to otherwise must give the same results."""
