@@ -205,14 +205,18 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_
 	// 512 threads: the list wave pays since the partition step's scan became cheap (BASELINE C3: phase C 8.2 -> 7.7 ms
 	// with six rows on seven waves and the list on the eighth; 576 threads would keep five rows per thread, but nine
 	// waves per workgroup place three on one SIMD and only one workgroup fits a CU)
+	// [late r3] ... with 16-bit LDS words (value ids are < m + B < 65536 anyway): 48 KiB instead of 70 per workgroup and 80
+	// registers by launch bounds put THREE workgroups on a CU -- a column step is a chain of three barriers and ~6 LDS round
+	// trips, and two workgroups left the SIMDs idle 43 % of the time (BASELINE C3: phase C 5.61 -> 5.08 ms; the unpacking
+	// costs less than the third workgroup brings)
 	if (ew_ok && m > 448u * 5u && m <= 448u * 6u && m <= 512u * 5u)
 	{
-		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 6, 4, false, true>>();
+		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 6, 4, true, true>>();
 		return true;
 	}
 	if (ew_ok && m > 256u * 5u && m <= 448u * 5u)
 	{
-		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 5, 4, false, true>>();
+		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 5, 4, true, true>>();
 		return true;
 	}
 	FSEQ_TRY(512, 5, false)
@@ -403,6 +407,7 @@ struct fseq_ctx {
 
 	// geometry
 	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
+	uint32_t auto_B = 0;                     // block length fitted to whole rounds of phase C's workgroups (short inputs)
 	Stream2Config s2{};                      // streamed phase C, second form (T = 0: not in use)
 	size_t s2_lds = 0;
 	bool stream_staged = false;              // streamed kernels lay tiles out in LDS before writing them (needs 64 KiB more)
@@ -588,6 +593,7 @@ void block_geometry(fseq_ctx *c)
 	bool const streamed = p.m > 11264u;
 	Shard &sh = c->sh;
 	if (p.block_len) c->B = p.block_len;
+	else if (c->auto_B) c->B = c->auto_B;                    // (prepare_geometry's second look, below)
 	else if (!sh.on)
 	{
 		// LDS-resident kernels: ~1024 blocks (2-4 workgroups per CU).  Streamed kernels stage a whole column
@@ -687,6 +693,7 @@ void block_geometry(fseq_ctx *c)
 int prepare_geometry(fseq_ctx *c)
 {
 	fseq_params const &p = c->p;
+	c->auto_B = 0;
 	block_geometry(c);
 	uint32_t n2 = 1;
 	while (n2 < p.m) n2 <<= 1;
@@ -752,6 +759,28 @@ int prepare_geometry(fseq_ctx *c)
 		if ((uint64_t) p.m + c->B > 65535u) return fail(c, FSEQ_E_UNSUPPORTED, "block length too large for the 16-bit value ids of phase C");
 		HIP_TRY(c, c->ks.prepare(c->lds_columns));
 		HIP_TRY(c, c->ks.prepare_columns(c->lds_columns));
+		// Short inputs: phase C is a few rounds of (CUs x workgroups per CU) blocks, and a last round that is a third full
+		// costs a whole one (BASELINE C2: 1,021 blocks on 768 slots; 764 blocks of 131 columns: phase C 0.65 -> 0.59 ms).
+		// Below three rounds the block length is refitted to whole rounds (long inputs measured no better for it).
+		if (!p.block_len && !c->sh.on && !c->auto_B)
+		{
+			int ncu = 0;
+			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
+			uint64_t const slots = (uint64_t) std::max(ncu, 1) * c->ks.columns_resident(c->lds_columns);
+			if (c->nblocks > slots && c->nblocks < 3 * slots)
+			{
+				uint64_t const rounds = (c->nblocks + slots / 2) / slots;
+				uint64_t const b = (p.n + rounds * slots - 1) / (rounds * slots);
+				if (b >= 16 && b <= 4096 && b != c->B && p.m + b <= 65535u)
+				{
+					c->auto_B = (uint32_t) b;
+					block_geometry(c);
+					c->lds_columns = c->ks.columns_lds(c->B);
+					if (c->lds_columns > LDS_LIMIT) return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
+					HIP_TRY(c, c->ks.prepare_columns(c->lds_columns));
+				}
+			}
+		}
 		// phase A in key space: the id arrays are (GL + 2) x m halfwords; the two maps take what is left of ~76 KiB
 		// (two workgroups per CU) when that holds the leaf map with a quarter to spare, else of the whole CU
 		{

@@ -207,6 +207,14 @@ __device__ __forceinline__ void stream_touch(void const *g, uint32_t lds_addr)
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// -DFSEQ_KC_STAMPS: cycle stamps of a column step per wave (k_columns prints them)
+#ifdef FSEQ_KC_STAMPS
+struct KcStamps { long long acc[8]; long long last; };
+#define KC_T(i) do { if (kc) { long long const t_ = clock64(); kc->acc[i] += t_ - kc->last; kc->last = t_; } } while (0)
+#else
+#define KC_T(i) do {} while (0)
+#endif
+
 template <int T, int SIGMA>
 struct StepScratch {
 	static constexpr int NW = T / WAVE;
@@ -258,7 +266,11 @@ struct TileCarry {
 template <int T, int E, int SIGMA, bool TILE = false, bool IDLE0 = false, int KS = 0, bool PW = false, bool FM = false, bool KO = false>
 __device__ __forceinline__ void partition_step(
 	uint32_t const (&d)[E], uint32_t const (&s)[E], uint32_t const first_val,
-	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr, uint32_t *runs = nullptr)
+	StepScratch<T, SIGMA> &scr, uint32_t (&dst)[E], uint32_t (&dnew)[E], TileCarry *tc = nullptr, uint32_t *runs = nullptr
+#ifdef FSEQ_KC_STAMPS
+	, KcStamps *kc = nullptr
+#endif
+	)
 {
 	// the idle wave has nothing to do between the step's barrier and the caller's: it runs the second level of the scan
 	// (the wave totals) and hands every wave its prefix through LDS -- ~35 instructions less in every row wave, one more barrier
@@ -272,7 +284,9 @@ __device__ __forceinline__ void partition_step(
 			uint32_t const l = lane_id();
 #pragma unroll
 			for (int e = 0; e < E; ++e) { dst[e] = 0; dnew[e] = 0; }
+			KC_T(0);
 			__syncthreads();
+			KC_T(1);
 			bool const in = l >= 1u && l < (uint32_t) NW_;       // lane l = wave l; wave 0 has no rows
 			uint32_t wc[2], wk[4];
 #pragma unroll
@@ -308,7 +322,9 @@ __device__ __forceinline__ void partition_step(
 				*reinterpret_cast<uint4 *>(&scr.glob[0]) = make_uint4(0u, s1, s2, s3);
 				*reinterpret_cast<uint4 *>(&scr.glob[4]) = make_uint4(first_val, (s1 << 16) + first_val, (s2 << 16) + first_val, (s3 << 16) + first_val);
 			}
+			KC_T(2);
 			__syncthreads();
+			KC_T(3);
 			return;
 		}
 	}
@@ -489,11 +505,15 @@ __device__ __forceinline__ void partition_step(
 #pragma unroll
 		for (int x = 0; x < SIGMA; ++x) pk[x] = 0;
 		uint32_t base[SIGMA], cval[SIGMA], seen = 0;
+		KC_T(0);
 		__syncthreads();
+		KC_T(1);
 		if constexpr (SCAN0)
 		{
 			if constexpr (PW) pw_chain();
+			KC_T(2);
 			__syncthreads();
+			KC_T(3);
 			uint4 const q0 = *reinterpret_cast<uint4 const *>(&scr.pre[wave][0]);
 			uint4 const q1 = *reinterpret_cast<uint4 const *>(&scr.pre[wave][4]);
 			uint4 const g0 = *reinterpret_cast<uint4 const *>(&scr.glob[0]);

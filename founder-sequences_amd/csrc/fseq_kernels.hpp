@@ -690,7 +690,7 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 // rows, the list's serial chain (~150 instructions under 8-way issue contention) stretched EVERY column's critical
 // path: 2.9 of 10.8 ms.  Needs m <= (T - 64) * E.
 template <int T, int E, int SIGMA, bool PK, bool EW = false>
-__global__ __launch_bounds__(T, 4) void k_columns(
+__global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
@@ -809,6 +809,7 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 	bool const zero_present = (V_l[0] == 0u);
 #ifdef FSEQ_KC_STAMPS
 	long long kc_work = 0, kc_wait = 0, kc_last = clock64();
+	KcStamps kcs{{0, 0, 0, 0, 0, 0, 0, 0}, clock64()};
 #endif
 
 	for (uint32_t j = 0; j < nb; ++j)
@@ -827,7 +828,12 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
 
 			// (value ids: D0 + nb <= m + B < 65536 -- the LDS of the id histogram bounds B long before -- so the keyed scan)
+#ifdef FSEQ_KC_STAMPS
+			kcs.last = clock64();
+			partition_step<T, E, SIGMA, false, EW, 16, PW, LU>(d, s, D0 + j, scr, dst, dnew, nullptr, runs, &kcs);
+#else
 			partition_step<T, E, SIGMA, false, EW, 16, PW, LU>(d, s, D0 + j, scr, dst, dnew, nullptr, runs);
+#endif
 
 #pragma unroll
 			for (int e = 0; e < E; ++e)
@@ -877,13 +883,21 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 		// cut bound (lp.cc:444-445), so only their total count matters.  Then the distinct values
 		// below thr, descending, until their cumulative count exceeds X (every DP cell is >= the lump's
 		// count, so the list always reaches X counts past the smallest value the cell can take).
+#ifdef FSEQ_KC_NOLIST
+		if (wave_id() == 0 && lane_id() == 0) { ent[(k0 + j) * (size_t) stride] = make_uint2((uint32_t) (k0 + j + 1), 7u); hdr[k0 + j] = make_uint4(1u, 0u, 1u, m); }
+		if (false)
+#else
 		if (wave_id() == 0)
+#endif
 		{
 			// The list is one wave's serial chain (LDS reads -> scan -> ballots -> stores) on every column's critical
 			// path: issue priority over the other waves of the SIMD, and four ids per lane (256 per step) -- the id
 			// space is sparse (one id per column and boundary value, most of them with count 0 by now), so a step of
 			// 64 ids needed 5-8 rounds of that chain per column, 256 need 1-2.
 			__builtin_amdgcn_s_setprio(3);
+#ifdef FSEQ_KC_STAMPS
+			long long const kc_l0 = clock64();
+#endif
 			uint32_t const lane = lane_id();
 			uint64_t const k = k0 + j;
 			uint32_t const thr = (k + 2 > (uint64_t) L) ? (uint32_t) (k + 2 - L) : 0u;
@@ -896,6 +910,9 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 				uint32_t c[4], v[4];
 				uint32_t lane_c = 0, lane_o = 0, lane_rc = 0;
 				bool cand[4];
+#ifdef FSEQ_KC_STAMPS
+				kcs.acc[4] += 1;
+#endif
 #pragma unroll
 				for (int q = 0; q < 4; ++q)
 				{
@@ -947,12 +964,19 @@ __global__ __launch_bounds__(T, 4) void k_columns(
 				out[0] = make_uint2((uint32_t) (k + 1), R);
 				hdr[k] = make_uint4(nent, zero_present ? cnt_get<PK>(cnt_l, 0u) : 0u, cum == m ? 1u : 0u, cum);
 			}
+#ifdef FSEQ_KC_STAMPS
+			kcs.acc[5] += clock64() - kc_l0;
+			kcs.acc[6] += nent;
+#endif
 			__builtin_amdgcn_s_setprio(0);
 		}
 	}
 #ifdef FSEQ_KC_STAMPS
 	if (lane_id() == 0 && (blockIdx.x == 100 || blockIdx.x == 3000))
-		printf("kc stamps block %u wave %u: work %lld wait %lld cycles per column (%u columns)\n", blockIdx.x, wave_id(), kc_work / nb, kc_wait / nb, nb);
+		printf("kc stamps block %u wave %u: work %lld wait %lld cycles per column (%u columns); step: to barrier 1 %lld, wait %lld, between %lld, wait 1b %lld\n",
+		       blockIdx.x, wave_id(), kc_work / nb, kc_wait / nb, nb, kcs.acc[0] / nb, kcs.acc[1] / nb, kcs.acc[2] / nb, kcs.acc[3] / nb);
+	if (lane_id() == 0 && wave_id() == 0 && (blockIdx.x == 100 || blockIdx.x == 3000))
+		printf("kc stamps block %u list: %lld rounds x 100 per column, %lld cycles per column, %lld entries x 100 per column, X %u D0 %u\n", blockIdx.x, kcs.acc[4] * 100 / nb, kcs.acc[5] / nb, kcs.acc[6] * 100 / nb, X, D0);
 #endif
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
 	publish_block_done(done_host, blockIdx.x + block0, epoch);
