@@ -767,6 +767,7 @@ int prepare_geometry(fseq_ctx *c)
 			int ncu = 0;
 			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
 			uint64_t const slots = (uint64_t) std::max(ncu, 1) * c->ks.columns_resident(c->lds_columns);
+			if (c->tune.debug) fprintf(stderr, "[fseq] phase C: %u blocks of %u columns on %llu workgroup slots (%zu bytes of LDS each)\n", c->nblocks, c->B, (unsigned long long) slots, c->lds_columns);
 			if (c->nblocks > slots && c->nblocks < 3 * slots)
 			{
 				uint64_t const rounds = (c->nblocks + slots / 2) / slots;
