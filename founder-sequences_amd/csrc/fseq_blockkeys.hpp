@@ -302,6 +302,29 @@ __device__ __forceinline__ void bk_copy8(uint32_t m, uint16_t const *src, uint16
 	}
 }
 
+// cw[c] = the 16 rows' symbols of column c (row j at bits 2j) -> out[i] = word(row 2i) | word(row 2i + 1) << 16,
+// word(row) = column c at bits 2c
+__device__ __forceinline__ void bk_words8(uint32_t const (&cw)[8], uint32_t (&out)[8])
+{
+#pragma unroll
+	for (uint32_t b = 0; b < 4; ++b)
+	{
+		uint32_t const sel = b | ((4u + b) << 8) | 0x0C0C0000u;                       // byte b of S1, byte b of S0, 0, 0
+		uint32_t const p01 = __builtin_amdgcn_perm(cw[1], cw[0], sel), p23 = __builtin_amdgcn_perm(cw[3], cw[2], sel);
+		uint32_t const p45 = __builtin_amdgcn_perm(cw[5], cw[4], sel), p67 = __builtin_amdgcn_perm(cw[7], cw[6], sel);
+		uint32_t x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                    // byte c = rows 4b .. 4b+3 of column c
+		uint32_t y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);                    // ... of column 4 + c
+		// 4 x 4 transpose of 2-bit elements: (c, r) at bit 8c + 2r -> (r, c) at bit 8r + 2c
+		uint32_t t;
+		t = ((x >> 6) ^ x) & 0x00CC00CCu; x ^= t ^ (t << 6);
+		t = ((x >> 12) ^ x) & 0x0000F0F0u; x ^= t ^ (t << 12);
+		t = ((y >> 6) ^ y) & 0x00CC00CCu; y ^= t ^ (t << 6);
+		t = ((y >> 12) ^ y) & 0x0000F0F0u; y ^= t ^ (t << 12);
+		out[2 * b] = __builtin_amdgcn_perm(y, x, 0x05010400u);                        // rows 4b, 4b + 1: {x0, y0, x1, y1}
+		out[2 * b + 1] = __builtin_amdgcn_perm(y, x, 0x07030602u);                    // rows 4b + 2, 4b + 3
+	}
+}
+
 // The 16-bit words of one leaf (nc <= 16 / bits columns staged at sym, ld bytes apart) for the rows this thread owns:
 // to `top` (LDS), to `leafw` (HBM) and as set bits of `map`.  BSH: log2 of the rows per byte (2 / 1 / 0).
 template <int T, int BSH>
@@ -323,19 +346,35 @@ __device__ __forceinline__ void bk_build_leaf(uint8_t const *sym, size_t ld, uin
 			else { uint2 const t = *reinterpret_cast<uint2 const *>(at); x0[c] = t.x; x1[c] = t.y; }
 		}
 		uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-		for (uint32_t c = 0; c < CL; ++c)
+		uint4 q;
+		if constexpr (BSH == 2)
 		{
-			uint32_t const a = c < nc ? x0[c] : 0u, b = c < nc ? x1[c] : 0u;
+			// 8 columns x 8 rows of 2-bit symbols: the register transpose of the pair leaves (bk_words8; 6 instructions per
+			// row instead of 24 shift / mask / or -- the word build was a quarter of a C3 block's time)
+			uint32_t cw[8], o[8];
 #pragma unroll
-			for (uint32_t u = 0; u < 8; ++u)
-			{
-				uint32_t const sh = u * BITS;
-				uint32_t const v = (sh < 32u ? a >> sh : b >> (sh - 32u)) & SMASK;
-				w[u] |= v << (BITS * c);
-			}
+			for (uint32_t c = 0; c < 8; ++c) cw[c] = c < nc ? x0[c] : 0u;
+			bk_words8(cw, o);
+			q = make_uint4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+			for (uint32_t u = 0; u < 8; ++u) w[u] = (u & 1u) ? o[u >> 1] >> 16 : o[u >> 1] & 0xFFFFu;
 		}
-		uint4 const q = bk_pack(w);
+		else
+		{
+#pragma unroll
+			for (uint32_t c = 0; c < CL; ++c)
+			{
+				uint32_t const a = c < nc ? x0[c] : 0u, b = c < nc ? x1[c] : 0u;
+#pragma unroll
+				for (uint32_t u = 0; u < 8; ++u)
+				{
+					uint32_t const sh = u * BITS;
+					uint32_t const v = (sh < 32u ? a >> sh : b >> (sh - 32u)) & SMASK;
+					w[u] |= v << (BITS * c);
+				}
+			}
+			q = bk_pack(w);
+		}
 		*reinterpret_cast<uint4 *>(top + r0) = q;
 		*reinterpret_cast<uint4 *>(leafw + r0) = q;
 		// (a row behind m sets the bit of row r0 once more)
@@ -617,29 +656,6 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m,
 // then takes the two leaves one by one.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr uint32_t BK_PAIR_NO = 0xFFFFFFFFu;
-
-// cw[c] = the 16 rows' symbols of column c (row j at bits 2j) -> out[i] = word(row 2i) | word(row 2i + 1) << 16,
-// word(row) = column c at bits 2c
-__device__ __forceinline__ void bk_words8(uint32_t const (&cw)[8], uint32_t (&out)[8])
-{
-#pragma unroll
-	for (uint32_t b = 0; b < 4; ++b)
-	{
-		uint32_t const sel = b | ((4u + b) << 8) | 0x0C0C0000u;                       // byte b of S1, byte b of S0, 0, 0
-		uint32_t const p01 = __builtin_amdgcn_perm(cw[1], cw[0], sel), p23 = __builtin_amdgcn_perm(cw[3], cw[2], sel);
-		uint32_t const p45 = __builtin_amdgcn_perm(cw[5], cw[4], sel), p67 = __builtin_amdgcn_perm(cw[7], cw[6], sel);
-		uint32_t x = __builtin_amdgcn_perm(p23, p01, 0x05040100u);                    // byte c = rows 4b .. 4b+3 of column c
-		uint32_t y = __builtin_amdgcn_perm(p67, p45, 0x05040100u);                    // ... of column 4 + c
-		// 4 x 4 transpose of 2-bit elements: (c, r) at bit 8c + 2r -> (r, c) at bit 8r + 2c
-		uint32_t t;
-		t = ((x >> 6) ^ x) & 0x00CC00CCu; x ^= t ^ (t << 6);
-		t = ((x >> 12) ^ x) & 0x0000F0F0u; x ^= t ^ (t << 12);
-		t = ((y >> 6) ^ y) & 0x00CC00CCu; y ^= t ^ (t << 6);
-		t = ((y >> 12) ^ y) & 0x0000F0F0u; y ^= t ^ (t << 12);
-		out[2 * b] = __builtin_amdgcn_perm(y, x, 0x05010400u);                        // rows 4b, 4b + 1: {x0, y0, x1, y1}
-		out[2 * b + 1] = __builtin_amdgcn_perm(y, x, 0x07030602u);                    // rows 4b + 2, 4b + 3
-	}
-}
 
 // exclusive prefix popcounts of the words bm[0 .. nW) into pref[0 .. nW); returns the total.  Three barriers; the last
 // one makes pref visible.
