@@ -249,7 +249,8 @@ constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column l
 #define FSEQ_S2_CONFIGS(X) X(512, 8, true) X(1024, 4, true) X(1024, 8, true) X(256, 8, true) X(256, 12, true) X(512, 8, false) X(1024, 6, false) X(1024, 8, false) X(256, 8, false) X(256, 12, false)
 struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
 	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
-	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t); };
+	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
+	uint32_t (*resident)(size_t lds); };
 template <int T, int E, bool PACK>
 struct LaunchS2 {
 	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E, PACK>(colbytes); }
@@ -259,7 +260,13 @@ struct LaunchS2 {
 	{
 		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack);
 	}
-	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch}; }
+	static uint32_t resident(size_t bytes)
+	{
+		int nb = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns_stream2<T, E, PACK>, T, bytes) != hipSuccess || nb < 1) nb = 1;
+		return (uint32_t) nb;
+	}
+	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch, &resident}; }
 };
 bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out)
 {
@@ -616,7 +623,11 @@ void block_geometry(fseq_ctx *c)
 		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
 		if (ncu < 1) ncu = 256;
 		uint64_t const cols = (p.n + sh.world - 1) / sh.world;
-		uint64_t per = streamed ? (uint64_t) ncu * ((cols + (uint64_t) ncu * 4096 - 1) / ((uint64_t) ncu * 4096)) : 1024u;
+		uint64_t k = (cols + (uint64_t) ncu * 4096 - 1) / ((uint64_t) ncu * 4096);
+		// (the second form of the streamed phase C runs two workgroups per CU: an odd number of half-rounds above one ends on a
+		// half-empty round)
+		if (k > 1 && (k & 1u) && (uint64_t) p.m + 4096u < (1ull << 19) && !c->tune.stream_plain_scan && c->tune.stream2 != "0") ++k;
+		uint64_t per = streamed ? (uint64_t) ncu * k : 1024u;
 		uint64_t b = (p.n + per * sh.world - 1) / (per * sh.world);
 		if (b < 16) b = 16;
 		c->B = (uint32_t) b;
@@ -739,6 +750,24 @@ int prepare_geometry(fseq_ctx *c)
 					HIP_TRY(c, allow_lds(k_columns_stream2_prologue, stream_lds_bytes(0, true)));
 					c->s2 = cfg; c->s2_lds = bytes;
 				}
+			}
+		}
+		// Long inputs (the block length was clamped to 4,096 columns): whole rounds of phase C's workgroups.  BASELINE C4 had
+		// 1,221 blocks on 512 slots -- 2.4 rounds, the last one 38 % full: 2.33 s; 1,536 blocks of 3,256 columns: 2.22 s
+		// (2,048 and 3,072 blocks the same: phase A gains what phase B loses).
+		if (!p.block_len && !c->sh.on && !c->auto_B && c->B == 4096u && c->B < p.n)
+		{
+			int ncu = 0;
+			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
+			uint64_t const slots = (uint64_t) std::max(ncu, 1) * (c->s2.T ? c->s2.resident(c->s2_lds) : 1u);
+			uint64_t const rounds = (c->nblocks + slots - 1) / slots;
+			uint64_t const b = (p.n + rounds * slots - 1) / (rounds * slots);
+			if (c->tune.debug) fprintf(stderr, "[fseq] streamed phase C: %u blocks on %llu workgroup slots -> %llu rounds of %llu columns\n", c->nblocks, (unsigned long long) slots,
+			                           (unsigned long long) rounds, (unsigned long long) b);
+			if (b >= 1024 && b < 4096)
+			{
+				c->auto_B = (uint32_t) b;
+				block_geometry(c);
 			}
 		}
 		// phase A in key space, streamed rows: the bitmap (and its 32-bit prefix counts) take the LDS
