@@ -395,8 +395,10 @@ __device__ __forceinline__ void colblock_body(char *smem,
 	}
 }
 
+// (pass 2 on 512 threads at 80 registers -- 81 otherwise --: three workgroups of this latency-bound kernel share a CU,
+// BASELINE C3 0.35 -> 0.29 ms; the same bound on k_chain cost more in spills than it brought, 0.71 -> 0.77 ms)
 template <int T, int E, int SIGMA, int MODE, bool PK>
-__global__ __launch_bounds__(T) void k_colblock(
+__global__ __launch_bounds__(T, (T == 512 && MODE == MODE_SNAP) ? 6 : 1) void k_colblock(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
