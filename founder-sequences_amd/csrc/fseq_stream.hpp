@@ -273,8 +273,10 @@ __device__ __forceinline__ void stream_emit_ranks(
 // phase A (MODE_RANK) and pass 2 (MODE_SNAP), streamed.  ws: [gridDim.x][4][m] words (a0, d0, a1, d1).
 // ------------------------------------------------------------------------------------------------
 // KO: every divergence is below 2^25 (n is): the partition steps scan occurrence keys (fseq_core.hpp) instead of {has, value}
+// (pass 2 at 64 registers, 19 spilled: two of these workgroups share a CU -- the staged column and the tile staging
+// are 58 KiB -- and hide each other's memory latency: BASELINE C4 pass 2 168 -> 157 ms; k_chain_stream the same way: 140 -> 150)
 template <int MODE, bool KO = false>
-__global__ __launch_bounds__(ST) void k_colblock_stream(
+__global__ __launch_bounds__(ST, MODE == MODE_SNAP ? 8 : 1) void k_colblock_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *ws, uint32_t staged,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
