@@ -885,12 +885,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 		// cut bound (lp.cc:444-445), so only their total count matters.  Then the distinct values
 		// below thr, descending, until their cumulative count exceeds X (every DP cell is >= the lump's
 		// count, so the list always reaches X counts past the smallest value the cell can take).
-#ifdef FSEQ_KC_NOLIST
-		if (wave_id() == 0 && lane_id() == 0) { ent[(k0 + j) * (size_t) stride] = make_uint2((uint32_t) (k0 + j + 1), 7u); hdr[k0 + j] = make_uint4(1u, 0u, 1u, m); }
-		if (false)
-#else
 		if (wave_id() == 0)
-#endif
 		{
 			// The list is one wave's serial chain (LDS reads -> scan -> ballots -> stores) on every column's critical
 			// path: issue priority over the other waves of the SIMD, and four ids per lane (256 per step) -- the id
