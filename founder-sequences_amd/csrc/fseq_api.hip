@@ -1297,9 +1297,10 @@ SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 	int ncu = 0;
 	(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
 	if (ncu < 1) ncu = 1;
-	// one chunk per CU, but chunks of at least max(1024, 8L) entries (several tail windows; the sweeps of shorter
-	// chunks are cheaper but more of them are needed)
-	uint32_t const min_entries = std::max<uint32_t>(1024u, 8u * S.L);
+	// one chunk per CU, but chunks of at least max(400, 8L) entries (the sweeps of shorter chunks are cheaper but more of
+	// them are needed; BASELINE C2, L = 50: 96 chunks of 21 rounds 0.32 ms in 3 sweeps, 250 of 8 rounds 0.20 ms in 4,
+	// 334 of 6 rounds 0.27 ms)
+	uint32_t const min_entries = std::max<uint32_t>(400u, 8u * S.L);
 	uint32_t forced = 0;
 	if (c->tune.dp_spec_rounds) forced = (uint32_t) c->tune.dp_spec_rounds;   // tests: any chunk length
 	auto cut = [&](uint32_t lo, uint32_t hi) {
