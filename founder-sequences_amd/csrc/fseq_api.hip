@@ -938,7 +938,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	{
 		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
 		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
-		// within [4 GiB, 160 GiB]; the smallest stride >= 16 that fits.  (FSEQ_DEBUG prints the choice.)
+		// within [4 GiB, 160 GiB]; the smallest stride >= 16 (8: below) that fits.  (FSEQ_DEBUG prints the choice.)
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
@@ -964,7 +964,10 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 			if (abits + dbits <= 40 && abits < 32) c->ss_pack = abits;
 		}
 		uint64_t const state_bytes = c->ss_pack ? (uint64_t) m * 4ull + ss_high_stride(p.m) : (uint64_t) m * 8ull;
-		uint64_t st_ = 16;
+		// first stride tried: 16 columns; 8 where a column is two digit passes (pass 2 replays stride / 2 columns per boundary at
+		// twice the price there, a state costs phase C the same: BASELINE C5 pass 2 4.3 -> 2.3 ms, phase C 36.7 -> 36.9;
+		// sigma <= 4: BASELINE C3 8.7 / 8.6 / 8.6 / 8.7 ms for 8 / 12 / 16 / 24)
+		uint64_t st_ = (c->npass >= 2 && !c->use_stream) ? 8 : 16;
 		if (c->tune.snap_stride) st_ = (uint64_t) c->tune.snap_stride;     // (experiments: first stride tried)
 		// the smallest stride >= 16 whose states fit (any number, not a power of two: pass 2 costs ~stride / 2 columns per boundary)
 		if ((k_cnt / st_ + 2) * state_bytes > budget) st_ = std::max<uint64_t>(st_, (k_cnt * state_bytes + budget - 1) / std::max<uint64_t>(1, budget - 2 * state_bytes));
