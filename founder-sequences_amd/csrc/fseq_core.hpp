@@ -365,23 +365,35 @@ __device__ __forceinline__ void partition_step(
 	// pairwise local pass, the values: dnew[e] = max d(j, e] for the nearest earlier row j of this thread with the symbol of
 	// row e, the whole prefix max d[0 .. e] when there is none.  Nothing in the scan needs them: with the idle wave running
 	// the second level (SCAN0) the row waves compute them while they wait for it.
+	// Six and more rows (TWO): the rows are taken as two halves, pairs only inside a half (E^2 / 4 instead of E^2 / 2 of
+	// them); a row of the second half whose symbol has no earlier row THERE starts from the first half's tail maximum of
+	// that symbol (t0s: read from the run slots) joined with the prefix maximum of the second half.  BASELINE C3 (E = 6)
+	// phase C 5.09 -> 4.98 ms; C5 (E = 10, which the one-level form never paid for) 37.0 -> 36.4 ms: 10 % fewer vector
+	// instructions there, but its LDS is nearly as busy as its SIMDs and the slots cost 20 % more LDS instructions.
+#ifndef FSEQ_PW_TWO_MIN
+#define FSEQ_PW_TWO_MIN 6
+#endif
+	constexpr bool TWO = PW && E >= FSEQ_PW_TWO_MIN;
+	constexpr int E0 = TWO ? (E + 1) / 2 : E;
+	uint32_t t0s[TWO ? E - E0 : 1];
 	auto pw_chain = [&]() {
 		uint32_t pre[E];
 		pre[0] = d[0];
 #pragma unroll
-		for (int e = 1; e < E; ++e) pre[e] = max(pre[e - 1], d[e]);
+		for (int e = 1; e < E; ++e) pre[e] = (e == E0) ? d[e] : max(pre[e - 1], d[e]);      // (TWO: per half)
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
-			uint32_t o = pre[e];
+			int const lo = (e >= E0) ? E0 : 0;                   // first row of e's half
+			uint32_t o = (e >= E0) ? max(t0s[TWO ? e - E0 : 0], pre[e]) : pre[e];
 			uint32_t ch[E];                                      // ch[j] = max d(j, e]
-			if (e >= 1)
+			if (e >= lo + 1)
 			{
 				ch[e - 1] = d[e];
 #pragma unroll
-				for (int j = e - 2; j >= 0; --j) ch[j] = max(ch[j + 1], d[j + 1]);
+				for (int j = e - 2; j >= lo; --j) ch[j] = max(ch[j + 1], d[j + 1]);
 #pragma unroll
-				for (int j = 0; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
+				for (int j = lo; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
 			}
 			dnew[e] = o;
 			asm volatile("" : "+v"(dnew[e]));
@@ -390,16 +402,14 @@ __device__ __forceinline__ void partition_step(
 	if constexpr (PW)
 	{
 		static_assert(!PW || (SIGMA == 4 && KS != 0), "pairwise local pass: four symbols, keyed scan");
-		// chain[e][j] = max d(j, e] for j < e (chain[e][e-1] = d[e]); pre[e] = max d[0 .. e]
-		uint32_t pre[E];
-		pre[0] = d[0];
+		// pre0 = max d[0 .. E0-1]; suf[j] = max d(j, last row of j's half]
+		uint32_t pre0 = d[0];
 #pragma unroll
-		for (int e = 1; e < E; ++e) pre[e] = max(pre[e - 1], d[e]);
-		uint32_t suf[E];                                       // suf[j] = max d(j, E-1] = chain[E-1][j]; suf[E-1] = 0
-		suf[E - 1] = 0u;
+		for (int e = 1; e < E0; ++e) pre0 = max(pre0, d[e]);
+		uint32_t suf[E];
+		suf[E0 - 1] = 0u;
 #pragma unroll
-		for (int j = E - 2; j >= 0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
-		if constexpr (!SCAN0) pw_chain();
+		for (int j = E0 - 2; j >= 0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
@@ -411,9 +421,28 @@ __device__ __forceinline__ void partition_step(
 		// tail maximum per symbol: the whole thread if the symbol does not occur, else what follows its last row
 		uint32_t const t_ = threadIdx.x;
 #pragma unroll
-		for (int x = 0; x < 4; ++x) runs[x * T + t_] = pre[E - 1];
+		for (int x = 0; x < 4; ++x) runs[x * T + t_] = pre0;
 #pragma unroll
-		for (int e = 0; e < E; ++e) runs[s[e] * (uint32_t) T + t_] = suf[e];
+		for (int e = 0; e < E0; ++e) runs[s[e] * (uint32_t) T + t_] = suf[e];
+		if constexpr (TWO)
+		{
+#pragma unroll
+			for (int e = E0; e < E; ++e) t0s[e - E0] = runs[s[e] * (uint32_t) T + t_];
+			uint32_t t0x[4];
+#pragma unroll
+			for (int x = 0; x < 4; ++x) t0x[x] = runs[x * T + t_];
+			uint32_t pre1 = d[E0];
+#pragma unroll
+			for (int e = E0 + 1; e < E; ++e) pre1 = max(pre1, d[e]);
+			suf[E - 1] = 0u;
+#pragma unroll
+			for (int j = E - 2; j >= E0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
+#pragma unroll
+			for (int x = 0; x < 4; ++x) runs[x * T + t_] = max(t0x[x], pre1);
+#pragma unroll
+			for (int e = E0; e < E; ++e) runs[s[e] * (uint32_t) T + t_] = suf[e];
+		}
+		if constexpr (!SCAN0) pw_chain();
 #pragma unroll
 		for (int x = 0; x < 4; ++x) run[x] = runs[x * T + t_];
 	}

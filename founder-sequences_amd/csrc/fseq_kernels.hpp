@@ -636,11 +636,15 @@ __global__ __launch_bounds__(T) void k_chain(
 #define FSEQ_PW_MAX_E 8
 #endif
 // (not the 1024 x 7 configuration: its 20 KiB of run slots would push the largest block lengths past the 160 KiB of a CU)
-__host__ __device__ constexpr bool columns_pairwise(int T, int E, int SIGMA) { return SIGMA == 4 && E >= 2 && E <= FSEQ_PW_MAX_E && !(T >= 1024 && E >= 7); }
+// (nine and ten rows of the 16-bit configurations: the two-level form, fseq_core.hpp)
+__host__ __device__ constexpr bool columns_pairwise(int T, int E, int SIGMA, bool PK = false)
+{
+	return SIGMA == 4 && ((E >= 2 && E <= FSEQ_PW_MAX_E && !(T >= 1024 && E >= 7)) || (PK && E >= 9 && T * E <= 10240));
+}
 
 // the resolve of a step as a read of per-thread run slots (partition_step's FM): wherever 4 * T more words of LDS are to be had
-__host__ __device__ constexpr bool columns_lookup(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA) || (SIGMA == 4 && PK && T * E <= 10240); }
-__host__ __device__ constexpr size_t columns_run_words(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA) ? 5 * (size_t) T : columns_lookup(T, E, SIGMA, PK) ? 4 * (size_t) T : 0; }
+__host__ __device__ constexpr bool columns_lookup(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA, PK) || (SIGMA == 4 && PK && T * E <= 10240); }
+__host__ __device__ constexpr size_t columns_run_words(int T, int E, int SIGMA, bool PK) { return columns_pairwise(T, E, SIGMA, PK) ? 5 * (size_t) T : columns_lookup(T, E, SIGMA, PK) ? 4 * (size_t) T : 0; }
 
 template <int T, int E, int SIGMA, bool PK>
 __host__ __device__ inline size_t columns_lds_bytes(uint32_t B)
@@ -713,7 +717,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint32_t *V_l = cv.take<uint32_t>(CAP);
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
-	constexpr bool PW = columns_pairwise(T, E, SIGMA);
+	constexpr bool PW = columns_pairwise(T, E, SIGMA, PK);
 	constexpr bool LU = columns_lookup(T, E, SIGMA, PK);
 	uint32_t *runs = LU ? cv.take<uint32_t>(columns_run_words(T, E, SIGMA, PK)) : nullptr;
 
