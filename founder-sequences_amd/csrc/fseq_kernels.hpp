@@ -304,7 +304,8 @@ __device__ __forceinline__ void colblock_body(char *smem,
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
-			uint32_t const idx = tid + i * T;
+			uint32_t idx = tid + i * T;
+			asm volatile("" : "+v"(idx));              // (opaque: no addresses kept -- and spilled -- across the loops)
 			a_l[idx] = (AT) (idx < m ? sa[idx] : 0u);
 			d_l[idx] = (DT) (idx < m ? sd[idx] : 0u);
 		}
@@ -329,7 +330,8 @@ __device__ __forceinline__ void colblock_body(char *smem,
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
-				uint32_t const idx = tid + i * T;
+				uint32_t idx = tid + i * T;
+				asm volatile("" : "+v"(idx));              // (opaque: no store addresses kept -- and spilled -- across the loops)
 				if (idx < m) { snap_a[ob + idx] = a_l[idx]; snap_d[ob + idx] = d_l[idx]; }
 			}
 			++t_next;
@@ -474,7 +476,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
-			uint32_t const idx = tid + i * T;
+			uint32_t idx = tid + i * T;
+			asm volatile("" : "+v"(idx));              // (opaque: no addresses kept -- and spilled -- across the loops)
 			bool const in = idx < m;
 			a_l[idx] = (AT) (in ? (start_a ? start_a[sb + idx] : idx) : 0u);
 			d_l[idx] = in ? (start_d ? start_d[sb + idx] : kstart) : 0u;
@@ -494,7 +497,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
-				uint32_t const idx = tid + i * T;
+				uint32_t idx = tid + i * T;
+				asm volatile("" : "+v"(idx));              // (opaque: no store addresses kept -- and spilled -- across the loops)
 				if (idx < m) { out_state_a[ob + idx] = a_l[idx]; out_state_d[ob + idx] = d_l[idx]; }
 			}
 		}
@@ -512,7 +516,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 				for (int i = 0; i < E; ++i)
 				{
-					uint32_t const idx = tid + i * T;
+					uint32_t idx = tid + i * T;
+					asm volatile("" : "+v"(idx));              // (opaque: no addresses kept -- and spilled -- across the loops)
 					pr[i] = idx < m ? rank[nbase + idx] : 0u;
 					pk[i] = idx < m ? keyd[nbase + idx] : 0u;
 				}
@@ -573,7 +578,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
-				uint32_t const idx = tid + i * T;
+				uint32_t idx = tid + i * T;
+				asm volatile("" : "+v"(idx));              // (opaque: no store addresses kept -- and spilled -- across the loops)
 				if constexpr (!PREF)
 				{
 					pr[i] = idx < m ? rank[nbase + idx] : 0u;
@@ -593,7 +599,8 @@ __global__ __launch_bounds__(T) void k_chain(
 #pragma unroll
 		for (int i = 0; i < E; ++i)
 		{
-			uint32_t const idx = tid + i * T;
+			uint32_t idx = tid + i * T;
+			asm volatile("" : "+v"(idx));              // (opaque: no store addresses kept -- and spilled -- across the loops)
 			if (idx < m) { out_state_a[ob + idx] = a_l[idx]; out_state_d[ob + idx] = d_l[idx]; }
 		}
 	}
@@ -873,7 +880,10 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 #pragma unroll
 			for (int i = 0; i < E; ++i)
 			{
-				uint32_t const idx = tid + i * T;
+				uint32_t idx = tid + i * T;
+				// (opaque: left alone, the compiler keeps the 2 E store addresses of this rare path in registers across the whole
+				// column loop -- and spills them: 6 GB of scratch traffic per C5 step at ten rows per thread)
+				asm volatile("" : "+v"(idx));
 				if (idx < m)
 				{
 					uint32_t const vid = d_l[idx];
