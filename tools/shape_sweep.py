@@ -5,7 +5,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 pkg = importlib.import_module("founder-sequences_amd")
-for (m, n, L) in [(2200, 500000, 100), (4800, 300000, 100), (1200, 500000, 60), (3400, 300000, 100), (7000, 200000, 100)]:
+for (m, n, L) in [(1200, 500000, 60), (2200, 500000, 100), (3400, 300000, 100), (4800, 300000, 100), (5008, 300000, 100), (7000, 200000, 100), (9000, 150000, 100)]:
     ctx = pkg.SegmentationContext(m, n, L)
     ctx.generate_synthetic(0x5EED0000 + m, 24, 2000, 1e-4, 0)
     best = None
