@@ -820,6 +820,9 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	__syncthreads();
 
 	bool const zero_present = (V_l[0] == 0u);
+	// (see the pass loop; compiled into the nine-to-eleven-row kernels only -- the 512-thread 16-bit kernels have no register to spare)
+	constexpr bool CARRY_OK = PK && E >= 9;
+	bool const carry = CARRY_OK && npass == 2u && bsh == 1u && m <= 16384u;
 #ifdef FSEQ_KC_STAMPS
 	long long kc_work = 0, kc_wait = 0, kc_last = clock64();
 	KcStamps kcs{{0, 0, 0, 0, 0, 0, 0, 0}, clock64()};
@@ -835,10 +838,36 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
-			uint32_t s[E], dst[E], dnew[E];
+			uint32_t s[E], dst[E], dnew[E], hi[CARRY_OK ? E : 1];
 			if (rows) read_chunk<T, E>(a_l, d_l, a, d, p0);
+			// 16-bit row ids of at most 14 bits and a 4-bit alphabet (two digit passes): the first pass fetches the whole symbol
+			// and the row carries its second digit in the two spare bits of its id through the scatter, so the second pass
+			// reads its digit where it reads the row -- half of the byte gathers at random rows (and their bank conflicts) gone
+			if (carry && pass == 0)
+			{
 #pragma unroll
-			for (int e = 0; e < E; ++e) s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA;
+				for (int e = 0; e < E; ++e)
+				{
+					uint32_t const sy = (symc[a[e] >> 1] >> ((a[e] & 1u) * 4u)) & 15u;
+					s[e] = (p0 + e < m) ? (sy & 3u) : (uint32_t) SIGMA;
+					hi[e] = sy >> 2;
+				}
+			}
+			else if (carry)
+			{
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					s[e] = (p0 + e < m) ? (a[e] >> 14) : (uint32_t) SIGMA;
+					a[e] &= 0x3FFFu;
+					hi[e] = 0;
+				}
+			}
+			else
+			{
+#pragma unroll
+				for (int e = 0; e < E; ++e) { s[e] = (p0 + e < m) ? sym_digit(symc, a[e], bsh, pass) : (uint32_t) SIGMA; if (CARRY_OK) hi[e] = 0; }
+			}
 
 			// (value ids: D0 + nb <= m + B < 65536 -- the LDS of the id histogram bounds B long before -- so the keyed scan)
 #ifdef FSEQ_KC_STAMPS
@@ -853,7 +882,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 			{
 				if (p0 + e < m)
 				{
-					a_l[dst[e]] = (AT) a[e];
+					a_l[dst[e]] = (AT) (CARRY_OK ? (a[e] | (hi[CARRY_OK ? e : 0] << 14)) : a[e]);
 					d_l[dst[e]] = (AT) dnew[e];
 					if (dnew[e] != d[e])
 					{
