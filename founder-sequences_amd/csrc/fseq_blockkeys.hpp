@@ -850,6 +850,12 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	__syncthreads();
 	uint32_t Dacc = 0, sliced = 0;
 	bool const pairs = bsh == 2u && pair_leaves;
+#ifdef FSEQ_BK_STAMPS
+	long long bks[5] = {0, 0, 0, 0, 0}, bkl = clock64();
+#define BKS_T(i) do { long long const t_ = clock64(); bks[i] += t_ - bkl; bkl = t_; } while (0)
+#else
+#define BKS_T(i) do {} while (0)
+#endif
 
 	for (uint32_t g = 0; g < ngrp; ++g)
 	{
@@ -868,6 +874,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 				uint32_t const nc2 = (uint32_t) min<uint64_t>(2u * cl, kend - kc);
 				__syncthreads();                                      // (`top` may still be read by the look-ups of the merge before)
 				uint32_t const Dp = bk_pair_leaf<T, IdT, PrefT>(S, m, msa, ld, kc, nc2, top);
+				BKS_T(0);
 				if (Dp != BK_PAIR_NO)
 				{
 					if (NARROW && Dp > 65536u) { __syncthreads(); return BK_WIDE; }
@@ -880,6 +887,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 						sz[sp - 2] += sz[sp - 1];
 						--sp;
 					}
+					BKS_T(1);
 					continue;
 				}
 			}
@@ -921,6 +929,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			}
 		}
 		// ---- the group joins the prefix
+		BKS_T(2);
 		IdT *const gi = S.stk(0);
 		if (g == 0)
 		{
@@ -934,6 +943,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			Dacc = bk_merge<T, IdT, PrefT>(S, m, Dacc, D[0], S.acc, gi, S.acc, &sliced);
 			if (NARROW && Dacc > 65536u) { __syncthreads(); return BK_WIDE; }
 		}
+		BKS_T(3);
 	}
 
 	// ---- outputs: rank of every row, one representative row per distinct key, the divergence in front of each key
@@ -970,6 +980,12 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 		}
 		keyd_out[j] = d;
 	}
+#ifdef FSEQ_BK_STAMPS
+	BKS_T(4);
+	if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100))
+		printf("bk stream stamps block %u: pair leaves %lld | merges in groups %lld | single leaves etc %lld | group -> prefix %lld | outputs %lld | Dacc %u sliced %u turns %u\n",
+		       blockIdx.x, bks[0], bks[1], bks[2], bks[3], bks[4], Dacc, sliced, S.turn);
+#endif
 	if (tid == 0) *nkeys_out = Dacc;
 	__syncthreads();                                          // the workspace is reused for the next block
 	return sliced;
