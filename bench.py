@@ -63,9 +63,10 @@ def csrc_sha():
     return h.hexdigest()[:16]
 
 
-def load_pmc(workload):
-    """HBM bytes per step and kernel from the newest profiles/r*_pmc_traffic_<workload>.json taken on the current
-    kernel sources (rocprofv3 cannot run inside this process); (None, reason) otherwise."""
+def load_pmc_summary(workload):
+    """The newest profiles/r*_pmc_traffic_<workload>.json taken on the current kernel sources (rocprofv3 cannot run
+    inside this process), or None: HBM bytes per phase and kernel, and -- since round 4 -- the issue-side counters
+    and the effective clock of every kernel (profiles/summarize_pmc.py)."""
     import glob
     hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % workload)))
     sha = csrc_sha()
@@ -75,10 +76,83 @@ def load_pmc(workload):
                 d = json.load(f)
             if d.get("csrc_sha") != sha:
                 continue
-            return d["phases_hbm_bytes_per_step"], os.path.relpath(path, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)"
+            d["_path"] = os.path.relpath(path, ROOT)
+            return d
         except Exception:
             continue
-    return None, "no PMC summary under profiles/ for workload %s on kernel sources %s" % (workload, sha)
+    return None
+
+
+def load_pmc(workload):
+    """(HBM bytes per step and phase, source) from load_pmc_summary; (None, reason) without one."""
+    d = load_pmc_summary(workload)
+    if d is None:
+        return None, "no PMC summary under profiles/ for workload %s on kernel sources %s" % (workload, csrc_sha())
+    return d["phases_hbm_bytes_per_step"], d["_path"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)"
+
+
+N_SIMD = 1024                   # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
+NOMINAL_CLOCK_GHZ = 2.4
+
+
+def dominant_kernel_bound(workload, m, n, avg_launch_ms):
+    """What bounds the dominant kernel (phase C), from the PMC passes committed for THIS workload on THESE kernel
+    sources and the launch duration measured live.
+
+    LDS-resident kernels (k_columns): the order (a, d) of a block never leaves LDS, so HBM bytes bound nothing;
+    the SIMDs' vector issue does.  frac = SQ_ACTIVE_INST_VALU [quad-cycles, summed over the SIMDs] x 4 /
+    (1024 SIMDs x clock x launch time): the share of all vector issue slots of the launch that issued.  The clock is
+    the effective one of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs / its duration, MI355X_MICROARCH.md "DVFS
+    give-back"), not an assumed 2.4 GHz.  The LDS pipe's share is put beside it in the same normalisation.
+    Streamed kernel (k_columns_stream2: the order streams through HBM / L2): bound hbm, priced at the bytes the PMC
+    passes counted (FETCH_SIZE x 2 + WRITE_SIZE), not at the 17 B/cell of the formula."""
+    d = load_pmc_summary(workload)
+    prefix = None
+    if d is None and workload == "C4":
+        # the full C4 under rocprofv3 --pmc is a quarter of an hour per pass: its kernels are profiled on the 50,000-column
+        # prefix (same rows, same tiles, same kernel) and the per-cell figures carried over
+        d = load_pmc_summary("C4cols50k")
+        prefix = "C4cols50k"
+    if d is None or "issue" not in d:
+        return {"bound": None, "frac": None, "note": "no PMC issue summary under profiles/ for workload %s on kernel sources %s "
+                "(profiles/collect_profiles.sh + summarize_pmc.py write it)" % (workload, csrc_sha())}
+    name = None
+    for k, v in d["issue"].items():
+        if "k_columns" in k and "prologue" not in k and (name is None or v.get("avg_ns", 0) > d["issue"][name].get("avg_ns", 0)):
+            name = k
+    if name is None:
+        return {"bound": None, "frac": None, "note": "no k_columns kernel in " + d["_path"]}
+    c = d["issue"][name]
+    scale = 1.0
+    if prefix:
+        scale = (m * n) / float(WORKLOADS[prefix]["m"] * WORKLOADS[prefix]["n"])
+    clock_ghz = c.get("clock_ghz_effective") or NOMINAL_CLOCK_GHZ
+    cycles = clock_ghz * 1e9 * avg_launch_ms * 1e-3
+    valu_q = c.get("SQ_ACTIVE_INST_VALU", 0.0) * scale
+    lds_q = c.get("SQ_ACTIVE_INST_LDS", 0.0) * scale
+    conflict = c.get("SQ_LDS_BANK_CONFLICT", 0.0) * scale
+    out = {
+        "kernel": name,
+        "source": d["_path"] + (" (per-cell figures of the %s prefix scaled to the full workload)" % prefix if prefix else ""),
+        "clock_ghz": round(clock_ghz, 3),
+        "clock_source": "GRBM_GUI_ACTIVE / 8 / duration of the profiled launch" if c.get("clock_ghz_effective") else "nominal (no GRBM pass in the summary)",
+        "lane_instructions_per_cell": round(c.get("SQ_INSTS_VALU", 0.0) * scale * 64.0 / (m * n), 2),
+        "valu_issue_frac": round(valu_q * 4.0 / (N_SIMD * cycles), 4) if cycles else None,
+        "lds_issue_frac": round(lds_q * 4.0 / (N_SIMD * cycles), 4) if cycles else None,
+        "lds_bank_conflict_over_lds_active": round(conflict / lds_q, 3) if lds_q else None,
+        "salu_over_valu_insts": round(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3) if c.get("SQ_INSTS_VALU") else None,
+        "pmc_hbm_bytes_per_launch": c.get("hbm_bytes_per_launch_corrected", 0.0) * scale,
+    }
+    hbm_frac = out["pmc_hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_launch_ms else None
+    out["hbm_frac_pmc_bytes"] = round(hbm_frac, 4) if hbm_frac is not None else None
+    if "stream" in name:
+        out["bound"] = "hbm"
+        out["frac"] = out["hbm_frac_pmc_bytes"]
+        out["pmc_bytes_per_cell"] = round(out["pmc_hbm_bytes_per_launch"] / (m * n), 2)
+    else:
+        out["bound"] = "valu_issue"
+        out["frac"] = out["valu_issue_frac"]
+    return out
 
 
 def single_gpu_reference(workload):
@@ -196,62 +270,15 @@ def rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehe
                        "transport": transport_name}}), flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
-    ap.add_argument("--block-len", type=int, default=0)
-    ap.add_argument("--list-cap", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
-    ap.add_argument("--no-batched", action="store_true", help="(default) skip the secondary 8-alignments-in-flight measurement")
-    ap.add_argument("--batched", action="store_true", help="also measure 8 alignments in flight on the one GPU (secondary figure)")
-    ap.add_argument("--concurrent", type=int, default=1,
-                    help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
-    ap.add_argument("--rowshard-cols", type=int, default=0,
-                    help="instead of the headline step: the north-star row split (fseq_rowshard_pbwt) over this many columns of the "
-                         "workload, one JSON line of its own (columns/s; latency-bound by design, DESIGN.md section 6)")
-    ap.add_argument("--rowshard-threads", type=int, default=0,
-                    help="with --rowshard-cols on ONE GPU: this many ranks as threads of the process (all-reduce = barrier + "
-                         "device reduction) instead of torch.distributed ranks")
-    args = ap.parse_args()
+# BASELINE.json's other single-GPU configurations measured beside the headline: (steps, warm-up)
+OTHER_WORKLOADS = {"C2": (20, 3), "C5": (5, 2), "C4": (2, 1)}
 
-    import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the segmentation path has no CPU fallback")
-    # rehearsal on a box with fewer GPUs than ranks (FSEQ_BENCH_REHEARSAL=1): ranks share the cards and the
-    # timing collectives run over gloo on CPU tensors; everything else is the path the driver launches
-    rehearsal = bool(os.environ.get("FSEQ_BENCH_REHEARSAL"))
-    if rehearsal:
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    pkg = importlib.import_module("founder-sequences_amd")
-    fdist = importlib.import_module("founder-sequences_amd.dist")
-    if args.workload is None:
-        args.workload = "C3" if world == 1 else "C4"
-    w = dict(WORKLOADS[args.workload])
+def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank, local_rank, rehearsal):
+    """`warmup` untimed and exactly `steps` timed steps of workload `name` (barrier + torch.cuda.synchronize() on both
+    sides, max over ranks); returns {"line": the JSON line without cpu_baseline, "ctx": the context, "extra": []}."""
+    w = dict(WORKLOADS[name])
     m, n, L = w["m"], w["n"], w["L"]
-    if args.rowshard_cols:
-        rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehearsal)
-        if world > 1:
-            dist.destroy_process_group()
-        return
     ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
     transport = None
     if world > 1:
@@ -288,18 +315,18 @@ def main():
             for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
                 phase[k] = phase.get(k, 0.0) + t[k]
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     counted["on"] = True
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, max over ranks
-    dt = fdist.timed_steps(step, args.steps, 0, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
+    dt = fdist.timed_steps(step, steps, 0, dist=dist if world > 1 else None, device_sync=torch.cuda.synchronize,
                            tensor_factory=lambda v: torch.tensor(v, dtype=torch.float64, device="cpu" if rehearsal else "cuda"))
 
     t = ctx.timings()
     res = ctx.result
-    steps = max(1, args.steps)
-    ph = {k: v / steps for k, v in phase.items()}
-    step_ms = dt / steps * 1e3
+    nsteps = max(1, steps)
+    ph = {k: v / nsteps for k, v in phase.items()}
+    step_ms = dt / nsteps * 1e3
     R = int(t["pass2_cells"])
     # ONE figure for the path -- 17 B per cell per pass-1 column update, pass 2's R cells at the
     # same price, over the whole step (pass 1 + DP + traceback + merge + pass 2)
@@ -308,7 +335,7 @@ def main():
     # per kernel: HIP-event time on the library's own stream (fseq_timings), algorithmic bytes of what the launch
     # processes, and -- when profiles/ holds PMC passes of THIS workload taken on THESE kernel sources -- the HBM
     # bytes rocprofv3 counted (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
-    pmc, pmc_src = load_pmc(args.workload)
+    pmc, pmc_src = load_pmc(name)
     launches_c = 1 + t["retries"]
     kernels = {
         "phase_a k_blockkeys (block keys ranked in key space)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
@@ -329,14 +356,30 @@ def main():
         d["ms"] = round(d["ms"], 4)
         d["algorithmic_GBps"] = round(d["algorithmic_bytes"] / (d["ms"] * 1e-3) / 1e9, 1) if d["ms"] > 0 and d["algorithmic_bytes"] else None
     ms_c = ph["ms_phase_c"]
+    # the dominant kernel: what really bounds it (VALU issue for the LDS-resident kernels, PMC-counted HBM bytes for the
+    # streamed one); the 17 B/cell figure stays as `algorithmic_frac` -- an accounting device that can exceed 1 because
+    # the order of a block never leaves LDS
+    dom = dominant_kernel_bound(name, m, n, ms_c / launches_c)
+    dom_out = {
+        "name": "k_columns (phase C: per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
+        "avg_launch_ms": ms_c / launches_c,
+        "bound": dom.get("bound"),
+        "frac": dom.get("frac"),
+        "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
+        "algorithmic_achieved_GBps": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9,
+        "algorithmic_frac": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+        "algorithmic_frac_note": "17 B/cell over the launch time against 8 TB/s: NOT a fraction of anything for the LDS-resident kernels "
+                                 "(it may exceed 1: the order (a, d) of a block never leaves LDS); `frac` is the bound that can be approached",
+    }
+    dom_out.update({k: v for k, v in dom.items() if k not in ("bound", "frac")})
     out = {
         "metric": "alignment cells/s (m*n/T) through pBWT+DP",
-        "value": max(1, args.concurrent) * m * n * steps / dt,
+        "value": max(1, args.concurrent) * m * n * nsteps / dt,
         "unit": "cells/s",
         "n_gpus": (min(world, max(1, torch.cuda.device_count())) if rehearsal else world),      # devices, not ranks: a rehearsal shares cards
         "ranks": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
+        "steps": steps,
+        "warmup": warmup,
         "ms_per_step": step_ms,
         "higher_is_better": True,
         "scaling": "strong" if world > 1 else "weak",
@@ -346,15 +389,16 @@ def main():
         "config": {
             "workload": "%s: m=%d x n=%d synthetic founder-mosaic DNA (sigma=%d), segment-length-bound L=%d, "
                         "input resident in HBM column-major, %d bits per cell; %s"
-                        % (args.workload, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2,
+                        % (name, m, n, 16 if w["kind"] else 4, L, 4 if w["kind"] else 2,
                            "one alignment on one GPU" if world == 1 else
                            "ONE alignment sharded over %d ranks by contiguous column blocks (each rank holds its own columns)" % world),
             "parallelism": "1 GPU" if world == 1 else "column-block shards x%d: phase A/C/pass 2 and the DP chunks local, %d all-reduces (%.1f MB) per step over %s"
-                           % (world, transport.calls // max(1, args.steps + args.warmup), transport.words_moved * 4 / max(1, args.steps + args.warmup) / 1e6,
+                           % (world, transport.calls // max(1, steps + warmup), transport.words_moved * 4 / max(1, steps + warmup) / 1e6,
                               "gloo via host (rehearsal: ranks share a GPU)" if rehearsal else "RCCL"),
             # strong scaling is judged against ONE GPU on the SAME workload: the N = 1 default of this script is C3, so the
-            # committed single-GPU line of this workload is quoted here (python bench.py --workload C4 reproduces it)
-            "single_gpu_same_workload": single_gpu_reference(args.workload) if world > 1 else None,
+            # committed single-GPU line of this workload is quoted here (python bench.py --workload C4 reproduces it; since
+            # round 4 the N = 1 line also carries it under config.other_workloads)
+            "single_gpu_same_workload": single_gpu_reference(name) if world > 1 else None,
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "dp_chunks": t["dp_chunks"], "dp_sweeps": t["dp_sweeps"],
@@ -368,7 +412,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "scope": "whole path, SURVEY.md 8(d): 17 B x (m*n + R) / step time; the block state lives in LDS, so the bytes "
-                     "HBM really moves (traffic) are far below this algorithmic figure",
+                     "HBM really moves (traffic) are far below this algorithmic figure; the kernel-level bound is under dominant_kernel",
             "achieved": path_gbps,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -377,20 +421,77 @@ def main():
             "traffic": traffic,
             "traffic_source": pmc_src,
             "algorithmic_bytes_per_step": path_bytes,
-            "dominant_kernel": {
-                "name": "k_columns (phase C: per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
-                "avg_launch_ms": ms_c / launches_c,
-                "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
-                "achieved": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9,
-                "frac": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            },
+            "dominant_kernel": dom_out,
             "kernels": kernels,
         },
     }
+    return {"line": out, "ctx": ctx, "extra": extra}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--block-len", type=int, default=0)
+    ap.add_argument("--list-cap", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-batched", action="store_true", help="(default) skip the secondary 8-alignments-in-flight measurement")
+    ap.add_argument("--batched", action="store_true", help="also measure 8 alignments in flight on the one GPU (secondary figure)")
+    ap.add_argument("--concurrent", type=int, default=1,
+                    help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="N = 1 without --workload also measures C2, C5 and C4 (config.other_workloads); this skips them")
+    ap.add_argument("--rowshard-cols", type=int, default=0,
+                    help="instead of the headline step: the north-star row split (fseq_rowshard_pbwt) over this many columns of the "
+                         "workload, one JSON line of its own (columns/s; latency-bound by design, DESIGN.md section 6)")
+    ap.add_argument("--rowshard-threads", type=int, default=0,
+                    help="with --rowshard-cols on ONE GPU: this many ranks as threads of the process (all-reduce = barrier + "
+                         "device reduction) instead of torch.distributed ranks")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the segmentation path has no CPU fallback")
+    # rehearsal on a box with fewer GPUs than ranks (FSEQ_BENCH_REHEARSAL=1): ranks share the cards and the
+    # timing collectives run over gloo on CPU tensors; everything else is the path the driver launches
+    rehearsal = bool(os.environ.get("FSEQ_BENCH_REHEARSAL"))
+    if rehearsal:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if rehearsal:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    pkg = importlib.import_module("founder-sequences_amd")
+    fdist = importlib.import_module("founder-sequences_amd.dist")
+    headline_default = args.workload is None
+    if args.workload is None:
+        args.workload = "C3" if world == 1 else "C4"
+    w = dict(WORKLOADS[args.workload])
+    m, n, L = w["m"], w["n"], w["L"]
+    if args.rowshard_cols:
+        rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehearsal)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    run = run_workload(pkg, fdist, torch, dist, args.workload, args.steps, args.warmup, args, world, rank, local_rank, rehearsal)
+    ctx, out = run["ctx"], run["line"]
     # secondary figure (not `value`): the DP of one alignment occupies one CU for ~2/3 of a step, so
     # several alignments (chromosomes) in flight share the chip; measured with 8 contexts / host threads
     if world == 1 and args.concurrent == 1 and args.batched:
-        import threading
         others = []
         for j in range(1, 8):
             e = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
@@ -411,6 +512,33 @@ def main():
         out["cpu_baseline"] = cpu_baseline(ctx, w, args.cpu_threads or min(os.cpu_count() or 1, 16))
     else:
         out["cpu_baseline"] = None
+    ctx.close()
+    for e in run["extra"]:
+        e.close()
+    # The other single-GPU configurations of BASELINE.json, each with its own small step count, in the same invocation
+    # (only when the driver's plain command is run: no --workload given): C2 (configs[1]), C5 (configs[4]'s alignment on
+    # one GPU) and C4 (configs[3]'s alignment on ONE GPU: the N = 1 anchor of the scaling curve).  Not part of `value`.
+    if world == 1 and headline_default and not args.no_other_workloads and args.concurrent == 1:
+        others_out = {}
+        for name, (k_steps, k_warm) in OTHER_WORKLOADS.items():
+            t0 = time.perf_counter()
+            try:
+                r = run_workload(pkg, fdist, torch, dist, name, k_steps, k_warm, args, world, rank, local_rank, rehearsal)
+                r["ctx"].close()
+                ln = r["line"]
+                others_out[name] = {
+                    "value": ln["value"], "unit": "cells/s", "ms_per_step": ln["ms_per_step"], "steps": k_steps, "warmup": k_warm,
+                    "workload": ln["config"]["workload"], "phases_ms": ln["config"]["phases_ms"], "pass2_cells": ln["config"]["pass2_cells"],
+                    "block_len": ln["config"]["block_len"], "n_blocks": ln["config"]["n_blocks"], "list_cap": ln["config"]["list_cap"],
+                    "dp_sweeps": ln["config"]["dp_sweeps"], "segments": ln["config"]["segments"], "max_segment_size": ln["config"]["max_segment_size"],
+                    "path_frac": ln["roofline"]["frac"], "path_achieved_GBps": ln["roofline"]["achieved"],
+                    "traffic": ln["roofline"]["traffic"],
+                    "dominant_kernel": ln["roofline"]["dominant_kernel"],
+                    "wall_s_incl_setup": round(time.perf_counter() - t0, 2),
+                }
+            except Exception as ex:                       # a failure here must not take the headline line with it
+                others_out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+        out["config"]["other_workloads"] = others_out
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -79,9 +79,10 @@ EXPORTS = [
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
     "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile", "fseq_debug_set_tuning",
+    "fseq_shard_abort", "fseq_debug_dp_owned",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
-DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
+DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_dp_owned", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
 
 FSEQ_E_PEER = 6
 STAGE_TRACEBACK, STAGE_MERGE, STAGE_SAMPLES = 0, 1, 2
@@ -158,6 +159,8 @@ def load_library():
     L.fseq_current_step.restype = u64
     L.fseq_current_step.argtypes = [vp]
     L.fseq_set_memory_budget.argtypes = [vp, u64]
+    L.fseq_shard_abort.argtypes = [vp, C.c_int]
+    L.fseq_debug_dp_owned.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -367,6 +370,10 @@ class SegmentationContext:
         self._check(self.L.fseq_set_shard(self.h, rank, world, xbuf_ptr, xbuf_words, self._shard_cb, None))
         self.rank, self.world = rank, world
 
+    def shard_abort(self, code=FSEQ_E_HIP):
+        """This rank's host has failed and makes no further calls: the other ranks return FSEQ_E_PEER from their next exchange."""
+        self._check(self.L.fseq_shard_abort(self.h, int(code)))
+
     def set_memory_budget(self, nbytes):
         """Device memory this context may hold in all (ranks that share a card); 0 = whatever is free."""
         self._check(self.L.fseq_set_memory_budget(self.h, int(nbytes)))
@@ -496,6 +503,13 @@ class SegmentationContext:
         sz = np.zeros(k, dtype=np.uint32)
         self._check(self.L.fseq_debug_dp(self.h, lb.ctypes.data, mx.ctypes.data, sz.ctypes.data))
         return lb, mx, sz
+
+    def debug_dp_owned(self):
+        """(first, last, owns_final_cell, whole_arrays): the DP entries this rank computed (everything when not sharded)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        f, w = C.c_int(), C.c_int()
+        self._check(self.L.fseq_debug_dp_owned(self.h, C.byref(a), C.byref(b), C.byref(f), C.byref(w)))
+        return a.value, b.value, bool(f.value), bool(w.value)
 
     def debug_block_state(self, b):
         a = np.zeros(self.m, dtype=np.uint32)

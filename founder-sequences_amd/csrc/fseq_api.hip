@@ -309,6 +309,8 @@ struct Tuning {
 	bool poison_lists = false;           // FSEQ_POISON_LISTS: lists and headers filled with 0xFF before phase C
 	bool no_emitter_wave = false;        // FSEQ_NO_EMITTER_WAVE: phase C without the list wave
 	bool join_host = false;              // FSEQ_JOIN_HOST: the greedy joiner's class tables and edges on the host
+	bool shard_dp_full = false;          // FSEQ_SHARD_DP_FULL: the sharded DP gathers the whole key array after every sweep (round 2-3 form)
+	int  shard_dp_window = 0;            // FSEQ_SHARD_DP_WINDOW: entries of the other ranks a rank holds in front of its own (tests: small windows)
 	int  inject_failure_rank = -1;       // FSEQ_INJECT_FAILURE_RANK: this rank of a sharded run fails after phase A
 	std::string sync_phases;             // FSEQ_SYNC_PHASES: "ABC": synchronise after these phases (a fault shows where it happened)
 	bool check_phase_a = false;          // FSEQ_CHECK_PHASE_A: validate the key blocks on the host before phase B
@@ -343,6 +345,8 @@ struct Tuning {
 		else if (n == "FSEQ_POISON_LISTS") poison_lists = on;
 		else if (n == "FSEQ_NO_EMITTER_WAVE") no_emitter_wave = on;
 		else if (n == "FSEQ_JOIN_HOST") join_host = on;
+		else if (n == "FSEQ_SHARD_DP_FULL") shard_dp_full = on;
+		else if (n == "FSEQ_SHARD_DP_WINDOW") shard_dp_window = on ? std::max(64, iv) : 0;
 		else if (n == "FSEQ_INJECT_FAILURE_RANK") inject_failure_rank = on ? iv : -1;
 		else if (n == "FSEQ_SYNC_PHASES") sync_phases = v;
 		else if (n == "FSEQ_CHECK_PHASE_A") check_phase_a = on;
@@ -355,7 +359,8 @@ struct Tuning {
 		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
-			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A"};
+			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
+			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -373,6 +378,8 @@ struct Shard {
 	uint32_t active = 1;                    // ranks that own blocks
 	uint32_t b_lo = 0, b_hi = 0;            // my blocks
 	uint64_t c_lo = 0, c_hi = 0, c_end = 0; // my columns [c_lo, c_hi); held: [c_lo, c_end) (halo for my last DP round)
+	bool posted = false;                    // this rank has told the others that it failed (once per context)
+	bool closed = false;                    // the run's last exchange is done: nobody is left to hear of a failure
 };
 
 struct fseq_ctx {
@@ -403,6 +410,13 @@ struct fseq_ctx {
 	uint2 *d_tau = nullptr;                  // merge thresholds (k_seg_tau) / counts
 	size_t tau_cap = 0;
 	std::vector<int64_t> snap_slot;          // segment index -> slot in d_snap_* (-1: another rank's)
+	// sharded DP (run_dp_spec): the DP entries [own_lo[g], own_hi[g]) belong to rank g (the last active rank also owns the
+	// final cell's); dp_window_mode: a rank holds its own entries and a window of the others' in front of them, not the
+	// whole arrays (the traceback then runs rank by rank, follow_traceback_sharded)
+	std::vector<uint32_t> own_lo, own_hi;
+	bool dp_window_mode = false;
+	bool shard_dp_full_sticky = false;       // a sweep of this input read below its window once: whole-array exchanges from then on
+	uint64_t dp_exchange_words = 0;          // words the DP's sweep exchanges moved in the last run (diagnostics)
 
 	// input
 	uint8_t *d_msa = nullptr;
@@ -429,11 +443,17 @@ struct fseq_ctx {
 	size_t lds_columns = 0;
 
 	// device work buffers
+	// per column block: key blocks (phase A) and boundary states (phase B), indexed by the block's place in the whole
+	// alignment.  A rank of a sharded run allocates its own blocks [b_lo, b_hi] only (*_alloc) and shifts the pointer
+	// (block b at d_rank + b * m as before): memory per rank falls with the rank count
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
+	uint32_t *d_rank_alloc = nullptr, *d_keyd_alloc = nullptr, *d_nkeys_alloc = nullptr, *d_bstate_a_alloc = nullptr, *d_bstate_d_alloc = nullptr;
+	uint32_t *d_ws_c = nullptr;              // streamed phase C: the per-block workspaces, block b at d_ws_c + b * (words per block)
 	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
 	// not sharded: phase B over any number of levels (levels[i - 1] = the composites of chain_fan level-(i - 1) key blocks)
-	struct ChainLevel { uint32_t count = 0; uint64_t cols = 0; uint32_t *rank = nullptr, *keyd = nullptr, *nkeys = nullptr, *state_a = nullptr, *state_d = nullptr; };
+	struct ChainLevel { uint32_t count = 0; uint64_t cols = 0; uint32_t *rank = nullptr, *keyd = nullptr, *nkeys = nullptr, *state_a = nullptr, *state_d = nullptr;
+	                    uint32_t *rank_alloc = nullptr, *keyd_alloc = nullptr, *nkeys_alloc = nullptr, *state_a_alloc = nullptr, *state_d_alloc = nullptr; };
 	std::vector<ChainLevel> levels;
 	uint32_t chain_fan = 0;
 	uint32_t shard_k = 0, shard_q = 0;       // sharded: a rank's hyper-block = shard_q groups of chain_fan^shard_k blocks
@@ -445,7 +465,7 @@ struct fseq_ctx {
 	uint32_t X_hint = 0;                     // list capacity that worked on the last run of this input
 	DpArrays dp{};
 	uint32_t *d_Mprev = nullptr;             // chunk-speculative DP: the iterate the last sweep started from
-	uint32_t *d_spec = nullptr;              // its per-chunk words (active, changed, tailmin, floor, lift, ovf) + SpecCtl
+	uint32_t *d_spec = nullptr;              // its per-chunk words (active, changed, tailmin, floor, lift, 2 x ovf) + SpecCtl
 	uint32_t spec_cap = 0;
 	uint32_t *d_flags = nullptr;
 	uint32_t *d_recent = nullptr;            // k_boundary_recent counts, one per block boundary
@@ -544,6 +564,16 @@ int dev_alloc(fseq_ctx *c, U **p, size_t count)
 	return FSEQ_OK;
 }
 
+// items [lo, hi) of an array of `per` words per item: *alloc owns the memory, *view is shifted so that item i sits at
+// *view + i * per (a rank of a sharded run holds its own column blocks only, addressed by their place in the whole alignment)
+template <typename U>
+int dev_alloc_range(fseq_ctx *c, U **alloc, U **view, size_t lo, size_t hi, size_t per)
+{
+	int const rc = dev_alloc(c, alloc, (hi > lo ? hi - lo : 0) * per);
+	*view = rc ? nullptr : *alloc - lo * per;
+	return rc;
+}
+
 // Pinned host staging.  A copy between the device and pageable host memory is staged by the runtime -- one blocking round
 // trip of 20-50 microseconds each, and a step had a dozen of them (flags, counts, the traceback, thresholds: a fifth of a
 // BASELINE C2 step).  pin_reserve(bytes) opens a stage (what the previous one handed out is dead), pin_take carves it.
@@ -624,9 +654,10 @@ void block_geometry(fseq_ctx *c)
 		if (ncu < 1) ncu = 256;
 		uint64_t const cols = (p.n + sh.world - 1) / sh.world;
 		uint64_t k = (cols + (uint64_t) ncu * 4096 - 1) / ((uint64_t) ncu * 4096);
-		// (the second form of the streamed phase C runs two workgroups per CU: an odd number of half-rounds above one ends on a
-		// half-empty round)
-		if (k > 1 && (k & 1u) && (uint64_t) p.m + 4096u < (1ull << 19) && !c->tune.stream_plain_scan && c->tune.stream2 != "0") ++k;
+		// (the second form of the streamed phase C runs -- and was tuned for -- two workgroups per CU: a rank's blocks are whole
+		// rounds of 2 x CUs workgroups, also when one workgroup per CU would hold its columns: BASELINE C4 on 8 ranks is 512
+		// blocks of 1,221 columns per rank, not 256 of 2,442 with every CU's second slot empty)
+		if ((k & 1u) && (uint64_t) p.m + 4096u < (1ull << 19) && !c->tune.stream_plain_scan && c->tune.stream2 != "0") ++k;
 		uint64_t per = streamed ? (uint64_t) ncu * k : 1024u;
 		uint64_t b = (p.n + per * sh.world - 1) / (per * sh.world);
 		if (b < 16) b = 16;
@@ -806,7 +837,14 @@ int prepare_geometry(fseq_ctx *c)
 					c->auto_B = (uint32_t) b;
 					block_geometry(c);
 					c->lds_columns = c->ks.columns_lds(c->B);
-					if (c->lds_columns > LDS_LIMIT) return fail(c, FSEQ_E_UNSUPPORTED, "block state does not fit the 160 KiB LDS of one CU");
+					// (rounds is rounded down, so the refit can RAISE the block length by up to ~1.5x: when the longer block no
+					// longer fits the LDS, or holds another number of workgroups per CU than it was fitted for, keep the first one)
+					if (c->lds_columns > LDS_LIMIT || (uint64_t) std::max(ncu, 1) * c->ks.columns_resident(c->lds_columns) != slots)
+					{
+						c->auto_B = 0;
+						block_geometry(c);
+						c->lds_columns = c->ks.columns_lds(c->B);
+					}
 					HIP_TRY(c, c->ks.prepare_columns(c->lds_columns));
 				}
 			}
@@ -842,49 +880,32 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	int rc;
 	if (!c->d_rank)
 	{
-		if ((rc = dev_alloc(c, &c->d_rank, (size_t) c->nblocks * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_keyd, (size_t) c->nblocks * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_nkeys, c->nblocks))) return rc;
-		if ((rc = dev_alloc(c, &c->d_bstate_a, ((size_t) c->nblocks + 1) * m))) return rc;
-		if ((rc = dev_alloc(c, &c->d_bstate_d, ((size_t) c->nblocks + 1) * m))) return rc;
-		if (!c->sh.on)
+		// my blocks [bl, bh) (all of them when not sharded); boundary states also behind my last block
+		size_t const bl = c->sh.on ? c->sh.b_lo : 0, bh = c->sh.on ? std::max(c->sh.b_hi, c->sh.b_lo) : c->nblocks;
+		if ((rc = dev_alloc_range(c, &c->d_rank_alloc, &c->d_rank, bl, bh, m))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_keyd_alloc, &c->d_keyd, bl, bh, m))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_nkeys_alloc, &c->d_nkeys, bl, bh, 1))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_bstate_a_alloc, &c->d_bstate_a, bl, bh + 1, m))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_bstate_d_alloc, &c->d_bstate_d, bl, bh + 1, m))) return rc;
 		{
-			// the composites of phase B, level by level, until at most chain_fan are left
+			// the composites of phase B, level by level: until at most chain_fan are left, or -- sharded -- shard_k levels below
+			// the hyper key blocks (indexed like the blocks: by their place in the whole alignment; a rank holds its own range)
 			uint32_t cnt = c->nblocks;
 			uint64_t cols = c->B;
-			while (cnt > c->chain_fan)
+			size_t lo = bl, hi = bh;
+			for (uint32_t i = 0; c->sh.on ? i < c->shard_k : cnt > c->chain_fan; ++i)
 			{
 				fseq_ctx::ChainLevel lv;
 				lv.count = (cnt + c->chain_fan - 1) / c->chain_fan;
 				lv.cols = cols * c->chain_fan;
-				if ((rc = dev_alloc(c, &lv.rank, (size_t) lv.count * m))) return rc;
+				lo = lo / c->chain_fan; hi = (hi + c->chain_fan - 1) / c->chain_fan;
 				c->levels.push_back(lv);                               // (pushed at once: free_work releases what is there)
 				fseq_ctx::ChainLevel &L = c->levels.back();
-				if ((rc = dev_alloc(c, &L.keyd, (size_t) L.count * m))) return rc;
-				if ((rc = dev_alloc(c, &L.nkeys, L.count))) return rc;
-				if ((rc = dev_alloc(c, &L.state_a, ((size_t) L.count + 1) * m))) return rc;
-				if ((rc = dev_alloc(c, &L.state_d, ((size_t) L.count + 1) * m))) return rc;
-				cnt = L.count; cols = L.cols;
-			}
-		}
-		else
-		{
-			// sharded: shard_k levels below the hyper key blocks (indexed like the blocks: by their place in the whole
-			// alignment; a rank fills its own range)
-			uint32_t cnt = c->nblocks;
-			uint64_t cols = c->B;
-			for (uint32_t i = 0; i < c->shard_k; ++i)
-			{
-				fseq_ctx::ChainLevel lv;
-				lv.count = (cnt + c->chain_fan - 1) / c->chain_fan;
-				lv.cols = cols * c->chain_fan;
-				if ((rc = dev_alloc(c, &lv.rank, (size_t) lv.count * m))) return rc;
-				c->levels.push_back(lv);
-				fseq_ctx::ChainLevel &L = c->levels.back();
-				if ((rc = dev_alloc(c, &L.keyd, (size_t) L.count * m))) return rc;
-				if ((rc = dev_alloc(c, &L.nkeys, L.count))) return rc;
-				if ((rc = dev_alloc(c, &L.state_a, ((size_t) L.count + 1) * m))) return rc;
-				if ((rc = dev_alloc(c, &L.state_d, ((size_t) L.count + 1) * m))) return rc;
+				if ((rc = dev_alloc_range(c, &L.rank_alloc, &L.rank, lo, hi, m))) return rc;
+				if ((rc = dev_alloc_range(c, &L.keyd_alloc, &L.keyd, lo, hi, m))) return rc;
+				if ((rc = dev_alloc_range(c, &L.nkeys_alloc, &L.nkeys, lo, hi, 1))) return rc;
+				if ((rc = dev_alloc_range(c, &L.state_a_alloc, &L.state_a, lo, hi + 1, m))) return rc;
+				if ((rc = dev_alloc_range(c, &L.state_d_alloc, &L.state_d, lo, hi + 1, m))) return rc;
 				cnt = L.count; cols = L.cols;
 			}
 		}
@@ -914,9 +935,13 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 	}
 	if (c->use_stream && !c->d_ws)
 	{
+		// one workspace per block of phase C (sharded: my blocks and the halo block behind them); phase A's column sweep, phase B
+		// and pass 2 index the same memory by workgroup (4m words each)
 		size_t const per_block = std::max<size_t>(columns_stream_ws_words(p.m, c->B), (size_t) 4 * m);
-		c->ws_words = per_block * std::max<size_t>(c->nblocks, 1);
+		size_t const bl = c->sh.on ? c->sh.b_lo : 0, bh = c->sh.on ? std::min<size_t>(c->nblocks, (size_t) std::max(c->sh.b_hi, c->sh.b_lo) + 1) : c->nblocks;
+		c->ws_words = per_block * std::max<size_t>(bh - bl, 1);
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) return rc;
+		c->d_ws_c = c->d_ws - bl * columns_stream_ws_words(p.m, c->B);
 	}
 	uint64_t const k_lo = held_lo(c), k_cnt = held_hi(c) - k_lo;      // sharded: lists and stride states of my columns only
 	if (X && (!c->d_ent || c->X != X))
@@ -994,10 +1019,11 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 
 void free_work(fseq_ctx *c)
 {
-	dev_free(c, &c->d_rank); dev_free(c, &c->d_keyd); dev_free(c, &c->d_nkeys);
-	dev_free(c, &c->d_bstate_a); dev_free(c, &c->d_bstate_d);
+	dev_free(c, &c->d_rank_alloc); dev_free(c, &c->d_keyd_alloc); dev_free(c, &c->d_nkeys_alloc);
+	dev_free(c, &c->d_bstate_a_alloc); dev_free(c, &c->d_bstate_d_alloc);
+	c->d_rank = c->d_keyd = c->d_nkeys = c->d_bstate_a = c->d_bstate_d = nullptr;
 	dev_free(c, &c->d_hrank); dev_free(c, &c->d_hkeyd); dev_free(c, &c->d_hnkeys); dev_free(c, &c->d_hstate_a); dev_free(c, &c->d_hstate_d);
-	for (auto &lv : c->levels) { dev_free(c, &lv.rank); dev_free(c, &lv.keyd); dev_free(c, &lv.nkeys); dev_free(c, &lv.state_a); dev_free(c, &lv.state_d); }
+	for (auto &lv : c->levels) { dev_free(c, &lv.rank_alloc); dev_free(c, &lv.keyd_alloc); dev_free(c, &lv.nkeys_alloc); dev_free(c, &lv.state_a_alloc); dev_free(c, &lv.state_d_alloc); }
 	c->levels.clear();
 	dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr; dev_free(c, &c->d_hdr); dev_free(c, &c->d_flags); dev_free(c, &c->d_recent);
 	dev_free(c, &c->d_chunk_r0); c->chunk_cap = 0; dev_free(c, &c->d_tau); c->tau_cap = 0;
@@ -1007,7 +1033,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
 	dev_free(c, &c->d_cols); dev_free(c, &c->d_grp); dev_free(c, &c->d_src); dev_free(c, &c->d_ss_a_alloc); dev_free(c, &c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
-	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws);
+	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 }
 
@@ -1017,7 +1043,18 @@ void free_work(fseq_ctx *c)
 int shard_exchange(fseq_ctx *c, uint64_t words, int op);
 void shard_post_failure(fseq_ctx *c, int code);
 
+int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows);
+
+// (sharded: the upload contains an exchange -- the alphabet of the whole alignment -- so a rank that fails here, before or
+// behind it, says so in the exchange the others make next instead of leaving them in a collective)
 int upload_rows_device(fseq_ctx *c, uint8_t const *const *rows)
+{
+	int const rc = upload_rows_device_impl(c, rows);
+	shard_post_failure(c, rc);
+	return rc;
+}
+
+int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 {
 	fseq_params const &p = c->p;
 	uint64_t const k_lo = held_lo(c), nloc = held_hi(c) - k_lo;      // sharded: this rank's columns only
@@ -1118,8 +1155,86 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 // follow_traceback (segmentation_lp_context.cc:191-224): the lb chain is followed on the device, window by window
 // (k_tb_windows / k_tb_chain / k_tb_emit, fseq_kernels.hpp); the S visited entries come back in one small copy.
 // Scratch: Mprev (exit pointers) and the first words of K (hop counts) -- both are free once the DP is done.
+int shard_exchange(fseq_ctx *c, uint64_t words, int op);
+
+// The same when every rank of a sharded run holds the lb's of its own entries only (run_dp_spec, windows): the chain is
+// followed rank by rank -- the owner of the entry it stands at walks its part and tells the others where it left and
+// how many entries it visited (two words) --, every rank emits its entries at their place in the whole list, and the
+// S x 16 bytes are gathered: one small exchange per rank the chain passes through instead of the lb and size arrays.
+int follow_traceback_sharded(fseq_ctx *c, hipStream_t st)
+{
+	Shard const &sh = c->sh;
+	uint32_t const L = (uint32_t) c->p.segment_length, dp_size = (uint32_t) c->dp_size;
+	size_t const cap = (size_t) (c->p.n / L + 2);
+	uint32_t const nwin = (dp_size + TB_WIN - 1u) / TB_WIN;
+	int rc;
+	if (c->tb_cap < cap || c->tb_win < nwin)
+	{
+		if ((rc = dev_alloc(c, &c->d_tb, cap + nwin / 2 + 2))) return rc;
+		c->tb_cap = cap; c->tb_win = nwin;
+	}
+	uint2 *d_head = reinterpret_cast<uint2 *>(c->d_tb + cap);
+	uint32_t *d_count = reinterpret_cast<uint32_t *>(d_head + nwin);
+	uint32_t *d_exit_next = c->d_Mprev, *d_exit_cnt = reinterpret_cast<uint32_t *>(c->dp.K);
+	// my part: my entries, and the final cell's (the last entry of the array) on the last active rank
+	bool const have = sh.rank < sh.active && c->own_hi[sh.rank] > c->own_lo[sh.rank];
+	uint32_t const vlo = have ? c->own_lo[sh.rank] : 0u, vhi = have ? (sh.rank + 1u == sh.active ? dp_size : c->own_hi[sh.rank]) : 0u;
+	HIP_TRY(c, hipMemsetAsync(d_count, 0, 16, st));
+	if (have) hipLaunchKernelGGL(k_tb_windows, dim3(nwin), dim3(256), 0, st, c->dp.LB, dp_size, L, d_exit_next, d_exit_cnt, vlo, vhi);
+	auto owner_of = [&](uint32_t t) {
+		uint32_t g = sh.active - 1u;
+		while (g > 0 && t < c->own_lo[g]) --g;
+		return g;
+	};
+	uint32_t cur = dp_size - 1u, off = 0, my_cnt = 0, my_off = 0, hops = 0;
+	while (true)
+	{
+		uint32_t const g = owner_of(cur);
+		HIP_TRY(c, hipMemsetAsync(sh.xbuf, 0, 16, st));
+		if (g == sh.rank) hipLaunchKernelGGL(k_tb_chain_part, dim3(1), dim3(64), 0, st, d_exit_next, d_exit_cnt, cur, off, vlo, d_head, nwin, d_count, sh.xbuf);
+		if ((rc = shard_exchange(c, 4, 0))) return rc;
+		uint32_t w[4];
+		HIP_TRY(c, hipMemcpy(w, sh.xbuf, 16, hipMemcpyDeviceToHost));
+		if (g == sh.rank) { my_cnt = w[1]; my_off = off; }
+		off += w[1];
+		if (w[1] == 0 || off > cap || ++hops > sh.active) return fail(c, FSEQ_E_HIP, "internal: the sharded traceback chain does not descend");
+		if (w[0] == 0) break;                                       // the chain ended on rank g
+		if (w[0] - 1u >= c->own_lo[g]) return fail(c, FSEQ_E_HIP, "internal: the sharded traceback chain left a rank upwards");
+		cur = w[0] - 1u;
+	}
+	size_t const S = off;
+	if (my_cnt) hipLaunchKernelGGL(k_tb_emit, dim3(nwin), dim3(256), 0, st, c->dp.LB, c->dp.M, c->dp.SZ, dp_size, L, d_head, d_count, c->d_tb, (uint32_t) cap, vlo);
+	// gather: every rank's entries sit at their final offsets of its own d_tb; word 4 S: "the chain ended in lb == 0"
+	if (4 * S + 2 > sh.xwords) return fail(c, FSEQ_E_ARG, "exchange buffer too small (fseq_shard_xbuf_words)");
+	HIP_TRY(c, hipMemsetAsync(sh.xbuf, 0, (4 * S + 1) * 4, st));
+	if (my_cnt)
+	{
+		// (the chain visits a rank once, so my entries are one range of the list: d_tb[my_off .. my_off + my_cnt))
+		HIP_TRY(c, hipMemcpyAsync(sh.xbuf + 4 * (size_t) my_off, c->d_tb + my_off, (size_t) my_cnt * sizeof(uint4), hipMemcpyDeviceToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(sh.xbuf + 4 * S, d_count + 1, 4, hipMemcpyDeviceToDevice, st));
+	}
+	if ((rc = shard_exchange(c, 4 * S + 1, 0))) return rc;
+	std::vector<uint4> h(S);
+	uint32_t ok = 0;
+	HIP_TRY(c, hipMemcpyAsync(h.data(), sh.xbuf, S * sizeof(uint4), hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(&ok, sh.xbuf + 4 * S, 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	HIP_TRY(c, hipGetLastError());
+	if (ok != 1u || S == 0) return fail(c, FSEQ_E_HIP, "internal: the traceback chain does not descend to lb == 0");
+	c->tau_host.clear();
+	c->tb_guess = S;
+	c->traceback.resize(S);
+	for (size_t j = 0; j < S; ++j)
+	{
+		uint4 const e = h[S - 1 - j];                        // the kernels list the last segment first
+		c->traceback[j] = fseq_dp_arg{e.y, (uint64_t) e.x + L, e.z, e.w};
+	}
+	return FSEQ_OK;
+}
+
 int follow_traceback(fseq_ctx *c, hipStream_t st)
 {
+	if (c->sh.on && c->dp_window_mode) return follow_traceback_sharded(c, st);
 	uint32_t const L = (uint32_t) c->p.segment_length, dp_size = (uint32_t) c->dp_size;
 	size_t const cap = (size_t) (c->p.n / L + 2);           // a segment is at least L columns long
 	uint32_t const nwin = (dp_size + TB_WIN - 1u) / TB_WIN;
@@ -1261,6 +1376,10 @@ int shard_exchange(fseq_ctx *c, uint64_t words, int op)
 void shard_post_failure(fseq_ctx *c, int code)
 {
 	if (!c->sh.on || code == FSEQ_OK || code == FSEQ_E_NO_REDUCTION || code == FSEQ_E_PEER) return;
+	// once per context (the status exchange is a collective: a second post would have no partner), and not behind the
+	// last exchange of a run (the other ranks have left)
+	if (c->sh.posted || c->sh.closed) return;
+	c->sh.posted = true;
 	std::string const keep = c->err;
 	(void) shard_status(c, (uint32_t) code);
 	c->err = keep;
@@ -1287,6 +1406,7 @@ int shard_gather_u32(fseq_ctx *c, uint32_t *d_array, uint64_t total, uint64_t lo
 struct SpecPlan {
 	std::vector<uint32_t> r0;                // nchunks + 1 entries
 	uint32_t mine_lo = 0, mine_hi = 0;       // my chunks
+	std::vector<uint32_t> rank_lo;           // sharded: rank g runs the chunks [rank_lo[g], rank_lo[g + 1]) (active + 1 entries)
 	uint32_t nchunks() const { return r0.empty() ? 0u : (uint32_t) r0.size() - 1u; }
 };
 
@@ -1336,10 +1456,12 @@ SpecPlan spec_plan(fseq_ctx *c, DpSchedule const &S)
 		}
 		if (r_hi < prev) r_hi = prev;
 		if (g == sh.rank) P.mine_lo = (uint32_t) P.r0.size();
+		P.rank_lo.push_back((uint32_t) P.r0.size());
 		cut(prev, r_hi);
 		if (g == sh.rank) P.mine_hi = (uint32_t) P.r0.size();
 		prev = r_hi;
 	}
+	P.rank_lo.push_back((uint32_t) P.r0.size());
 	P.r0.push_back(S.nreg);
 	if (sh.rank >= sh.active) P.mine_lo = P.mine_hi = P.nchunks();
 	return P;
@@ -1353,7 +1475,7 @@ int dp_spec_reset(fseq_ctx *c, SpecPlan const &P, hipStream_t s)
 	int rc;
 	if (c->spec_cap < nch)
 	{
-		if ((rc = dev_alloc(c, &c->d_spec, (size_t) 6 * nch + 16))) return rc;
+		if ((rc = dev_alloc(c, &c->d_spec, (size_t) 7 * nch + 16))) return rc;
 		c->spec_cap = nch;
 	}
 	if (c->chunk_cap < nch + 1u)
@@ -1364,7 +1486,7 @@ int dp_spec_reset(fseq_ctx *c, SpecPlan const &P, hipStream_t s)
 	HIP_TRY(c, hipMemcpyAsync(c->d_chunk_r0, P.r0.data(), (size_t) (nch + 1u) * 4, hipMemcpyHostToDevice, s));
 	HIP_TRY(c, hipMemsetAsync(c->dp.M, 0, c->dp_size * 4, s));
 	HIP_TRY(c, hipMemsetAsync(c->d_Mprev, 0, c->dp_size * 4, s));
-	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 6 * nch + 16) * 4, s));
+	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0, ((size_t) 7 * nch + 16) * 4, s));
 	HIP_TRY(c, hipMemsetAsync(c->d_spec, 0x01, (size_t) nch * 4, s));         // d_active != 0: every chunk runs in sweep 1
 	if (c->sh.on)
 	{
@@ -1374,6 +1496,8 @@ int dp_spec_reset(fseq_ctx *c, SpecPlan const &P, hipStream_t s)
 	}
 	return FSEQ_OK;
 }
+
+uint32_t Wx_for_debug(fseq_ctx const *c, uint32_t L) { return c->tune.shard_dp_window ? (uint32_t) c->tune.shard_dp_window : std::max<uint32_t>(2u * DPW, 16u * L); }
 
 // Phase D as chunk-speculative sweeps on the whole chip (fseq_dpspec.hpp).  Leaves M / LB / SZ exactly as
 // k_dp<DP_WHOLE> would (on every rank of a sharded run); *overflow = some cell's list was too short.
@@ -1388,7 +1512,7 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	if (!reset_done && (rc = dp_spec_reset(c, P, st))) return rc;
 	uint32_t *d_active = c->d_spec, *d_changed = d_active + nch, *d_tailmin = d_changed + nch, *d_floor = d_tailmin + nch,
 	         *d_lift = d_floor + nch, *d_ovf = d_lift + nch;
-	SpecCtl *d_ctl = reinterpret_cast<SpecCtl *>(d_ovf + nch);
+	SpecCtl *d_ctl = reinterpret_cast<SpecCtl *>(d_ovf + 2 * (size_t) nch);      // (ovf: {list too short, lowest entry read} per chunk)
 	SpecGeom G;
 	G.chunk_r0 = c->d_chunk_r0;
 	G.RL = S.RL;
@@ -1424,6 +1548,47 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	uint32_t max_sweeps = 12;
 	if (c->tune.dp_spec_max_sweeps) max_sweeps = (uint32_t) c->tune.dp_spec_max_sweeps;
 	SpecCtl h{};
+	// "list too short" of my chunks lo .. hi - 1 (ovf words are {flag, lowest entry read} pairs)
+	auto own_overflow = [&](std::vector<uint32_t> const &ovf2, uint32_t lo, uint32_t hi) {
+		uint32_t o = 0;
+		for (uint32_t k = lo; k < hi; ++k) o |= ovf2[2 * (size_t) k] ? 1u : 0u;
+		return o;
+	};
+	// ---- sharded: who owns which entries, and whether a rank keeps windows or whole arrays
+	c->dp_window_mode = false;
+	c->dp_exchange_words = 0;
+	std::vector<uint32_t> win_lo, win_off;                    // window in front of rank g: entries [win_lo[g], own_lo[g]) at xbuf + win_off[g]
+	uint64_t win_total = 0;
+	if (sharded)
+	{
+		Shard const &sh = c->sh;
+		c->own_lo.assign(sh.world, 0); c->own_hi.assign(sh.world, 0);
+		for (uint32_t g = 0; g < sh.active; ++g)
+		{
+			uint32_t const c_lo = P.rank_lo[g], c_hi = P.rank_lo[g + 1];
+			c->own_lo[g] = P.r0[c_lo] * S.RL;
+			c->own_hi[g] = c_hi == nch ? G.NR : P.r0[c_hi] * S.RL;
+			if (c_hi <= c_lo) c->own_hi[g] = c->own_lo[g];
+		}
+		// A chunk reads entries in front of it through its LDS ring (the DPW entries in front of its first cell) and, rarely,
+		// straight from memory: both stay within a few thousand entries on every input measured (the candidates of a cell end
+		// where the cumulative count of its list passes the cell's value).  So a rank keeps, of the other ranks' keys, a WINDOW
+		// in front of its own entries, the sweeps report the lowest entry they read (k_dp: ovf words), and a sweep that looked
+		// below the window makes the run start again with whole-array exchanges (exactness never rests on the window).
+		uint32_t Wx = std::max<uint32_t>(2u * DPW, 16u * L);
+		if (c->tune.shard_dp_window) Wx = (uint32_t) c->tune.shard_dp_window;
+		win_lo.assign(sh.world, 0); win_off.assign(sh.world, 0);
+		uint64_t off = 2ull * nch + 2;                          // [changed nch][tailmin nch][below][pad]
+		for (uint32_t g = 1; g < sh.active; ++g)
+		{
+			uint32_t const th = c->own_lo[g];
+			win_lo[g] = th > Wx ? ((th - Wx) & ~63u) : 0u;       // (whole 64-blocks: the block minima of the window are then right too)
+			win_off[g] = (uint32_t) off;
+			off += th - win_lo[g];
+		}
+		win_total = off;
+		c->dp_window_mode = !c->tune.shard_dp_full && !c->shard_dp_full_sticky && 2 * win_total < c->dp_size && win_total + 1 <= c->sh.xwords;
+	}
 	sweep(true);
 	uint32_t done_sweeps = 1;
 	std::vector<uint32_t> ovf_early;
@@ -1443,16 +1608,16 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 				++done_sweeps;
 			}
 			compare(done_sweeps == 1);
-			if ((rc = pin_reserve(c, sizeof(h) + (size_t) nch * 4 + 64))) return rc;
+			if ((rc = pin_reserve(c, sizeof(h) + (size_t) nch * 8 + 64))) return rc;
 			auto *const hpin = pin_take<std::remove_reference_t<decltype(h)>>(c, 1);
-			uint32_t *const opin = pin_take<uint32_t>(c, nch);
+			uint32_t *const opin = pin_take<uint32_t>(c, 2 * (size_t) nch);
 			HIP_TRY(c, hipMemcpyAsync(hpin, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
 			// (the chunks' "list too short" words in the same round trip: final if the iteration has converged)
-			HIP_TRY(c, hipMemcpyAsync(opin, d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipMemcpyAsync(opin, d_ovf, (size_t) nch * 8, hipMemcpyDeviceToHost, st));
 			HIP_TRY(c, hipStreamSynchronize(st));
 			HIP_TRY(c, hipGetLastError());
 			h = *hpin;
-			ovf_early.assign(opin, opin + nch);
+			ovf_early.assign(opin, opin + 2 * (size_t) nch);
 			if (h.done || done_sweeps >= max_sweeps) break;
 			// the compare just queued has already chosen the next sweep's active set and lifts
 			rebuild();
@@ -1461,18 +1626,66 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 			batch = 1;
 		}
 	}
-	else
+	else if (!c->dp_window_mode)
 	{
-		// sharded: after every sweep the ranks exchange the keys of their chunks; compare / lift / rebuild then run
+		// sharded, whole arrays: after every sweep the ranks exchange the keys of their chunks; compare / lift / rebuild then run
 		// on the whole arrays on every rank (same inputs, same results), the next sweep again on the rank's own chunks
 		while (true)
 		{
 			if ((rc = shard_gather_u32(c, c->dp.M, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+			c->dp_exchange_words += c->dp_size;
 			compare(done_sweeps == 1);
 			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
 			HIP_TRY(c, hipStreamSynchronize(st));
 			HIP_TRY(c, hipGetLastError());
 			if (h.done) break;                   // no serial fallback here: after sweep k the chunks 0..k-1 are exact, so this ends
+			if (done_sweeps > nch + 2u) return fail(c, FSEQ_E_HIP, "internal: speculative DP did not converge");
+			rebuild();
+			sweep(false);
+			++done_sweeps;
+		}
+	}
+	else
+	{
+		// sharded, windows: after every sweep ONE exchange carries what the others need of a rank -- "changed" and the tail
+		// minimum of each of its chunks (the lifts follow from those on every rank alike), whether one of its chunks read
+		// below its window, and the keys in the window in front of every other rank's entries (a rank contributes the part
+		// of each window it owns).  compare (of its own chunks) / decide / lift / rebuild run on every rank; what a rank holds
+		// outside its entries and its window is never read.
+		Shard const &sh = c->sh;
+		uint32_t *const xb = sh.xbuf;
+		uint32_t const my_valid_lo = sh.rank < sh.active ? win_lo[sh.rank] : 0u;
+		while (true)
+		{
+			HIP_TRY(c, hipMemsetAsync(xb, 0, (size_t) win_total * 4, st));
+			if (mine)
+				hipLaunchKernelGGL(k_spec_scan, dim3(mine), dim3(256), 0, st, c->dp.M, c->d_Mprev, G, d_active, xb, xb + nch, d_ctl,
+				                   P.mine_lo, (uint32_t const *) d_ovf, my_valid_lo, xb + 2 * (size_t) nch);
+			for (uint32_t g = 1; mine && g < sh.active; ++g)
+			{
+				uint64_t const a = std::max<uint64_t>(win_lo[g], t_lo), b = std::min<uint64_t>(c->own_lo[g], t_hi);
+				if (b > a) HIP_TRY(c, hipMemcpyAsync(xb + win_off[g] + (a - win_lo[g]), c->dp.M + a, (b - a) * 4, hipMemcpyDeviceToDevice, st));
+			}
+			if ((rc = shard_exchange(c, win_total, 0))) return rc;
+			c->dp_exchange_words += win_total;
+			HIP_TRY(c, hipMemcpyAsync(d_changed, xb, (size_t) 2 * nch * 4, hipMemcpyDeviceToDevice, st));      // changed | tailmin are adjacent
+			if (sh.rank >= 1 && sh.rank < sh.active && c->own_lo[sh.rank] > win_lo[sh.rank])
+				HIP_TRY(c, hipMemcpyAsync(c->dp.M + win_lo[sh.rank], xb + win_off[sh.rank], (size_t) (c->own_lo[sh.rank] - win_lo[sh.rank]) * 4, hipMemcpyDeviceToDevice, st));
+			hipLaunchKernelGGL(k_spec_decide, dim3(1), dim3(64), 0, st, nch, done_sweeps == 1 ? 1u : 0u, d_changed, d_tailmin, d_floor, d_lift, d_active, d_ovf, d_ctl);
+			uint32_t below = 0;
+			HIP_TRY(c, hipMemcpyAsync(&h, d_ctl, sizeof(h), hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipMemcpyAsync(&below, xb + 2 * (size_t) nch, 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipStreamSynchronize(st));
+			HIP_TRY(c, hipGetLastError());
+			if (below)
+			{
+				// some rank's sweep read a key it does not hold: nothing of this run is trusted; whole arrays from here on
+				// (every rank sees the same word, so every rank takes this way)
+				if (c->tune.debug) fprintf(stderr, "[fseq] sharded DP: a sweep read below its window (%u entries): again with whole-array exchanges\n", Wx_for_debug(c, L));
+				c->shard_dp_full_sticky = true;
+				return run_dp_spec(c, S, P, st, overflow, sweeps_out, false);
+			}
+			if (h.done) break;
 			if (done_sweeps > nch + 2u) return fail(c, FSEQ_E_HIP, "internal: speculative DP did not converge");
 			rebuild();
 			sweep(false);
@@ -1489,36 +1702,36 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 		hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, n, L,
 		                   c->d_flags, r0, S.nrounds, DpSpecArgs{});
 		// overflow: the serial part reports through d_flags, the frozen chunks through their own words
-		std::vector<uint32_t> ovf(nch);
+		std::vector<uint32_t> ovf(2 * (size_t) nch);
 		uint32_t fl[4] = {0, 0, 0, 0};
-		HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 8, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipMemcpyAsync(fl, c->d_flags, 16, hipMemcpyDeviceToHost, st));
 		HIP_TRY(c, hipStreamSynchronize(st));
 		HIP_TRY(c, hipGetLastError());
-		uint32_t o = fl[0] & 1u;
-		for (uint32_t k = P.mine_lo; k < P.mine_hi && k <= h.first_changed; ++k) o |= ovf[k] ? 1u : 0u;
-		*overflow = o;
+		*overflow = (fl[0] & 1u) | own_overflow(ovf, P.mine_lo, std::min(P.mine_hi, h.first_changed + 1u));
 		if (c->tune.debug) fprintf(stderr, "[fseq] speculative DP: not converged after %u sweeps, serial from round %u\n", done_sweeps, r0);
 	}
 	else
 	{
 		// the chunks' "list too short" words are written by their owners only
-		std::vector<uint32_t> ovf(nch);
-		if (ovf_early.size() == nch) ovf = ovf_early;           // (read together with the control word that said "done")
+		std::vector<uint32_t> ovf(2 * (size_t) nch);
+		if (ovf_early.size() == 2 * (size_t) nch) ovf = ovf_early;           // (read together with the control word that said "done")
 		else
 		{
-			HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 4, hipMemcpyDeviceToHost, st));
+			HIP_TRY(c, hipMemcpyAsync(ovf.data(), d_ovf, (size_t) nch * 8, hipMemcpyDeviceToHost, st));
 			HIP_TRY(c, hipStreamSynchronize(st));
 		}
-		uint32_t o = 0;
-		for (uint32_t k = P.mine_lo; k < P.mine_hi; ++k) o |= ovf[k] ? 1u : 0u;
-		*overflow = o;
+		*overflow = own_overflow(ovf, P.mine_lo, P.mine_hi);
 	}
 	if (sharded)
 	{
-		// lb and size of every entry from the rank that computed it (frozen chunks: from the sweep that last ran them)
-		if ((rc = shard_gather_u32(c, c->dp.LB, c->dp_size, t_lo, t_hi, t_extra))) return rc;
-		if ((rc = shard_gather_u32(c, c->dp.SZ, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+		if (!c->dp_window_mode)
+		{
+			// lb and size of every entry from the rank that computed it (frozen chunks: from the sweep that last ran them)
+			if ((rc = shard_gather_u32(c, c->dp.LB, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+			if ((rc = shard_gather_u32(c, c->dp.SZ, c->dp_size, t_lo, t_hi, t_extra))) return rc;
+			c->dp_exchange_words += 2 * c->dp_size;
+		}
 		uint32_t o = *overflow;
 		HIP_TRY(c, hipMemcpyAsync(c->sh.xbuf, &o, 4, hipMemcpyHostToDevice, st));
 		if ((rc = shard_exchange(c, 1, 1))) return rc;
@@ -1527,7 +1740,8 @@ int run_dp_spec(fseq_ctx *c, DpSchedule const &S, SpecPlan const &P, hipStream_t
 	}
 	if (sweeps_out) *sweeps_out = h.done ? h.sweeps : done_sweeps + 1000u;
 	if (c->tune.debug)
-		fprintf(stderr, "[fseq] speculative DP: %u chunks (mine %u..%u), %u sweeps compared, done=%u\n", nch, P.mine_lo, P.mine_hi, h.sweeps, h.done);
+		fprintf(stderr, "[fseq] speculative DP: %u chunks (mine %u..%u), %u sweeps compared, done=%u%s, %.2f MB exchanged by the sweeps\n", nch, P.mine_lo, P.mine_hi, h.sweeps, h.done,
+		        sharded ? (c->dp_window_mode ? ", windows" : ", whole arrays") : "", c->dp_exchange_words * 4 / 1e6);
 	return FSEQ_OK;
 }
 
@@ -1935,15 +2149,15 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		{
 			uint32_t pack_abits = 0;
 			if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
-			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
-			c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
+			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws_c, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
+			c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
 			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 		}
 		else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !c->tune.stream_plain_scan)
-			hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+			hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) c->stream_staged,
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 		else if (c->use_stream)
-			hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged,
+			hipLaunchKernelGGL(k_columns_stream<0>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) c->stream_staged,
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 		else
 			ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
@@ -2225,6 +2439,7 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 			HIP_TRY(c, hipMemcpy(all.data(), sh.xbuf, all.size() * 4, hipMemcpyDeviceToHost));
 			pass2_cells = 0;
 			for (uint32_t g = 0; g < sh.world; ++g) pass2_cells += (uint64_t) all[2 * g] | ((uint64_t) all[2 * g + 1] << 32);
+			c->sh.closed = true;                                 // the last exchange of the run
 		}
 	}
 
@@ -2304,6 +2519,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 	{
 		c->ws_words = (size_t) 4 * m;
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
+		c->d_ws_c = c->d_ws;
 	}
 	// one block [0, n): ranked in key space (fseq_blockkeys.hpp); FSEQ_PHASE_A_CLASSIC: the per-column sweep
 	if (c->bk_cap_words && !c->tune.phase_a_classic)
@@ -2544,7 +2760,7 @@ uint64_t fseq_shard_xbuf_words(fseq_ctx const *c, uint32_t world)
 	// phase B (world x (2m + 1) words), the merge thresholds (2 words per traceback boundary <= n / L + 1)
 	uint64_t const dp = c->p.n >= c->p.segment_length ? c->p.n - c->p.segment_length + 1 : 1;
 	uint64_t const keys = (uint64_t) world * (2ull * c->p.m + 1);
-	uint64_t const tb = 2 * (c->p.n / std::max<uint64_t>(1, c->p.segment_length) + 2);
+	uint64_t const tb = 4 * (c->p.n / std::max<uint64_t>(1, c->p.segment_length) + 2) + 2;     // the gathered traceback entries (16 bytes each)
 	return std::max<uint64_t>(std::max(std::max(dp, tb), keys), 1024) + 64;
 }
 
@@ -2581,6 +2797,15 @@ int fseq_set_shard(fseq_ctx *c, uint32_t rank, uint32_t world, void *xbuf_device
 	return FSEQ_OK;
 }
 
+int fseq_shard_abort(fseq_ctx *c, int code)
+{
+	if (!c) return FSEQ_E_ARG;
+	if (!c->sh.on) return FSEQ_OK;
+	(void) hipSetDevice(c->p.device);
+	shard_post_failure(c, code ? code : FSEQ_E_HIP);
+	return FSEQ_OK;
+}
+
 int fseq_shard_columns(fseq_ctx const *c, uint64_t *first, uint64_t *last)
 {
 	if (!c || !first || !last) return FSEQ_E_ARG;
@@ -2603,7 +2828,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	uint32_t const sigma = spec->kind ? 16u : 4u;
 	c->sigma = sigma;
 	int rc = alloc_msa(c);
-	if (rc) return rc;
+	if (rc) { shard_post_failure(c, rc); return rc; }
 	SynthArgs A;
 	A.seed = spec->seed; A.n_founders = spec->n_founders; A.block_len = spec->block_len;
 	A.mut_threshold = spec->mut_threshold; A.kind = spec->kind; A.sigma = sigma;
@@ -2651,6 +2876,7 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 	if (!c->have_input) return fail(c, FSEQ_E_ARG, "no input set");
 	(void) hipSetDevice(c->p.device);
 	c->have_result = false;
+	c->sh.closed = false;
 	if (!c->kernels_ready)
 	{
 		int rc = prepare_geometry(c);
@@ -2672,8 +2898,16 @@ int fseq_run_segmentation(fseq_ctx *c, fseq_result *res)
 int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
 {
 	if (!c || !name) return FSEQ_E_ARG;
+	// sharded: the input was laid out for the block partition of the knobs in force when it was set, and every rank must
+	// plan the same partition -- the knobs of a sharded run are set (identically on every rank) before the input
+	if (c->sh.on && c->have_input) return fail(c, FSEQ_E_ARG, "sharded run: set tuning knobs before the input is set (identically on every rank)");
 	if (!c->tune.set(name, value)) return fail(c, FSEQ_E_ARG, "unknown tuning knob");
-	c->kernels_ready = false;                    // (the geometry and the kernel choice may depend on it)
+	// (the geometry and the kernel choice may depend on it: the work buffers of an earlier run were sized for the old one)
+	(void) hipSetDevice(c->p.device);
+	if (c->stream) (void) hipStreamSynchronize(c->stream);
+	free_work(c);
+	c->have_result = false;
+	c->kernels_ready = false;
 	return FSEQ_OK;
 }
 
@@ -2759,9 +2993,30 @@ int fseq_debug_dp(fseq_ctx *c, uint32_t *lb, uint32_t *max_size, uint32_t *size)
 	return FSEQ_OK;
 }
 
+int fseq_debug_dp_owned(fseq_ctx *c, uint64_t *first, uint64_t *last, int *final_cell, int *whole_arrays)
+{
+	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	uint64_t lo = 0, hi = c->dp_size;
+	int fin = 1, whole = 1;
+	if (c->sh.on)
+	{
+		Shard const &sh = c->sh;
+		bool const have = sh.rank < sh.active && sh.rank < c->own_lo.size();
+		lo = have ? c->own_lo[sh.rank] : 0; hi = have ? c->own_hi[sh.rank] : 0;
+		fin = have && sh.rank + 1u == sh.active ? 1 : 0;
+		whole = c->dp_window_mode ? 0 : 1;
+	}
+	if (first) *first = lo;
+	if (last) *last = hi;
+	if (final_cell) *final_cell = fin;
+	if (whole_arrays) *whole_arrays = whole;
+	return FSEQ_OK;
+}
+
 int fseq_debug_block_state(fseq_ctx *c, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out)
 {
 	if (!c || !c->have_result || c->res.short_path || block_idx > c->nblocks) return FSEQ_E_ARG;
+	if (c->sh.on && (block_idx < c->sh.b_lo || block_idx > c->sh.b_hi)) return fail(c, FSEQ_E_ARG, "block state held by another rank");
 	(void) hipSetDevice(c->p.device);
 	size_t const m = c->p.m;
 	if (a_out) HIP_TRY(c, hipMemcpy(a_out, c->d_bstate_a + block_idx * m, m * 4, hipMemcpyDeviceToHost));
@@ -2798,24 +3053,30 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 	size_t const m = c->p.m, S = c->segments.size();
 	double const t0 = now_ms();
 	uint32_t const X = c->res.max_segment_size;
-	if (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !c->tune.join_host)
+	// class tables and co-occurrence edges where the boundary states are (fseq_joinprep.hpp); the host hands out
+	// the copies and draws the edges (the serial part of greedy_matcher.cc).  Falls through to the all-host joiner
+	// below when the edge array cannot be allocated or the tables come back implausible.
+	while (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !c->tune.join_host)
 	{
-		// class tables and co-occurrence edges where the boundary states are (fseq_joinprep.hpp); the host hands out
-		// the copies and draws the edges (the serial part of greedy_matcher.cc)
 		hipStream_t st = c->stream;
 		uint16_t *d_of = nullptr;
 		uint32_t *d_rep = nullptr, *d_size = nullptr, *d_count = nullptr, *d_off = nullptr, *d_ne = nullptr;
 		uint64_t *d_rb = nullptr;
 		uint2 *d_edges = nullptr;
 		unsigned long long *d_cursor = nullptr;
-		uint64_t const cap_total = (uint64_t) (S > 1 ? S - 1 : 0) * std::min<uint64_t>(m, (uint64_t) X * X) + 1;
+		// (offsets into the edge array are 32-bit words on the way to the host: the capacity stays below 2^32)
+		uint64_t const cap_total = std::min<uint64_t>((uint64_t) (S > 1 ? S - 1 : 0) * std::min<uint64_t>(m, (uint64_t) X * X) + 1, 0xFFFFFFFFull);
 		int rc;
 		auto cleanup = [&]() { dev_free(c, &d_of); dev_free(c, &d_rep); dev_free(c, &d_size); dev_free(c, &d_count); dev_free(c, &d_off); dev_free(c, &d_ne);
 		                       dev_free(c, &d_rb); dev_free(c, &d_edges); dev_free(c, &d_cursor); };
 		if ((rc = dev_alloc(c, &d_of, S * m)) || (rc = dev_alloc(c, &d_rep, S * X)) || (rc = dev_alloc(c, &d_size, S * X)) || (rc = dev_alloc(c, &d_count, S)) ||
 		    (rc = dev_alloc(c, &d_off, S)) || (rc = dev_alloc(c, &d_ne, S)) || (rc = dev_alloc(c, &d_rb, S)) || (rc = dev_alloc(c, &d_edges, cap_total)) ||
 		    (rc = dev_alloc(c, &d_cursor, 1)))
-		{ cleanup(); return rc; }
+		{
+			cleanup();
+			if (rc == FSEQ_E_OOM) { c->err.clear(); break; }       // no room for the device front: the host joiner needs none
+			return rc;
+		}
 		std::vector<uint64_t> rbs(S);
 		for (size_t i = 0; i < S; ++i) rbs[i] = c->segments[i].rb;
 		hipError_t e = hipMemcpyAsync(d_rb, rbs.data(), S * 8, hipMemcpyHostToDevice, st);
@@ -2826,7 +3087,7 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "join preparation", e); }
 		hipLaunchKernelGGL(k_join_classes, dim3((uint32_t) S), dim3(JP_T), 0, st, c->d_snap_a, c->d_snap_d, d_rb, (uint32_t) m, X, d_of, d_rep, d_size, d_count);
 		if (S > 1)
-			hipLaunchKernelGGL(k_join_edges, dim3((uint32_t) (S - 1)), dim3(JP_T), lds, st, d_of, d_count, (uint32_t) m, d_edges, cap_total, d_off, d_ne, d_cursor);
+			hipLaunchKernelGGL(k_join_edges, dim3((uint32_t) (S - 1)), dim3(JP_T), lds, st, d_of, d_count, (uint32_t) m, X, d_edges, cap_total, d_off, d_ne, d_cursor);
 		std::vector<uint32_t> count(S), rep(S * X), size(S * X), off(S), ne(S);
 		unsigned long long total = 0;
 		e = hipMemcpyAsync(count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st);
@@ -2837,13 +3098,13 @@ int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
 		if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, 8, hipMemcpyDeviceToHost, st);
 		if (e == hipSuccess) e = hipStreamSynchronize(st);
 		if (e == hipSuccess) e = hipGetLastError();
-		std::vector<uint32_t> edge_words(2 * (size_t) total + 2);
-		bool sane = e == hipSuccess && total < cap_total;
+		bool sane = e == hipSuccess && total < cap_total && total <= 0xFFFFFFFFull;
 		for (size_t i = 0; sane && i < S; ++i) sane = count[i] >= 1 && count[i] <= X;
+		std::vector<uint32_t> edge_words(sane ? 2 * (size_t) total + 2 : 2);
 		if (sane && total) e = hipMemcpy(edge_words.data(), d_edges, (size_t) total * 8, hipMemcpyDeviceToHost);
 		cleanup();
 		if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "join preparation", e);
-		if (!sane) return fail(c, FSEQ_E_HIP, "internal: join preparation produced class tables that do not fit max_segment_size");
+		if (!sane) break;                                         // (the host joiner builds its own tables from the boundary states)
 		double const t1 = now_ms();
 		JoinProfile prof;
 		greedy_match_prepared(c->p.m, X, S, count.data(), rep.data(), size.data(), edge_words.data(), off.data(), ne.data(), permutations, &prof);

@@ -721,6 +721,9 @@ __device__ __forceinline__ uint32_t bk_pair_leaf(BkState<IdT, PrefT> &S, uint32_
 		bk_words8(cl_, lo);
 		bk_words8(ch_, hi);
 	};
+	// (the two leaf maps and their prefix counts take 2 LW words: a bitmap smaller than that -- FSEQ_BLOCKKEYS_CAP in the tests --
+	// has no room for pass 1, so the capacity is tested before anything is written)
+	if (S.cap_words < 2u * LW + 64u) return BK_PAIR_NO;
 	// ---- pass 1
 	for (uint32_t q = tid; q < nq; q += T)
 	{
@@ -740,7 +743,7 @@ __device__ __forceinline__ uint32_t bk_pair_leaf(BkState<IdT, PrefT> &S, uint32_
 	uint32_t const both = bk_prefix_words<T, PrefT>(bmA, S.pref, 2u * LW, S.sscr);
 	uint32_t const Dlo = (uint32_t) S.pref[LW], Dhi = both - Dlo;
 	uint32_t const W = (uint32_t) (((uint64_t) Dlo * Dhi + 31u) >> 5);
-	if ((uint64_t) Dlo * Dhi > (uint64_t) (S.cap_words - 2u * LW) * 32u || S.cap_words < 2u * LW + 64u)
+	if ((uint64_t) Dlo * Dhi > (uint64_t) (S.cap_words - 2u * LW) * 32u)
 	{
 		for (uint32_t w = tid; w < 2u * LW; w += T) bmA[w] = 0u;
 		__syncthreads();

@@ -185,7 +185,7 @@ struct CellState {
 // range needs the next entry's value).  Returns true when the cell is decided (pruned).
 __device__ __forceinline__ bool dp_strip(
 	DpArrays const &A, DpLds const &D, DpView const &V, uint2 en_in, uint32_t vnext_in, uint32_t nent, uint32_t s0,
-	uint32_t ncand, uint32_t L, uint32_t end, CellState &st)
+	uint32_t ncand, uint32_t L, uint32_t end, CellState &st, uint32_t &reach)
 {
 	uint32_t const lane = lane_id();
 	uint32_t const i = s0 + lane;
@@ -208,6 +208,7 @@ __device__ __forceinline__ bool dp_strip(
 	uint32_t const qb = lo - L, qe = c - L;
 	bool const open_lhs = ok && qb < V.fresh_lo;             // range reaches in front of a speculative chunk: a key 0 is in it
 	bool const okq = ok && !open_lhs;
+	reach = min(reach, okq ? qb : 0xFFFFFFFFu);               // the lowest entry any query of this lane has read (k_dp, sharded sweeps)
 	if (__ballot(okq && qb < V.safe_lo) == 0)
 	{
 		// every candidate of the strip lies inside the LDS ring
@@ -247,18 +248,18 @@ __device__ __forceinline__ bool dp_strip(
 // too short to prove the result.
 __device__ __forceinline__ CellState dp_cell_sequential(
 	DpArrays const &A, DpLds const &D, DpView const &V, uint2 const *__restrict__ list, uint2 en0, uint32_t vnext0,
-	uint4 const h, uint32_t m, uint32_t L, uint32_t end, uint32_t *flags)
+	uint4 const h, uint32_t m, uint32_t L, uint32_t end, uint32_t *flags, uint32_t &reach)
 {
 	uint32_t const lane = lane_id();
 	CellState st;
 	st.best_v = 0xFFFFFFFFu; st.best_lb = 0; st.best_sz = 0; st.cum_base = 0;
 	uint32_t const nent = h.x;
-	bool done = dp_strip(A, D, V, en0, vnext0, nent, 0, 63, L, end, st);
+	bool done = dp_strip(A, D, V, en0, vnext0, nent, 0, 63, L, end, st, reach);
 	for (uint32_t s0 = 63; !done && s0 < nent; s0 += 64)     // continue from HBM (rare; only this wave waits)
 	{
 		uint2 const e2 = list[s0 + lane];
 		uint32_t const v2 = list[s0 + lane + 1u].x;
-		done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st);
+		done = dp_strip(A, D, V, e2, v2, nent, s0, 64, L, end, st, reach);
 	}
 	uint32_t const cnt0 = h.y, complete = h.z;
 	bool const stopped = st.best_v != 0xFFFFFFFFu && st.cum_base > st.best_v;
@@ -307,7 +308,7 @@ __device__ __forceinline__ uint32_t half_min_u32(uint32_t v)
 // bit 32); the caller runs the general path for it.
 __device__ __forceinline__ uint64_t dp_cell_pair(
 	DpArrays const &A, DpLds const &D, DpView const &V, uint32_t slot, uint32_t i0, DpRound const &R,
-	uint32_t m, uint32_t L, uint32_t *flags)
+	uint32_t m, uint32_t L, uint32_t *flags, uint32_t &reach)
 {
 	uint32_t const lane = lane_id(), half = lane >> 5, sub = lane & 31u;
 	bool const has = i0 + half < R.len;
@@ -335,6 +336,7 @@ __device__ __forceinline__ uint64_t dp_cell_pair(
 	uint32_t const qb = lo - L, qe = c - L;
 	bool const open_lhs = ok && qb < V.fresh_lo;             // see dp_strip
 	bool const okq = ok && !open_lhs;
+	reach = min(reach, okq ? qb : 0xFFFFFFFFu);
 	if (__ballot(okq && qb < V.safe_lo) == 0)
 	{
 		if (okq)
@@ -666,7 +668,7 @@ struct DpSpecArgs {
 	uint32_t chunk0;                      // workgroup i of the launch runs chunk chunk0 + i (a rank of a sharded run owns a chunk range)
 	uint32_t fresh;                       // first sweep: nothing is known in front of a chunk (keys there count as 0)
 	uint32_t const *active;               // [nchunks] chunks to run in this sweep
-	uint32_t *ovf;                        // [nchunks] "list too short" flag of the sweep that last ran the chunk
+	uint32_t *ovf;                        // [nchunks][2] {"list too short" flag, lowest entry read} of the sweep that last ran the chunk
 	uint32_t const *ctl;                  // ctl[0] != 0: the iteration has converged, nothing to do
 };
 
@@ -685,7 +687,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 	if (MODE == DP_SPEC)
 	{
 		if (SP.ctl[0] != 0u || SP.active[blockIdx.x + SP.chunk0] == 0u) return;
-		flags = SP.ovf + blockIdx.x + SP.chunk0;
+		flags = SP.ovf + 2u * (blockIdx.x + SP.chunk0);           // {list too short, lowest entry a query of the chunk read}
 	}
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	lds_char *const lds0 = (lds_char *) smem;
@@ -801,7 +803,10 @@ __global__ __launch_bounds__(1024) void k_dp(
 		}
 	};
 
-	if (MODE == DP_SPEC && threadIdx.x == 0) *flags = 0u;
+	if (MODE == DP_SPEC && threadIdx.x == 0) { flags[0] = 0u; flags[1] = 0xFFFFFFFFu; }
+	// lowest DP entry a query of this lane reads: a rank of a sharded run holds the entries of the other ranks only for a
+	// window in front of its own (fseq_api.hip, run_dp_spec) and must know when a sweep looked below it
+	uint32_t reach = 0xFFFFFFFFu;
 	if (PARTIAL && r_begin > 0u && !fresh)
 	{
 		// resume: entries < T0 are computed, indexed and in HBM
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 					lds_u32 const *ls = D.LS + (slot * DP_RL + i) * 128u;
 					uint2 const en = make_uint2(ls[2u * lane], ls[2u * lane + 1u]);
 					uint32_t const vnext = ls[2u * ((lane + 1u) & 63u)];
-					st = dp_cell_sequential(A, D, V, ent + (size_t) (end - 1u) * stride, en, vnext, h, m, L, end, flags);
+					st = dp_cell_sequential(A, D, V, ent + (size_t) (end - 1u) * stride, en, vnext, h, m, L, end, flags, reach);
 				}
 				if (lane == 0)
 				{
@@ -911,7 +916,7 @@ __global__ __launch_bounds__(1024) void k_dp(
 #pragma nounroll
 				for (uint32_t i0 = 2u * wave; i0 < R.len; i0 += 2u * NWC)
 				{
-					uint64_t const fb = dp_cell_pair(A, D, V, slot, i0, R, m, L, flags);
+					uint64_t const fb = dp_cell_pair(A, D, V, slot, i0, R, m, L, flags, reach);
 					if (fb & 1ull) todo |= 1ull << i0;
 					if (fb >> 32) todo |= 2ull << i0;
 				}
@@ -1029,6 +1034,11 @@ __global__ __launch_bounds__(1024) void k_dp(
 	}
 #endif
 
+	if (MODE == DP_SPEC && wave < NWC)
+	{
+		uint32_t const lo = wave_min_u32(reach);
+		if (lane == 0 && lo != 0xFFFFFFFFu) atomicMin(flags + 1, lo);
+	}
 	// the writer flushes what is still only in LDS
 	if (wave == DP_WRITER)
 	{

@@ -58,12 +58,17 @@ __device__ __forceinline__ uint32_t spec_chunk_of(SpecGeom const &G, uint32_t t)
 }
 
 // A: one workgroup per chunk: did the sweep change a key of the chunk, and the minimum over its tail window
+// (sharded: a rank scans its own chunks chunk0 .. chunk0 + grid - 1 -- changed / tailmin of the others arrive by exchange --
+// and reports in *below whether a query of one of its active chunks read an entry below valid_lo, the start of the
+// window of foreign entries it holds; ovf2 = nullptr: not asked)
 __global__ __launch_bounds__(256) void k_spec_scan(
 	uint32_t const *__restrict__ M, uint32_t const *__restrict__ Mprev, SpecGeom const G,
-	uint32_t const *__restrict__ active, uint32_t *__restrict__ changed, uint32_t *__restrict__ tailmin, SpecCtl const *ctl)
+	uint32_t const *__restrict__ active, uint32_t *__restrict__ changed, uint32_t *__restrict__ tailmin, SpecCtl const *ctl,
+	uint32_t chunk0 = 0, uint32_t const *__restrict__ ovf2 = nullptr, uint32_t valid_lo = 0, uint32_t *__restrict__ below = nullptr)
 {
 	if (ctl->done) return;
-	uint32_t const c = blockIdx.x;
+	uint32_t const c = blockIdx.x + chunk0;
+	if (ovf2 && threadIdx.x == 0 && active[c] != 0u && ovf2[2u * c + 1u] < valid_lo) atomicOr(below, 1u);
 	uint32_t const lo = spec_chunk_lo(G, c), hi = spec_chunk_hi(G, c);
 	uint32_t const w0 = (hi - lo > G.win) ? hi - G.win : lo;
 	uint32_t ch = 0, mn = 0xFFFFFFFFu;
@@ -98,7 +103,7 @@ __global__ __launch_bounds__(64) void k_spec_decide(
 		uint32_t const c = c0 + lane;
 		uint64_t const chm = __ballot(c < nchunks && changed[c] != 0u);
 		if (chm && first == 0xFFFFFFFFu) first = c0 + (uint32_t) __builtin_ctzll(chm);
-		any_ovf |= __ballot(c < nchunks && ovf[c] != 0u) ? 1u : 0u;
+		any_ovf |= __ballot(c < nchunks && ovf[2u * c] != 0u) ? 1u : 0u;
 	}
 	if (first_sweep) first = 0;           // sweep 1: chunk 0 is exact, everything behind it is a guess
 	if (first == 0xFFFFFFFFu)

@@ -59,14 +59,15 @@ __global__ __launch_bounds__(JP_T) void k_join_classes(
 
 // pair p = (segment p, segment p + 1): edges[offset[p] .. offset[p] + nedges[p]) = {l << 16 | r, rows}, ascending (l, r)
 __global__ __launch_bounds__(JP_T) void k_join_edges(
-	uint16_t const *__restrict__ of_row, uint32_t const *__restrict__ count, uint32_t m,
+	uint16_t const *__restrict__ of_row, uint32_t const *__restrict__ count, uint32_t m, uint32_t X,
 	uint2 *__restrict__ edges, uint64_t cap_total, uint32_t *__restrict__ offset, uint32_t *__restrict__ nedges, unsigned long long *__restrict__ cursor)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t cooc[];
 	__shared__ uint32_t scratch[JP_T / WAVE + 1];
 	__shared__ unsigned long long s_base;
 	uint32_t const p = blockIdx.x, tid = threadIdx.x;
-	uint32_t const LC = min(count[p], JP_MAX_CLASSES), RC = min(count[p + 1], JP_MAX_CLASSES);
+	// (the LDS matrix holds X x X counters: a class count above X -- which the host rejects afterwards -- must not index past it)
+	uint32_t const LC = min(min(count[p], JP_MAX_CLASSES), X), RC = min(min(count[p + 1], JP_MAX_CLASSES), X);
 	uint32_t const cells = LC * RC;
 	uint16_t const *L = of_row + (size_t) p * m, *R = of_row + (size_t) (p + 1) * m;
 	for (uint32_t i = tid; i < cells; i += JP_T) cooc[i] = 0;

@@ -1073,12 +1073,17 @@ constexpr uint32_t TB_TERM = 0xFFFFFFFFu;
 // writes; they are never on the chain from n - L)
 __device__ __forceinline__ uint32_t tb_next(uint32_t lb, uint32_t t, uint32_t L) { return (lb >= L && lb - L < t) ? lb - L : TB_TERM; }
 
+// (a rank of a sharded run holds valid lb's for the entries [vlo, vhi) it computed: the chain leaves its part at the
+// first entry below vlo, windows outside the part have nothing to do; vlo = 0, vhi = dp_size: the whole array)
 __global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__ LB, uint32_t dp_size, uint32_t L,
-                                                    uint32_t *__restrict__ exit_next, uint32_t *__restrict__ exit_cnt)
+                                                    uint32_t *__restrict__ exit_next, uint32_t *__restrict__ exit_cnt,
+                                                    uint32_t vlo = 0, uint32_t vhi = 0xFFFFFFFFu)
 {
 	__shared__ uint32_t nx[2][TB_WIN];
 	__shared__ uint16_t cn[2][TB_WIN];
-	uint32_t const base = blockIdx.x * TB_WIN;
+	uint32_t const wbase = blockIdx.x * TB_WIN;
+	if (wbase >= vhi || wbase + TB_WIN <= vlo) return;
+	uint32_t const base = wbase;
 	for (uint32_t i = threadIdx.x; i < TB_WIN; i += 256u)
 	{
 		uint32_t const t = base + i;
@@ -1095,7 +1100,7 @@ __global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__
 		{
 			uint32_t j = nx[cur][i];
 			uint32_t c = cn[cur][i];
-			if (j != TB_TERM && j >= base) { c += cn[cur][j - base]; j = nx[cur][j - base]; }
+			if (j != TB_TERM && j >= base && j >= vlo) { c += cn[cur][j - base]; j = nx[cur][j - base]; }
 			nx[cur ^ 1u][i] = j;
 			cn[cur ^ 1u][i] = (uint16_t) c;
 		}
@@ -1123,9 +1128,31 @@ __global__ __launch_bounds__(64) void k_tb_chain(uint32_t const *__restrict__ ex
 	count[0] = off; count[2] = nw;
 }
 
+// The chain of one rank of a sharded run: from entry `start` (inside the rank's part [vlo, ..)) window by window until the
+// chain ends or leaves the part; the rank's output begins at offset off0 of the whole traceback.
+// count[0] = entries of this rank, count[2] = its windows; word[0] = 1 + the entry the chain continues at (0: it ended
+// here), word[1] = entries of this rank -- what the other ranks need to carry on (fseq_api.hip, follow_traceback_sharded)
+__global__ __launch_bounds__(64) void k_tb_chain_part(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t start, uint32_t off0,
+                                                      uint32_t vlo, uint2 *__restrict__ head, uint32_t max_windows, uint32_t *__restrict__ count, uint32_t *__restrict__ word)
+{
+	if (threadIdx.x != 0) return;
+	uint32_t cur = start, off = off0, nw = 0, next = 0;
+	while (nw < max_windows)
+	{
+		head[nw++] = make_uint2(cur, off);
+		off += exit_cnt[cur];
+		uint32_t const e = exit_next[cur];
+		if (e == TB_TERM) break;
+		if (e < vlo) { next = e + 1u; break; }
+		cur = e;
+	}
+	count[0] = off - off0; count[2] = nw;
+	word[0] = next; word[1] = off - off0;
+}
+
 __global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB, uint32_t const *__restrict__ M, uint32_t const *__restrict__ SZ,
                                                  uint32_t dp_size, uint32_t L, uint2 const *__restrict__ head, uint32_t *__restrict__ count,
-                                                 uint4 *__restrict__ out, uint32_t cap)
+                                                 uint4 *__restrict__ out, uint32_t cap, uint32_t vlo = 0)
 {
 	if (blockIdx.x >= count[2]) return;
 	__shared__ uint32_t lbw[TB_WIN];
@@ -1144,7 +1171,7 @@ __global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB
 			++n;
 			uint32_t const nx = tb_next(lb, cur, L);
 			if (nx == TB_TERM) { if (lb == 0u) count[1] = 1u; break; }       // (only the last window of the chain ends like this)
-			if (nx < base) break;
+			if (nx < base || nx < vlo) break;
 			cur = nx;
 		}
 		s_n = n;

@@ -216,9 +216,17 @@ int main(int argc, char **argv)
 		fseq_params pr(p);
 		pr.device = r;
 		int rc_(fseq_create(&pr, &ctxs[r]));
-		if (FSEQ_OK != rc_) return rc_;
-		if (sharded && FSEQ_OK != (rc_ = world.attach(ctxs[r], r))) return rc_;
-		if (FSEQ_OK != (rc_ = fseq_set_rows(ctxs[r], rows.data()))) return rc_;
+		if (FSEQ_OK == rc_ && sharded) rc_ = world.attach(ctxs[r], r);
+		if (sharded)
+		{
+			// Before the first collective the rank threads agree on the host: a rank without a context or an exchange buffer
+			// (no device memory, ...) cannot take part in a status exchange, so everybody leaves here with its code.  From
+			// here on a failing rank posts its code in the exchange the others make next (fseq.h: FSEQ_E_PEER).
+			int const worst(world.agree(rc_));
+			if (FSEQ_OK != worst) return FSEQ_OK != rc_ ? rc_ : FSEQ_E_PEER;
+		}
+		else if (FSEQ_OK != rc_) return rc_;
+		if (FSEQ_OK != (rc_ = fseq_set_rows(ctxs[r], rows.data()))) return rc_;     // (sharded: posts its own failures)
 		return fseq_run_segmentation(ctxs[r], &results[r]);
 	};
 	if (sharded)

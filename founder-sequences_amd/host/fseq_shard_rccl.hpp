@@ -14,8 +14,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -40,6 +42,34 @@ inline int rccl_allreduce(void *user, std::uint64_t off, std::uint64_t count, in
 	return hipSuccess == hipStreamSynchronize(l->stream) ? 0 : 1;
 }
 
+// The ranks are threads of one process, so they can agree on the host before a collective: everybody arrives with a
+// status word and leaves with the largest one.  A rank that failed before the first exchange (no context, no exchange
+// buffer) makes the others return instead of waiting in an all-reduce it will never join.
+class agreement {
+public:
+	explicit agreement(int parties = 1): m_parties(parties) {}
+	void reset(int parties) { m_parties = parties; m_waiting = 0; m_acc = 0; m_result = 0; ++m_generation; }
+	int arrive(int status)
+	{
+		std::unique_lock<std::mutex> lock(m_mutex);
+		if (status > m_acc) m_acc = status;
+		unsigned long const gen(m_generation);
+		if (++m_waiting == m_parties)
+		{
+			m_result = m_acc; m_acc = 0; m_waiting = 0; ++m_generation;
+			m_cv.notify_all();
+			return m_result;
+		}
+		m_cv.wait(lock, [&]() { return gen != m_generation; });
+		return m_result;
+	}
+private:
+	std::mutex m_mutex;
+	std::condition_variable m_cv;
+	int m_parties = 1, m_waiting = 0, m_acc = 0, m_result = 0;
+	unsigned long m_generation = 0;
+};
+
 class rccl_world {
 public:
 	// devices 0 .. world - 1 of this node
@@ -52,6 +82,7 @@ public:
 			return false;
 		}
 		m_links.resize(world);
+		m_agree.reset(world);
 		std::vector<ncclComm_t> comms(world);
 		std::vector<int> devs(world);
 		for (int r = 0; r < world; ++r) devs[r] = r;
@@ -67,6 +98,8 @@ public:
 	}
 
 	int world() const { return (int) m_links.size(); }
+	// every rank thread calls this with its own status (0 = fine); all leave with the largest one
+	int agree(int status) { return m_agree.arrive(status); }
 	shard_link &link(int rank) { return m_links[rank]; }
 
 	// the exchange buffer of a rank, sized for its context (fseq_shard_xbuf_words), and the context made a shard
@@ -92,7 +125,9 @@ public:
 			ths.emplace_back([&, r]() {
 				(void) hipSetDevice(r);
 				std::uint32_t const mine(r + 1);
-				if (hipSuccess != hipMalloc(reinterpret_cast<void **>(&bufs[r]), 4) || hipSuccess != hipMemcpy(bufs[r], &mine, 4, hipMemcpyHostToDevice)) { bad[r] = 1; return; }
+				bool ok(hipSuccess == hipMalloc(reinterpret_cast<void **>(&bufs[r]), 4) && hipSuccess == hipMemcpy(bufs[r], &mine, 4, hipMemcpyHostToDevice));
+				// (a rank that could not set up must not leave the others in the collective: agree on the host first)
+				if (agree(ok ? 0 : 1) != 0) { bad[r] = ok ? 0 : 1; if (bufs[r]) (void) hipFree(bufs[r]); return; }
 				shard_link probe(m_links[r]);
 				probe.xbuf = bufs[r];
 				if (rccl_allreduce(&probe, 0, 1, 0) != 0) { bad[r] = 1; return; }
@@ -102,7 +137,9 @@ public:
 		for (auto &t : ths) t.join();
 		std::uint32_t const want((std::uint32_t) (W * (W + 1) / 2));
 		for (int r = 0; r < W; ++r)
-			if (bad[r] || got[r] != want) { err = "RCCL self-test failed on rank " + std::to_string(r); return false; }
+			if (bad[r]) { err = "RCCL self-test: rank " + std::to_string(r) + " could not set up its buffer"; return false; }
+		for (int r = 0; r < W; ++r)
+			if (got[r] != want) { err = "RCCL self-test failed on rank " + std::to_string(r); return false; }
 		return true;
 	}
 
@@ -132,6 +169,7 @@ public:
 
 private:
 	std::vector<shard_link> m_links;
+	agreement m_agree;
 };
 
 } // namespace fseq_host

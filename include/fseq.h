@@ -24,7 +24,8 @@ extern "C" {
 
 /* 2: fseq_timings grew (dp_chunks .. reserved), FSEQ_E_PEER, fseq_set_memory_budget, fseq_set_progress /
  *    fseq_step_max / fseq_current_step; the fseq_debug_* entry points moved to include/fseq_debug.h */
-#define FSEQ_ABI_VERSION 2
+/* 3: fseq_shard_abort */
+#define FSEQ_ABI_VERSION 3
 
 enum {
 	FSEQ_OK             = 0,
@@ -153,6 +154,12 @@ typedef int (*fseq_allreduce_fn)(void *user, uint64_t offset_words, uint64_t cou
 uint64_t fseq_shard_xbuf_words(fseq_ctx const *ctx, uint32_t world);
 int  fseq_set_shard(fseq_ctx *ctx, uint32_t rank, uint32_t world, void *xbuf_device, uint64_t xbuf_words,
                     fseq_allreduce_fn fn, void *user);
+/* A rank whose HOST failed between two library calls (it could not read its input, allocate a buffer of its own, ...) and
+ * will make no further calls on this context: tells the other ranks, who learn of it in the exchange they make next and
+ * return FSEQ_E_PEER instead of waiting in a collective.  One status exchange, at most once per context; failures inside
+ * the library's own calls (fseq_set_rows, fseq_generate_synthetic, fseq_run_segmentation) are posted by the library
+ * itself.  code: what the others see as this rank's error code (0 = FSEQ_E_HIP).  Nothing to do on unsharded contexts. */
+int  fseq_shard_abort(fseq_ctx *ctx, int code);
 /* columns [*first, *last) this rank holds (its block range plus the few columns of the next rank that its last
  * DP round reads) */
 int  fseq_shard_columns(fseq_ctx const *ctx, uint64_t *first, uint64_t *last);

@@ -15,8 +15,12 @@ extern "C" {
  * to a resumed DP launch while later columns are still being produced). */
 int  fseq_debug_dp_schedule(uint64_t segment_length, uint64_t n, uint64_t col_hi, uint32_t *n_rounds, uint32_t *cells_per_round,
                             uint32_t *rounds_within, int *pipelined);
-/* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L. */
+/* Whole DP array (debug / parity of intermediate state): n - L + 1 entries, rb = index + L.
+ * A rank of a sharded run computes the entries [*first, *last) (and the final cell's, entry n - L, when *final_cell);
+ * since round 4 it holds the other ranks' entries only for a window in front of its own (*whole_arrays == 0), so
+ * fseq_debug_dp is meaningful there for its own entries only (FSEQ_SHARD_DP_FULL keeps whole arrays on every rank). */
 int  fseq_debug_dp(fseq_ctx *ctx, uint32_t *lb, uint32_t *max_size, uint32_t *size);
+int  fseq_debug_dp_owned(fseq_ctx *ctx, uint64_t *first, uint64_t *last, int *final_cell, int *whole_arrays);
 /* Exact (a,d) at column block_idx*block_len (block_idx <= n_blocks). */
 int  fseq_debug_block_state(fseq_ctx *ctx, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out);
 /* Per-column divergence list after column c: descending (value,count), up to list_cap+1 entries;
@@ -33,7 +37,9 @@ int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t c
 
 /* The library's diagnostic knobs (FSEQ_* names, listed in csrc/fseq_api.hip `struct Tuning`): a context reads them
  * from the environment once, at fseq_create; this sets one afterwards (value NULL = off).  Every knob selects among
- * exact alternatives; results never depend on them.  Call before the first fseq_run_segmentation. */
+ * exact alternatives; results never depend on them.  Call before the first fseq_run_segmentation (a later call drops the work buffers and
+ * the result of the context: the geometry may change); on a sharded context before the input is set, identically on
+ * every rank (FSEQ_E_ARG afterwards: the input is laid out for the block partition in force when it was set). */
 int  fseq_debug_set_tuning(fseq_ctx *ctx, char const *name, char const *value);
 
 #ifdef __cplusplus

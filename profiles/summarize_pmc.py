@@ -26,15 +26,28 @@ def find(pattern):
 
 
 def per_kernel(path):
-    """{kernel: {counter: (sum, launches)}} from a rocprofv3 counter_collection.csv"""
+    """{kernel: {counter: (sum, launches, summed dispatch duration in ns)}} from a rocprofv3 counter_collection.csv"""
     acc = {}
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"].split("(")[0]
-            a = acc.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0])
+            a = acc.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0, 0.0])
             a[0] += float(row["Counter_Value"])
             a[1] += 1
+            try:
+                a[2] += float(row["End_Timestamp"]) - float(row["Start_Timestamp"])
+            except (KeyError, ValueError):
+                pass
     return acc
+
+
+def kernel_avg_ns(path):
+    """{kernel: average duration in ns} from a rocprofv3 kernel_stats.csv (the --kernel-trace --stats pass)"""
+    out = {}
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            out[row["Name"].split("(")[0]] = float(row["AverageNs"])
+    return out
 
 
 def phase_of(name):
@@ -67,8 +80,8 @@ def main():
     for d in sorted(os.listdir(src)):
         for path in find(os.path.join(src, d, "**", "*counter_collection.csv")):
             for k, cs in per_kernel(path).items():
-                for cname, (tot, cnt) in cs.items():
-                    counters.setdefault(k, {})[cname] = {"sum": tot, "launches": cnt, "avg_per_launch": tot / cnt}
+                for cname, (tot, cnt, dur) in cs.items():
+                    counters.setdefault(k, {})[cname] = {"sum": tot, "launches": cnt, "avg_per_launch": tot / cnt, "duration_ns": dur}
     # flat csv of every counter
     with open(os.path.join(HERE, "%s_pmc_counters_%s.csv" % (prefix, workload)), "w", newline="") as f:
         wr = csv.writer(f)
@@ -94,6 +107,25 @@ def main():
         }
         if phase_of(k):
             phases[phase_of(k)] = phases.get(phase_of(k), 0.0) + per_step
+    # issue side, per kernel (round 4): every SQ counter's average per launch, the launch's average duration in the
+    # kernel-trace pass, and the EFFECTIVE clock of the profiled launches -- GRBM_GUI_ACTIVE is summed over the 8 XCDs, so
+    # clock = GRBM_GUI_ACTIVE / 8 / dispatch duration (MI355X_MICROARCH.md, "DVFS give-back"; reads high on dispatches
+    # shorter than ~0.3 ms).  bench.py prices the dominant kernel's VALU issue share with it.
+    avg_ns = kernel_avg_ns(stats[0]) if stats else {}
+    issue = {}
+    for k, cs in counters.items():
+        d = {c: v["avg_per_launch"] for c, v in cs.items() if c.startswith("SQ_") or c.startswith("GRBM_")}
+        if not d:
+            continue
+        if k in avg_ns:
+            d["avg_ns"] = avg_ns[k]
+        g = cs.get("GRBM_GUI_ACTIVE")
+        if g and g.get("duration_ns"):
+            d["clock_ghz_effective"] = g["sum"] / 8.0 / g["duration_ns"]
+            d["avg_ns_in_grbm_pass"] = g["duration_ns"] / g["launches"]
+        if k in kernels:
+            d["hbm_bytes_per_launch_corrected"] = kernels[k]["hbm_bytes_per_launch_corrected"]
+        issue[k] = d
     out = {
         "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload %s --steps 5 --warmup 2 "
                    "--no-cpu-baseline --no-batched (one pass per counter set, profiles/collect_profiles.sh)" % workload,
@@ -103,6 +135,9 @@ def main():
         "units": "FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE x2 on gfx950 (wide coalesced reads are under-counted by half)",
         "phases_hbm_bytes_per_step": phases,
         "kernels": kernels,
+        "issue_units": "SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles summed over the SIMDs, SQ_INSTS_* in wave-instructions, "
+                       "GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs; averages per launch",
+        "issue": issue,
     }
     with open(os.path.join(HERE, "%s_pmc_traffic_%s.json" % (prefix, workload)), "w") as f:
         json.dump(out, f, indent=1)

@@ -47,3 +47,20 @@ def optimal_max_segment_size(msa, L):
                 break
         best[end] = cur
     return best[n]
+
+
+def owned_dp_mask(ctx, n, L):
+    """DP entries a context answers for in fseq_debug_dp: the entries some cell writes (the L - 1 in front of the final
+    cell's are never written), restricted -- on a rank of a sharded run that keeps windows, not whole arrays -- to the
+    entries the rank computed itself."""
+    import numpy as np
+    written = np.ones(n - L + 1, dtype=bool)
+    written[n - 2 * L + 1:n - L] = False
+    lo, hi, final_cell, whole = ctx.debug_dp_owned()
+    if whole:
+        return written
+    mine = np.zeros(n - L + 1, dtype=bool)
+    mine[lo:hi] = True
+    if final_cell:
+        mine[n - L] = True
+    return written & mine

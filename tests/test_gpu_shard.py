@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import fso
+from helpers import owned_dp_mask
 
 pytestmark = pytest.mark.gpu
 
@@ -53,11 +54,12 @@ def run_world(pkg, world, make_input, m, n, L, **kw):
 def check_against_oracle(pkg, ctxs, msa, L):
     m, n = msa.shape
     ref = fso.segment_long(msa, L, keep_dp=True, threads=4)
-    written = np.ones(n - L + 1, dtype=bool)
-    written[n - 2 * L + 1:n - L] = False
+    covered = np.zeros(n - L + 1, dtype=bool)
     for ctx in ctxs:
         assert ctx.result.max_segment_size == ref["max_segment_size"]
         lb, mx, sz = ctx.debug_dp()
+        written = owned_dp_mask(ctx, n, L)                # (a rank that keeps windows answers for the entries it computed)
+        covered |= written
         assert np.array_equal(mx[written], ref["dp"]["segment_max_size"][written])
         assert np.array_equal(lb[written], ref["dp"]["lb"][written].astype(np.uint32))
         assert np.array_equal(sz[written], ref["dp"]["segment_size"][written])
@@ -71,6 +73,9 @@ def check_against_oracle(pkg, ctxs, msa, L):
         assert len(red) == len(ref["reduced"])
         for f in ("lb", "rb", "segment_size"):
             assert np.array_equal(red[f], ref["reduced"][f]), f
+    all_written = np.ones(n - L + 1, dtype=bool)
+    all_written[n - 2 * L + 1:n - L] = False
+    assert np.array_equal(covered, all_written)           # the ranks' parts tile the DP array
     if ref["status"] != 0:
         return
     red = ctxs[0].reduced_traceback()
@@ -142,6 +147,31 @@ def test_sharded_device_generator_and_short_lists(pkg, monkeypatch):
     assert np.array_equal(ctxs[1].get_sequences(c0, c1), msa[:, c0:c1])
     with pytest.raises(pkg.FseqError):
         ctxs[1].get_sequences(0, 10)
+
+
+@pytest.mark.parametrize("mode", ["window_1024", "window_64", "full"])
+def test_sharded_dp_exchange_modes(pkg, monkeypatch, mode):
+    """The sharded DP keeps, of the other ranks' keys, a window in front of its own entries and follows the traceback rank by
+    rank.  A window that holds everything the sweeps read (1,024 entries here), one that does not (64: a sweep reports that
+    it read below it and the run starts again with whole-array exchanges), and the whole-array form asked for outright --
+    all bit-identical to the oracle, DP entries included."""
+    if mode == "full":
+        monkeypatch.setenv("FSEQ_SHARD_DP_FULL", "1")
+    else:
+        monkeypatch.setenv("FSEQ_SHARD_DP_WINDOW", mode.split("_")[1])
+    monkeypatch.setenv("FSEQ_DP_SPEC_ROUNDS", "7")
+    for world, (m, n, L, K, Brec, mu, seed, kind, B) in [(3, (300, 24000, 25, 8, 200, 2e-3, 51, 0, 50)), (4, (2500, 20000, 50, 16, 2000, 1e-4, 0x5EED0002, 0, 0)),
+                                                          (2, (12000, 6000, 20, 12, 120, 3e-4, 53, 0, 30))]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctxs = run_world(pkg, world, lambda c: c.set_sequences(msa), m, n, L, block_len=B)
+        check_against_oracle(pkg, ctxs, msa, L)
+        whole = {c.debug_dp_owned()[3] for c in ctxs}
+        assert len(whole) == 1                            # every rank took the same way
+        if mode == "full":
+            assert whole == {True}
+        if mode == "window_1024":
+            assert whole == {False}
+        assert len({c._transport.calls for c in ctxs}) == 1
 
 
 def test_too_many_ranks_fail_together(pkg):
