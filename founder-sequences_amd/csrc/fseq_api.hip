@@ -46,7 +46,7 @@ struct KernelSet {
 	size_t lds_colblock, lds_snap;
 	uint32_t scan_shift;                     // partition steps of this configuration may scan keys while every divergence is < 2^scan_shift
 	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
-	             uint32_t *, uint32_t *, uint32_t *, uint64_t col0);
+	             uint32_t *, uint32_t *, uint32_t *, uint64_t col0, uint32_t const *only);
 	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
 	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
 	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d, uint32_t keyed);
@@ -74,10 +74,11 @@ hipError_t allow_lds(K kernel, size_t bytes)
 template <int T, int E, int SIGMA, bool PK, bool EW = false>
 struct Launch {
 	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0)
+	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0, uint32_t const *only)
 	{
+		// (only: per-block filter, passed in the start-state slot the rank mode does not use -- k_colblock)
 		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh, rank_, keyd, nkeys,
-		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
+		                   only, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
 		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0,
 		                   (uint64_t) B < (1ull << scan_shift_for(T, E)) ? 1u : 0u);      // (divergences relative to the block start: <= B)
 	}
@@ -137,12 +138,12 @@ struct Launch {
 #define FSEQ_BK_SIZES(X) X(256) X(320) X(512) X(768) X(1024)
 void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
                       uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
-                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced)
+                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced, uint32_t *todo)
 {
 	switch (T)
 	{
 #define X(T_) case T_: hipLaunchKernelGGL((k_blockkeys<T_>), dim3(grid), dim3(T_), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0, \
-	                                          scratch, scratch_per_block, cap_words, sliced); break;
+	                                          scratch, scratch_per_block, cap_words, sliced, todo); break;
 		FSEQ_BK_SIZES(X)
 #undef X
 		default: break;
@@ -302,6 +303,7 @@ struct Tuning {
 	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
+	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
 	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
 	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
 	bool ss_unpacked = false;            // FSEQ_SS_UNPACKED: 8-byte stride states in the streamed regime
@@ -338,6 +340,7 @@ struct Tuning {
 		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
 		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
 		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
+		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
 		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
@@ -360,7 +363,7 @@ struct Tuning {
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
-			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW"};
+			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -404,6 +407,10 @@ struct fseq_ctx {
 	size_t bk_per_block = 0, bk_blocks = 0;
 	uint32_t bk_cap_words = 0;
 	uint32_t bk_T = 0;                       // threads of k_blockkeys (LDS-resident rows)
+	uint32_t *d_todo = nullptr;              // phase A: blocks the key-space tree gave up on (the column sweep does them)
+	size_t todo_cap = 0;
+	int bk_given_up = -1;                    // ... in the last run on this input (-1: not run yet): later runs skip the sweep's launch when
+	                                         // it was none, and the tree altogether when it was most blocks
 	size_t bk_lds = 0;
 	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
 	uint32_t chunk_cap = 0;
@@ -1027,7 +1034,7 @@ void free_work(fseq_ctx *c)
 	c->levels.clear();
 	dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr; dev_free(c, &c->d_hdr); dev_free(c, &c->d_flags); dev_free(c, &c->d_recent);
 	dev_free(c, &c->d_chunk_r0); c->chunk_cap = 0; dev_free(c, &c->d_tau); c->tau_cap = 0;
-	dev_free(c, &c->d_bk); c->bk_blocks = 0; dev_free(c, &c->d_bkws); c->bkws_words = 0;
+	dev_free(c, &c->d_bk); c->bk_blocks = 0; dev_free(c, &c->d_bkws); c->bkws_words = 0; dev_free(c, &c->d_todo); c->todo_cap = 0;
 	dev_free(c, &c->d_tb); c->tb_cap = 0; c->tb_win = 0;
 	dev_free(c, &c->dp.M); dev_free(c, &c->dp.LB); dev_free(c, &c->dp.SZ); dev_free(c, &c->dp.K); dev_free(c, &c->dp.Tb); dev_free(c, &c->dp.Tbv);
 	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
@@ -1109,6 +1116,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	c->bk_given_up = -1;
 	return FSEQ_OK;
 }
 
@@ -1149,6 +1157,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	c->bk_given_up = -1;
 	return FSEQ_OK;
 }
 
@@ -1310,17 +1319,18 @@ uint32_t scan_keyed(fseq_ctx const *c)
 // streamed rows: occurrence keys while every column number fits 25 bits (FSEQ_PLAIN_SCAN: the has-based scan)
 bool stream_keyed(fseq_ctx const *c) { return c->p.n < (1ull << 25) && !c->tune.plain_scan; }
 
-void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0)
+// only: per-block filter (blocks whose word is zero are skipped), or nullptr
+void launch_rank(fseq_ctx *c, uint32_t grid, uint32_t B, uint32_t nblocks, uint32_t *rank, uint32_t *keyd, uint32_t *nkeys, uint64_t col0 = 0, uint32_t const *only = nullptr)
 {
 	fseq_params const &p = c->p;
 	if (!grid) return;
 	if (c->use_stream)
 		hipLaunchKernelGGL((stream_keyed(c) ? k_colblock_stream<MODE_RANK, true> : k_colblock_stream<MODE_RANK, false>), dim3(grid), dim3(ST), stream_lds_bytes(sym_bytes(p.m, c->bsh), c->stream_staged), c->stream, c->d_msa, c->ld, p.m, p.n, B, nblocks,
-		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, (uint32_t const *) nullptr, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
+		                   c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, rank, keyd, nkeys, only, (uint32_t const *) nullptr, (uint64_t const *) nullptr,
 		                   (uint2 const *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u,
 		                   (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0, 0u);
 	else
-		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys, col0);
+		c->ks.rank(c->stream, grid, c->ks.lds_colblock, c->d_msa, c->ld, p.m, p.n, B, nblocks, c->npass, c->bsh, rank, keyd, nkeys, col0, only);
 }
 
 // grid chains grp0 .. grp0 + grid - 1, chain g over the key blocks [g * G, min(nb_total, (g + 1) * G))
@@ -1751,6 +1761,8 @@ struct LongRun {
 	double ms_c = 0, ms_dp = 0, ms_host = 0, ms_p2 = 0;
 	uint64_t pass2_cells = 0;
 	bool keyspace = false;
+	bool tree_ran = false;                   // phase A ran the key-space tree at all (else: the column sweep did every block, as last time)
+	bool tree_alone = false;                 // phase A ran the key-space tree without the column sweep behind it (no block was given up last time)
 };
 
 // the aliases every phase uses
@@ -1779,7 +1791,25 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 	progress(c, FSEQ_STAGE_TRACEBACK, 0, n);
 	FSEQ_RANGE_PUSH("fseq pass 1: phases A + B (block keys, boundary states)");
 	bool const keyspace = R.keyspace = c->bk_cap_words && my_blocks && !c->tune.phase_a_classic;
-	if (keyspace && c->use_stream)
+	// The key-space tree hands the blocks whose merges would slice past their budget to the column sweep (fseq_blockkeys.hpp,
+	// BK_ABORT): per-block flags, the sweep launched over my blocks with the flags as its filter.  What the last run on this
+	// input saw decides what is launched now (the input has not changed, so neither has the outcome): no block given up ->
+	// the tree alone; most of them -> the sweep alone; else both.  FSEQ_BLOCKKEYS_CAP (tests of the slices) and
+	// FSEQ_BLOCKKEYS_NO_LIMIT: the tree slices as often as it takes.
+	bool const limited = keyspace && !c->tune.blockkeys_no_limit && !c->tune.blockkeys_cap;
+	bool const tree = keyspace && !(limited && c->bk_given_up >= 0 && 2u * (uint32_t) c->bk_given_up > my_blocks);
+	bool const sweep_after = limited && !(tree && c->bk_given_up == 0);
+	R.tree_alone = tree && limited && !sweep_after;
+	R.tree_ran = tree;
+	uint32_t *todo = nullptr;
+	if (limited)
+	{
+		if (c->todo_cap < my_blocks) { if ((rc = dev_alloc(c, &c->d_todo, my_blocks))) return rc; c->todo_cap = my_blocks; }
+		todo = c->d_todo;
+		HIP_TRY(c, hipMemsetAsync(todo, tree ? 0 : 0x01, (size_t) my_blocks * 4, st));     // (no tree: every block is the sweep's)
+	}
+	if (keyspace) HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 8, st));
+	if (tree && c->use_stream)
 	{
 		// phase A in key space, streamed rows: one workgroup per CU with its own workspace, blocks round-robin
 		int ncu = 0;
@@ -1791,12 +1821,11 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 			if ((rc = dev_alloc(c, &c->d_bkws, per * groups))) return rc;
 			c->bkws_words = per * groups;
 		}
-		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
 		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
 		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u));
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u), todo);
 	}
-	else if (keyspace)
+	else if (tree)
 	{
 		// phase A in key space (fseq_blockkeys.hpp)
 		size_t const per = (blockkeys_scratch_halfwords(m, c->B, c->bsh) + 7) & ~size_t(7);
@@ -1805,12 +1834,12 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 			if ((rc = dev_alloc(c, &c->d_bk, per * my_blocks))) return rc;
 			c->bk_per_block = per; c->bk_blocks = my_blocks;
 		}
-		HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 4, st));
 		launch_blockkeys(c->bk_T, st, my_blocks, c->bk_lds, c->d_msa, c->ld, m, n, c->B, c->bsh, c->d_rank + (size_t) b_lo * m,
-		                 c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64);
+		                 c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64, todo);
 	}
-	else
-		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B);
+	if (!keyspace || sweep_after)
+		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
+		            keyspace && tree ? todo : nullptr);
 	HIP_TRY(c, hipEventRecord(c->ev[1], st));
 	if (sharded && c->tune.inject_failure_rank >= 0 && (uint32_t) c->tune.inject_failure_rank == sh.rank)
 		return fail(c, FSEQ_E_OOM, "injected failure (FSEQ_INJECT_FAILURE_RANK)");
@@ -2287,9 +2316,18 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	uint32_t *const h_flags = pin_take<uint32_t>(c, 8);
 	h_flags[4] = 0;
 	HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
-	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 4, hipMemcpyDeviceToHost, st));
+	h_flags[5] = 0;
+	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
-	if (keyspace) c->tm.phase_a_fallbacks = h_flags[4];
+	if (keyspace)
+	{
+		if (!R.tree_ran) h_flags[5] = my_blocks;               // (no tree this time: every block went to the column sweep, as last time)
+		c->tm.phase_a_fallbacks = h_flags[4];
+		c->tm.phase_a_given_up = h_flags[5];
+		// (the tree ran alone because no block was given up last time; the same input gives the same outcome)
+		if (R.tree_alone && h_flags[5] != 0u) return fail(c, FSEQ_E_HIP, "internal: the key-space tree gave up blocks it ranked in the run before");
+		c->bk_given_up = (int) h_flags[5];
+	}
 	{
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
@@ -2533,7 +2571,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				c->bkws_words = per;
 			}
 			hipLaunchKernelGGL(k_blockkeys_stream, dim3(1), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, 1u,
-			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u));
+			                   d_rank, d_keyd, d_nk, (uint64_t) 0, c->d_bkws, per, c->bk_cap_words, (uint32_t *) nullptr, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u), (uint32_t *) nullptr);
 		}
 		else
 		{
@@ -2543,7 +2581,7 @@ int run_short_path(fseq_ctx *c, fseq_result *res)
 				if ((rc = dev_alloc(c, &c->d_bk, per))) { dev_free(c, &d_rank); dev_free(c, &d_keyd); dev_free(c, &d_nk); return rc; }
 				c->bk_per_block = per; c->bk_blocks = 1;
 			}
-			launch_blockkeys(c->bk_T, st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr);
+			launch_blockkeys(c->bk_T, st, 1, c->bk_lds, c->d_msa, c->ld, m, p.n, (uint32_t) p.n, c->bsh, d_rank, d_keyd, d_nk, 0, c->d_bk, per, c->bk_cap_words, nullptr, nullptr);
 		}
 	}
 	else
@@ -2726,6 +2764,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	c->bk_given_up = -1;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2749,6 +2788,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	c->bk_given_up = -1;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2852,6 +2892,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
+	c->bk_given_up = -1;
 	return FSEQ_OK;
 }
 

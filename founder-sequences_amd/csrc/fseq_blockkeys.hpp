@@ -40,6 +40,12 @@ namespace fseq {
 
 constexpr uint32_t BK_GL = 3;                 // 2^3 leaves per group (64 columns at 2 bits per symbol)
 constexpr uint32_t BK_LEAF_BITS = 65536;      // one bit per 16-bit leaf word
+// A rank operation whose map exceeds the LDS runs in slices (exact for any data), each slice one more pass over the rows:
+// fine for the odd diverse block, ruinous when every merge of every block needs dozens of them (rows that are all
+// distinct: BASELINE C5's shape ran phase A in 1.1 s instead of 7 ms, profiles/r04_diversity_sweep.txt).  So a block has a
+// budget of extra slices (about what its rank operations cost without any); a rank operation that would pass it returns
+// BK_ABORT, the tree gives the block up, and the column sweep (k_colblock<MODE_RANK>) does it instead.  0 = no limit.
+constexpr uint32_t BK_ABORT = 0xFFFFFFFEu;
 
 #ifdef FSEQ_BK_STAMPS
 #define BK_T(S, i) do { long long const t_ = clock64(); (S).acc_t[i] += t_ - (S).last_t; (S).last_t = t_; } while (0)
@@ -98,6 +104,7 @@ struct BkLds {
 	uint32_t cap_words;
 	uint32_t turn;                 // rank operations done so far (selects the map)
 	uint32_t used_a, used_b;       // entries of map 0 / 1 that may be non-zero
+	uint32_t budget;               // extra slices the block may take in all (0: any number)
 #ifdef FSEQ_BK_STAMPS
 	long long acc_t[8], last_t;
 #endif
@@ -145,7 +152,12 @@ __device__ __forceinline__ uint32_t bk_rank8(BkLds &S, uint32_t m, uint32_t Dlo,
 	uint32_t const tid = threadIdx.x;
 	uint32_t const cap_bits = S.cap_words * 32u;
 	uint32_t const hps = ((uint64_t) Dlo * Dhi <= cap_bits) ? Dhi : max(1u, cap_bits / Dlo);     // hi values per slice (Dlo <= cap_bits)
-	if (hps < Dhi) ++*sliced;
+	if (hps < Dhi)
+	{
+		uint32_t const extra = (Dhi + hps - 1u) / hps - 1u;
+		if (S.budget && *sliced + extra > S.budget) return BK_ABORT;       // (uniform: every thread sees the same sizes)
+		*sliced += extra;
+	}
 	uint32_t base = 0;
 	for (uint32_t h0 = 0; h0 < Dhi; h0 += hps)
 	{
@@ -402,7 +414,7 @@ __device__ __forceinline__ void bk_build_leaf(uint8_t const *sym, size_t ld, uin
 template <int T>
 __device__ __forceinline__ uint32_t blockkeys_tree_lds(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
-	uint16_t *__restrict__ scratch, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out)
+	uint16_t *__restrict__ scratch, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out, bool limited)
 {
 	uint32_t const tid = threadIdx.x;
 	uint32_t const bits = 8u >> bsh, cl = 16u / bits;
@@ -422,6 +434,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_lds(
 	S.cap_words = cap_words;
 	S.turn = 0;
 	S.used_a = S.used_b = 0;
+	S.budget = limited ? 2u * nleaf + ngrp : 0u;              // about one extra pass per rank operation of the block
 	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.map0[w] = make_uint2(0u, 0u);
 	uint32_t Dacc = 0, sliced = 0;
 #ifdef FSEQ_BK_STAMPS
@@ -480,6 +493,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_lds(
 			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
 			{
 				D[sp - 2] = bk_rank8<T, false>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced, nothing);
+				if (D[sp - 2] == BK_ABORT) return BK_ABORT;
 				sz[sp - 2] += sz[sp - 1];
 				--sp;
 			}
@@ -495,6 +509,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_lds(
 		{
 			bk_copy8<T>(m, gi, grpid + (size_t) g * m8);
 			Dacc = bk_rank8<T, false>(S, m, Dacc, D[0], S.acc, gi, S.acc, &sliced, nothing);
+			if (Dacc == BK_ABORT) return BK_ABORT;
 		}
 	}
 
@@ -552,6 +567,7 @@ struct BkState {
 	uint32_t cap_words;
 	uint32_t turn;                 // rank operations done so far (selects the bitmap)
 	uint32_t used_a, used_b;       // words of bitmap 0 / 1 that may be non-zero
+	uint32_t budget;               // extra slices the block may take in all (0: any number)
 	__device__ __forceinline__ IdT *stk(uint32_t i) const { return stk0 + (size_t) i * stk_stride; }
 };
 
@@ -574,7 +590,12 @@ __device__ __forceinline__ uint32_t bk_merge(BkState<IdT, PrefT> &S, uint32_t m,
 	uint32_t const tid = threadIdx.x;
 	uint32_t const cap_bits = S.cap_words * 32u;
 	uint32_t const hps = ((uint64_t) Dlo * Dhi <= cap_bits) ? Dhi : max(1u, cap_bits / Dlo);     // hi values per slice (Dlo <= cap_bits)
-	if (hps < Dhi) ++*sliced;
+	if (hps < Dhi)
+	{
+		uint32_t const extra = (Dhi + hps - 1u) / hps - 1u;
+		if (S.budget && *sliced + extra > S.budget) return BK_ABORT;       // (uniform: every thread sees the same sizes)
+		*sliced += extra;
+	}
 	uint32_t base = 0;
 	for (uint32_t h0 = 0; h0 < Dhi; h0 += hps)
 	{
@@ -824,7 +845,7 @@ template <typename IdT>
 __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
 	uint32_t *__restrict__ ws_words, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out,
-	bool pair_leaves)
+	bool pair_leaves, bool limited)
 {
 	constexpr int T = 1024;
 	constexpr bool NARROW = sizeof(IdT) == 2;
@@ -849,6 +870,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	S.cap_words = cap_words;
 	S.turn = 0;
 	S.used_a = S.used_b = 0;
+	S.budget = limited ? 2u * nleaf + ngrp : 0u;              // about one extra pass per rank operation of the block
 	for (uint32_t w = tid; w < 2u * cap_words; w += T) S.bm0[w] = 0u;
 	__syncthreads();
 	uint32_t Dacc = 0, sliced = 0;
@@ -886,6 +908,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 					while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
 					{
 						D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced);
+						if (D[sp - 2] == BK_ABORT) { __syncthreads(); return BK_ABORT; }
 						if (NARROW && D[sp - 2] > 65536u) { __syncthreads(); return BK_WIDE; }
 						sz[sp - 2] += sz[sp - 1];
 						--sp;
@@ -921,11 +944,13 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 			}
 			__syncthreads();                                      // the words were written by row groups, the rank reads them by rows
 			D[sp] = bk_merge<T, IdT, PrefT>(S, m, BK_LEAF_BITS, 1u, top, nullptr, top, &sliced);
+			if (D[sp] == BK_ABORT) { __syncthreads(); return BK_ABORT; }
 			sz[sp] = 1;
 			++sp;
 			while (sp >= 2 && (sz[sp - 2] == sz[sp - 1] || l + 1 == l1))
 			{
 				D[sp - 2] = bk_merge<T, IdT, PrefT>(S, m, D[sp - 2], D[sp - 1], S.stk(sp - 2), S.stk(sp - 1), S.stk(sp - 2), &sliced);
+				if (D[sp - 2] == BK_ABORT) { __syncthreads(); return BK_ABORT; }
 				if (NARROW && D[sp - 2] > 65536u) { __syncthreads(); return BK_WIDE; }
 				sz[sp - 2] += sz[sp - 1];
 				--sp;
@@ -944,6 +969,7 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 		{
 			bk_copy<T, IdT>(m, gi, grpid + (size_t) g * m);
 			Dacc = bk_merge<T, IdT, PrefT>(S, m, Dacc, D[0], S.acc, gi, S.acc, &sliced);
+			if (Dacc == BK_ABORT) { __syncthreads(); return BK_ABORT; }
 			if (NARROW && Dacc > 65536u) { __syncthreads(); return BK_WIDE; }
 		}
 		BKS_T(3);
@@ -1000,14 +1026,18 @@ template <int T>
 __global__ __launch_bounds__(T) void k_blockkeys(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
-	uint16_t *__restrict__ scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *__restrict__ sliced)
+	uint16_t *__restrict__ scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t *__restrict__ todo)
 {
+	// todo (per block, zeroed by the host): set to 1 for a block the tree gave up on (BK_ABORT) -- the column sweep that
+	// follows does those; sliced[0] counts the blocks that sliced some merge, sliced[1] the blocks given up.  todo ==
+	// nullptr: no limit on the slices.
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	uint64_t const k0 = col0 + (uint64_t) blockIdx.x * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	size_t const ob = (size_t) blockIdx.x * m;
 	uint32_t const ns = blockkeys_tree_lds<T>(smem, msa, ld, m, k0, kend, bsh, cap_words, scratch + (size_t) blockIdx.x * scratch_per_block,
-	                                          rank + ob, keyd + ob, nkeys + blockIdx.x);
+	                                          rank + ob, keyd + ob, nkeys + blockIdx.x, todo != nullptr);
+	if (ns == BK_ABORT) { if (threadIdx.x == 0) { todo[blockIdx.x] = 1u; if (sliced) atomicAdd(sliced + 1, 1u); } return; }
 	if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 }
 
@@ -1016,8 +1046,9 @@ __global__ __launch_bounds__(T) void k_blockkeys(
 __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
-	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide)
+	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide, uint32_t *__restrict__ todo)
 {
+	// (todo, sliced[1]: as in k_blockkeys)
 	// wide bit 0: 32-bit ids from the start (tests; else a block is tried with halfword ids first); bit 1: leaves one by one
 	bool const pair_leaves = !(wide & 2u);
 	wide &= 1u;
@@ -1028,10 +1059,11 @@ __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		size_t const ob = (size_t) b * m;
 		uint32_t ns = wide ? BK_WIDE : blockkeys_tree_stream<uint16_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-		                                                               rank + ob, keyd + ob, nkeys + b, pair_leaves);
+		                                                               rank + ob, keyd + ob, nkeys + b, pair_leaves, todo != nullptr);
 		if (ns == BK_WIDE)
 			ns = blockkeys_tree_stream<uint32_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-			                                     rank + ob, keyd + ob, nkeys + b, pair_leaves);
+			                                     rank + ob, keyd + ob, nkeys + b, pair_leaves, todo != nullptr);
+		if (ns == BK_ABORT) { if (threadIdx.x == 0) { todo[b] = 1u; if (sliced) atomicAdd(sliced + 1, 1u); } continue; }
 		if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 	}
 }

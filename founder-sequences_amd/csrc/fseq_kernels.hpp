@@ -410,6 +410,9 @@ __global__ __launch_bounds__(T, (T == 512 && MODE == MODE_SNAP) ? 6 : 1) void k_
 	uint64_t col0, uint32_t keyed)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
+	// MODE_RANK has no start state: bstate_a, if given, is a per-block filter -- the workgroups of blocks whose word is zero
+	// have nothing to do (phase A: the blocks the key-space tree gave up on, fseq_blockkeys.hpp)
+	if (MODE == MODE_RANK && bstate_a && bstate_a[blockIdx.x] == 0u) return;
 	colblock_body<T, E, SIGMA, MODE, PK>(smem, msa, ld, m, n, B, nblocks, npass, bsh, rank, keyd, nkeys, bstate_a, bstate_d, task_rb, task_grp,
 	                                     snap_a, snap_d, task_src, snap_stride, ss_a, ss_d, col0, keyed);
 }

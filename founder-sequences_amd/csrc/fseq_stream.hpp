@@ -331,6 +331,8 @@ __global__ __launch_bounds__(ST, MODE == MODE_SNAP ? 8 : 1) void k_colblock_stre
 	uint64_t const *__restrict__ task_src, uint32_t snap_stride, uint32_t const *__restrict__ ss_a, uint32_t const *__restrict__ ss_d,
 	uint64_t col0, uint32_t ss_pack)
 {
+	// (MODE_RANK: bstate_a, if given, is a per-block filter as in k_colblock)
+	if (MODE == MODE_RANK && bstate_a && bstate_a[blockIdx.x] == 0u) return;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
 	uint8_t *sym = cv.take<uint8_t>((size_t) sym_bytes(m, bsh) + 16);

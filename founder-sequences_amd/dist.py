@@ -57,11 +57,40 @@ class ThreadWorld:
     over the ranks' exchange tensors, and a second barrier.  ctypes releases the GIL around the library call and
     takes it again for the callback, so the ranks really run side by side."""
 
-    def __init__(self, world):
+    def __init__(self, world, take_turns=False):
+        """take_turns: the ranks hold a common lock whenever they are NOT in an exchange, so one rank at a time has work on
+        the card and its phase times are those of a GPU of its own (tools/rehearsal_threads.py --serialize: the per-rank
+        times a prediction of T(N) is made from; the caller takes / drops the lock around its own calls with turn())."""
         import threading
         self.world = world
         self.barrier = threading.Barrier(world)
         self.bufs = [None] * world
+        self.turn_lock = threading.Lock() if take_turns else None
+        self.busy = [0.0] * world             # seconds a rank held the card (its own host + device time between exchanges)
+        self._since = [0.0] * world
+
+    def _take(self, rank):
+        if self.turn_lock is not None:
+            self.turn_lock.acquire()
+            self._since[rank] = time.perf_counter()
+
+    def _drop(self, rank):
+        if self.turn_lock is not None:
+            self.busy[rank] += time.perf_counter() - self._since[rank]
+            self.turn_lock.release()
+
+    def turn(self, rank):
+        """context manager: this rank's turn on the card (a no-op unless take_turns)"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            self._take(rank)
+            try:
+                yield
+            finally:
+                self._drop(rank)
+        return cm()
 
     def transport(self, words, rank, device):
         """(ShardTransport, allreduce(offset, count, op)) of one rank: a buffer of `words` words on `device`."""
@@ -72,16 +101,20 @@ class ThreadWorld:
         def allreduce(offset, count, op, self=self, tr=tr, rank=rank):
             tr.calls += 1
             tr.words_moved += count
-            self.barrier.wait()
-            if rank == 0:
-                views = [b[offset:offset + count] for b in self.bufs]
-                acc = views[0].clone()
-                for v in views[1:]:
-                    acc = acc + v if op == 0 else torch.maximum(acc, v)
-                for v in views:
-                    v.copy_(acc)
-                torch.cuda.synchronize(tr.buf.device)
-            self.barrier.wait()
+            self._drop(rank)                              # (the card is never held while waiting for the others)
+            try:
+                self.barrier.wait()
+                if rank == 0:
+                    views = [b[offset:offset + count] for b in self.bufs]
+                    acc = views[0].clone()
+                    for v in views[1:]:
+                        acc = acc + v if op == 0 else torch.maximum(acc, v)
+                    for v in views:
+                        v.copy_(acc)
+                    torch.cuda.synchronize(tr.buf.device)
+                self.barrier.wait()
+            finally:
+                self._take(rank)
             return 0
 
         return tr, allreduce

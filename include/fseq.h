@@ -100,7 +100,7 @@ typedef struct fseq_timings {
 	uint32_t dp_chunks;             /* chunks of the speculative DP (0: the serial kernel ran)               */
 	uint32_t dp_sweeps;             /* sweeps it compared until no key changed (>= 1000: serial fallback took over) */
 	uint32_t phase_a_fallbacks;     /* blocks in which a merge of the key-space tree exceeded the LDS bitmap and ran in slices */
-	uint32_t reserved;
+	uint32_t phase_a_given_up;      /* blocks the key-space tree handed to the column sweep (their merges would have sliced past the budget) */
 } fseq_timings;
 
 uint32_t    fseq_abi_version(void);

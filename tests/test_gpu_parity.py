@@ -905,6 +905,58 @@ def test_phase_a_in_key_space_matches_the_column_sweep(pkg, monkeypatch, mode):
         assert fallbacks == 0
 
 
+@pytest.mark.parametrize("shape", [
+    # m, n, L, K, mu, kind, block_len: every row its own founder -- every merge of the key-space tree would slice many times over
+    (2504, 2000, 20, 2504, 1e-2, 0, 245),                 # LDS-resident rows (BASELINE C3's), 32-bit words
+    (10000, 1400, 30, 10000, 1e-3, 1, 200),               # sigma = 16, 16-bit LDS state (BASELINE C5's rows)
+    (30000, 400, 10, 30000, 1e-3, 0, 80),                 # streamed rows
+])
+def test_diverse_blocks_go_to_the_column_sweep(pkg, shape):
+    """A block whose merges would slice past its budget is given up by the key-space tree and ranked by the column sweep
+    (profiles/r04_diversity_sweep.txt: with all rows distinct the slices made phase A 25 - 150 times slower).  First run:
+    tree + filtered sweep; the second run knows that most blocks were given up and runs the sweep alone; a friendly input
+    on the same shape gives nothing up and its second run launches the tree alone.  All bit-identical to the oracle."""
+    m, n, L, K, mu, kind, B = shape
+    msa = fso.synth_msa(fso.synth_spec(91, K, 500, mu, kind), m, n)
+    ctx, ref = compare_long(pkg, msa, L, check_dp=False, block_len=B)
+    t = ctx.timings()
+    assert t["phase_a_given_up"] > t["n_blocks"] // 2, t
+    tb0 = ctx.traceback().copy()
+    try:
+        ctx.run()                                                    # the sweep alone
+    except pkg.NoReduction:
+        pass
+    assert ctx.timings()["phase_a_given_up"] == t["n_blocks"]
+    assert np.array_equal(ctx.traceback(), tb0)
+    bl = t["block_len"]
+    p = fso.Pbwt(msa)
+    for b in (1, t["n_blocks"] // 2, t["n_blocks"]):
+        while p.idx < min(n, b * bl):
+            p.step()
+        a, d = ctx.debug_block_state(b)
+        assert np.array_equal(a, p.a) and np.array_equal(d, p.d), b
+    # a friendly mosaic on the same shape: nothing given up, and the second run (tree alone) agrees with the first
+    msa2 = fso.synth_msa(fso.synth_spec(92, 12, 300, 2e-4, kind), m, n)
+    ctx2, _ = compare_long(pkg, msa2, L, check_dp=False, block_len=B)
+    assert ctx2.timings()["phase_a_given_up"] == 0
+    tb2 = ctx2.traceback().copy()
+    ctx2.run()
+    assert ctx2.timings()["phase_a_given_up"] == 0 and np.array_equal(ctx2.traceback(), tb2)
+    # mixed: the first half of the columns friendly, the second half all distinct -> some blocks given up, not most... or most:
+    # either way the run after it repeats the outcome exactly
+    msa3 = msa2.copy()
+    msa3[:, n // 2 + n // 8:] = msa[:, n // 2 + n // 8:]
+    ctx3, _ = compare_long(pkg, msa3, L, check_dp=False, block_len=B)
+    g3 = ctx3.timings()["phase_a_given_up"]
+    assert 0 < g3 < t["n_blocks"]
+    tb3 = ctx3.traceback().copy()
+    try:
+        ctx3.run()
+    except pkg.NoReduction:
+        pass
+    assert np.array_equal(ctx3.traceback(), tb3)
+
+
 def test_repeated_runs_are_bit_identical(pkg):
     """The same context run again and again (phase A's staged leaf columns, the emitter wave, the speculative DP and
     the benign races they allow must never show in a result): traceback, segments and a boundary state each time."""

@@ -7,6 +7,8 @@ chip --, it is (a) that W ranks run the whole workload to the same result as one
 exchanges and bytes a step makes, (c) which phases are replicated: a rank's phase times against the single-GPU ones.
 
     python tools/rehearsal_threads.py C4 8 > profiles/r04_rehearsal_C4_8ranks_one_gpu.json
+    python tools/rehearsal_threads.py C4 8 2 --serialize     # one rank at a time on the card: per-rank phase times as on a
+                                                              # GPU of its own -> the predicted T(N) of DESIGN.md section 6
 """
 import hashlib
 import importlib
@@ -39,7 +41,8 @@ def main():
     fdist = importlib.import_module("founder-sequences_amd.dist")
     name = sys.argv[1] if len(sys.argv) > 1 else "C4"
     world = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 and not sys.argv[3].startswith("-") else 2
+    serialize = "--serialize" in sys.argv
     w = bench.WORKLOADS[name]
     m, n, L = w["m"], w["n"], w["L"]
     dev = torch.device("cuda", 0)
@@ -69,7 +72,7 @@ def main():
     torch.cuda.empty_cache()
 
     # ---- W ranks as threads
-    tw = fdist.ThreadWorld(world)
+    tw = fdist.ThreadWorld(world, take_turns=serialize)
     ctxs = [pkg.SegmentationContext(m, n, L, device=0) for _ in range(world)]
     errs = [None] * world
     per_rank = [None] * world
@@ -79,13 +82,16 @@ def main():
         try:
             tw.attach(ctxs[r], r, dev)
             ctxs[r].set_memory_budget(int(total * 0.92 / world))
-            ctxs[r].generate_synthetic(w["seed"], w["K"], w["B"], w["mu"], w["kind"])
-            ctxs[r].run()                                  # warm-up (allocations, list capacity)
+            with tw.turn(r):
+                ctxs[r].generate_synthetic(w["seed"], w["K"], w["B"], w["mu"], w["kind"])
+                ctxs[r].run()                              # warm-up (allocations, list capacity)
             tw.barrier.wait()
+            tw.busy[r] = 0.0
             acc = {k: 0.0 for k in keys}
             t0 = time.perf_counter()
             for _ in range(steps):
-                ctxs[r].run()
+                with tw.turn(r):
+                    ctxs[r].run()
                 t = ctxs[r].timings()
                 for k in keys:
                     acc[k] += t[k]
@@ -116,7 +122,9 @@ def main():
     runs = steps + 1
     t0_ = ctxs[0].timings()
     out = {
-        "what": "rehearsal: %d ranks as threads of one process on ONE MI355X (barrier + device reduction for the all-reduce); NOT a scaling measurement" % world,
+        "what": "rehearsal: %d ranks as threads of one process on ONE MI355X (barrier + device reduction for the all-reduce); NOT a scaling measurement%s"
+                % (world, "; ranks take turns on the card (one at a time outside the exchanges): the per-rank phase times are those of a GPU of its own" if serialize else ""),
+        "serialized": serialize,
         "workload": name, "m": m, "n": n, "L": L, "n_gpus": 1, "ranks": world, "steps": steps,
         "single_gpu": single,
         "sharded": {
@@ -125,6 +133,10 @@ def main():
             "exchanges_per_step": tr.calls // runs, "MB_per_step": round(tr.words_moved * 4 / runs / 1e6, 3),
             "dp_keeps": "windows" if not ctxs[0].debug_dp_owned()[3] else "whole arrays",
             "phases_ms_per_rank": per_rank,
+            # --serialize: what a rank spent holding the card per step (its own kernels and host code between the exchanges) --
+            # its step on a GPU of its own, exchanges excluded; phases that contain exchanges (B, DP, host) include the
+            # other ranks' turns in their event times above and are to be read from this figure minus A, C and pass 2
+            "busy_ms_per_rank": [round(b / steps * 1e3, 3) for b in tw.busy] if serialize else None,
             "columns_per_rank": [c.shard_columns() for c in ctxs],
         },
         "bit_identical_to_single_gpu": all(d == single["digest"] for d in digests),
