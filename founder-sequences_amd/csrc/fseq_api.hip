@@ -12,6 +12,7 @@
 #include "fseq_dpspec.hpp"
 #include "fseq_stream.hpp"
 #include "fseq_stream2.hpp"
+#include "fseq_chainsort.hpp"
 #include "fseq_blockkeys.hpp"
 #include "fseq_rowshard.hpp"
 #include "fseq_join.hpp"
@@ -301,6 +302,7 @@ struct Tuning {
 	bool phase_a_classic = false;        // FSEQ_PHASE_A_CLASSIC: phase A as a column sweep
 	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
 	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
+	bool chain_stream_passes = false;    // FSEQ_CHAIN_STREAM_PASSES: streamed phase B as two-bit digit passes (the form before fseq_chainsort.hpp)
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
 	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
@@ -338,6 +340,7 @@ struct Tuning {
 		else if (n == "FSEQ_PHASE_A_CLASSIC") phase_a_classic = on;
 		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
 		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
+		else if (n == "FSEQ_CHAIN_STREAM_PASSES") chain_stream_passes = on;
 		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
 		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
@@ -363,7 +366,7 @@ struct Tuning {
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
-			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT"};
+			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -771,6 +774,7 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_columns_stream<0>, lds));
 		HIP_TRY(c, allow_lds(k_chain_stream<false>, stream_lds_bytes(0, true)));
 		HIP_TRY(c, allow_lds(k_chain_stream<true>, stream_lds_bytes(0, true)));
+		HIP_TRY(c, allow_lds(k_chain_stream_sort, chainsort_lds_bytes()));
 		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
 		// (FSEQ_STREAM2=T,E[,0] picks another configuration [8-byte rows], FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
 		c->s2 = Stream2Config{};
@@ -1339,7 +1343,12 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
                   uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0 = 0)
 {
 	if (!grid) return;
-	if (c->use_stream)
+	// streamed rows: a chain step as a radix sort by rank + range maxima (fseq_chainsort.hpp) where the workspace holds its
+	// arrays for every workgroup of the launch; else (and with FSEQ_CHAIN_STREAM_PASSES) the two-bit digit passes
+	if (c->use_stream && !c->tune.chain_stream_passes && (size_t) grid * chainsort_ws_words(c->p.m) <= c->ws_words)
+		hipLaunchKernelGGL(k_chain_stream_sort, dim3(grid), dim3(ST), chainsort_lds_bytes(), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
+		                   cols_per_block, c->d_ws, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
+	else if (c->use_stream)
 		hipLaunchKernelGGL((stream_keyed(c) ? k_chain_stream<true> : k_chain_stream<false>), dim3(grid), dim3(ST), stream_lds_bytes(0, true), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
 		                   cols_per_block, c->d_ws, 1u, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	else

@@ -1,0 +1,265 @@
+// fseq_chainsort.hpp -- phase B for orders that do not fit LDS (m > 11,264 rows): one chain step as a stable radix
+// sort by the block rank plus range maxima, instead of ceil(log2(nkeys) / 2) two-bit partition passes.
+//
+// A chain step (k_chain / k_chain_stream, fseq_kernels.hpp) takes the order (a, d) in front of a key block
+// {rank[row], keyd[key], nkeys} to the order behind it: a' = the stable sort of a by rank[a]; the row at new position p
+// whose predecessor there has ANOTHER rank starts a block key and takes d' = keyd[rank]; a row whose predecessor has the
+// SAME rank was, in the old order, the next row of that rank behind it, at positions q < r, and takes
+// d' = max d(q, r] -- the column update of libbio::pbwt::pbwt_context (founder_sequences.hh:56-65, SURVEY.md Appendix A
+// step 2) with nkeys buckets.  The two-bit digit passes of the partition step carry that maximum through every pass,
+// which is what makes them exact -- and, for 100,000 rows and 17-bit ranks, nine passes of the whole tile machinery by
+// ONE workgroup: 2.5 ms a step, and phase B is a chain of ~40 such steps whatever the chip (and whatever the rank count of
+// a sharded run: its Amdahl floor).  Here:
+//   1. pairs (rank[a[i]], i), stably sorted by rank with an LSD radix sort of <= 9-bit digits (two passes for ranks below
+//      2^18).  A wave owns a contiguous chunk of the array: per-wave digit histograms in LDS, one prefix over (digit,
+//      wave), then every wave scatters its chunk in order -- the rows of a 64-row group that share a digit found with
+//      one ballot per digit bit (their rank within the group = a popcount below the lane) -- no barrier inside a sweep;
+//   2. prefix and suffix maxima of d inside 64-blocks (one wave scan each) and a sparse table over the block maxima;
+//   3. every new position: its row, and keyd or the range maximum between the old positions of the two rows (two
+//      block-end look-ups and two table entries, or a scan of at most 63 values inside one block).
+// Everything but the histograms lives in the workgroup's workspace (L2-resident: a few MB).
+#pragma once
+
+#include "fseq_stream.hpp"
+
+namespace fseq {
+
+constexpr uint32_t CS_MAX_DIGIT_BITS = 9;
+constexpr uint32_t CS_BINS = 1u << CS_MAX_DIGIT_BITS;
+constexpr uint32_t CS_LEVELS = 16;               // sparse table over at most 2^16 blocks of 64 rows
+
+// workspace words of one workgroup: a0 d0 | a1 d1 (= pairs A during a sort) | pairs B | prefix max | suffix max | table
+__host__ __device__ inline size_t chainsort_ws_words(uint32_t m)
+{
+	size_t const nblk = ((size_t) m + 63) / 64;
+	return 8 * (size_t) m + CS_LEVELS * nblk + 64;
+}
+
+struct ChainSortLds {
+	uint32_t hist[ST / WAVE][CS_BINS];           // per wave: digit counts, then the wave's write offsets
+	uint32_t total[CS_BINS];
+	uint32_t scan[ST / WAVE + 1];
+};
+
+__host__ __device__ inline size_t chainsort_lds_bytes() { return carve_bytes(1, sizeof(StreamLds)) + carve_bytes(1, sizeof(ChainSortLds)); }
+
+// lanes of the wave whose digit equals mine (in = this lane holds a row), nbits digit bits
+__device__ __forceinline__ uint64_t cs_match(uint32_t dg, bool in, uint32_t nbits)
+{
+	uint64_t mask = __ballot(in);
+#pragma unroll
+	for (uint32_t b = 0; b < CS_MAX_DIGIT_BITS; ++b)
+		if (b < nbits)
+		{
+			uint64_t const bal = __ballot(in && ((dg >> b) & 1u));
+			mask &= ((dg >> b) & 1u) ? bal : ~bal;
+		}
+	return mask;
+}
+
+__device__ __forceinline__ uint32_t cs_below(uint64_t mask)
+{
+	return (uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+// One step: (a0, d0) -> (a1, d1) through the key block (rk, kd, nkeys).  w: the workgroup's workspace with a0 d0 at
+// w + off0 .. and a1 d1 at w + off1 .. (each 2m words, off in {0, 2m}); ends with a barrier.
+__device__ __forceinline__ void chain_step_sorted(
+	uint32_t m, uint32_t const *__restrict__ rk, uint32_t const *__restrict__ kd, uint32_t nkeys,
+	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L)
+{
+	uint32_t const tid = threadIdx.x, lane = lane_id();
+	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+	constexpr uint32_t NW = ST / WAVE;
+	uint32_t const *a0 = w + (size_t) cur * 2u * m, *d0 = a0 + m;
+	uint32_t *a1 = w + (size_t) (cur ^ 1u) * 2u * m, *d1 = a1 + m;
+	uint2 *const pairA = reinterpret_cast<uint2 *>(a1);                 // (the output buffers are free until step 3)
+	uint2 *const pairB = reinterpret_cast<uint2 *>(w + 4u * (size_t) m);
+	uint32_t *const pm = w + 6u * (size_t) m, *const sm = w + 7u * (size_t) m, *const tab = w + 8u * (size_t) m;
+	uint32_t const nblk = (m + 63u) / 64u;
+
+	// ---- 1. the sort.  bits of a rank, passes of at most 9 bits, the last pass lands in pairB
+	uint32_t bits = 1;
+	while (bits < 32u && ((nkeys - 1u) >> bits) != 0u) ++bits;
+	uint32_t const npass = (bits + CS_MAX_DIGIT_BITS - 1u) / CS_MAX_DIGIT_BITS;
+	uint32_t const db = (bits + npass - 1u) / npass, nbins = 1u << db;
+	// a wave's chunk: whole groups of 64 positions
+	uint32_t const per = ((m + NW - 1u) / NW + 63u) & ~63u;
+	uint32_t const c_lo = min(m, wave * per), c_hi = min(m, c_lo + per);
+	for (uint32_t p = 0; p < npass; ++p)
+	{
+		uint32_t const shift = p * db;
+		bool const first = p == 0;
+		uint2 const *src = ((npass - p) & 1u) ? pairA : pairB;          // (unused in the first pass)
+		uint2 *dst = ((npass - p) & 1u) ? pairB : pairA;
+		auto load = [&](uint32_t i) -> uint2 {
+			// first pass: the pairs are made on the way (rank of the row at position i, i)
+			return first ? make_uint2(rk[a0[i]], i) : src[i];
+		};
+		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] = 0;
+		// (a wave's histogram row is its own: no barrier between clearing and counting; LDS operations of a wave stay in order)
+		// U groups of 64 positions per iteration: their (dependent: position -> row -> rank) loads in flight together -- one
+		// workgroup has a CU to itself here, and a sweep of ~100 round trips to L2 per wave would be all latency
+		constexpr uint32_t U = 4;
+		for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 64u * U)
+		{
+			uint2 pr[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load(i) : make_uint2(0u, 0u); }
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+				if (i0 + u * 64u + lane < c_hi) atomicAdd(&S.hist[wave][(pr[u].x >> shift) & (nbins - 1u)], 1u);
+		}
+		__syncthreads();
+		// offsets: bins ascending, inside a bin the waves ascending (= the array order: the sort is stable)
+		uint32_t tot = 0;
+		if (tid < nbins)
+			for (uint32_t v = 0; v < NW; ++v) { uint32_t const c = S.hist[v][tid]; S.hist[v][tid] = tot; tot += c; }
+		uint32_t all;
+		uint32_t const start = block_excl_add<ST>(tid < nbins ? tot : 0u, S.scan, &all);
+		if (tid < nbins) S.total[tid] = start;
+		__syncthreads();
+		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] += S.total[b];
+		for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 64u * U)
+		{
+			uint2 pr[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load(i) : make_uint2(0u, 0u); }
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				bool const in = i0 + u * 64u + lane < c_hi;
+				uint32_t const dg = (pr[u].x >> shift) & (nbins - 1u);
+				uint64_t const same = cs_match(dg, in, db);
+				uint32_t const below = cs_below(same);
+				uint32_t const base = S.hist[wave][dg];
+				if (in) dst[base + below] = pr[u];
+				// (the read above and this write are LDS operations of one wave: they execute in order)
+				if (in && below == 0u) S.hist[wave][dg] = base + (uint32_t) __popcll(same);
+			}
+		}
+		__syncthreads();
+	}
+	uint2 const *perm = pairB;
+
+	// ---- 2. range maxima of the old d: prefix / suffix maxima inside 64-blocks, sparse table over the block maxima
+	for (uint32_t blk = wave; blk < nblk; blk += NW)
+	{
+		uint32_t const i = blk * 64u + lane;
+		uint32_t const v = i < m ? d0[i] : 0u;
+		uint32_t const pre = wave_incl_max(v);
+		uint32_t const rev = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((63u - lane) << 2), (int) v);
+		uint32_t const sufr = wave_incl_max(rev);
+		uint32_t const suf = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((63u - lane) << 2), (int) sufr);
+		if (i < m) { pm[i] = pre; sm[i] = suf; }
+		if (lane == 63u) tab[blk] = pre;
+	}
+	__syncthreads();
+	for (uint32_t k = 1; k < CS_LEVELS && (1u << k) <= nblk; ++k)
+	{
+		uint32_t const *lo = tab + (size_t) (k - 1u) * nblk;
+		uint32_t *hi = tab + (size_t) k * nblk;
+		for (uint32_t j = tid; j + (1u << k) <= nblk; j += ST) hi[j] = max(lo[j], lo[j + (1u << (k - 1u))]);
+		__syncthreads();
+	}
+
+	// ---- 3. the new order (U positions per thread and iteration, their loads side by side; the branches are selects on
+	// clamped look-ups, but for the rare range that lies inside one 64-block)
+	{
+		constexpr uint32_t U = 4;
+		for (uint32_t p0 = tid; p0 < m; p0 += ST * U)
+		{
+			uint2 me[U], pv[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				uint32_t const p = min(p0 + u * ST, m - 1u);
+				me[u] = perm[p];
+				pv[u] = perm[p ? p - 1u : 0u];
+			}
+			uint32_t row[U], kdv[U], sv[U], pmv[U], t0[U], t1[U], dlast[U];
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				uint32_t const lo = min(pv[u].y + 1u, m - 1u), hi = me[u].y;
+				uint32_t const bl = lo >> 6, bh = hi >> 6;
+				uint32_t const cnt = bh > bl + 1u ? bh - bl - 1u : 1u;
+				uint32_t const k = 31u - (uint32_t) __builtin_clz(cnt);
+				uint32_t const *t = tab + (size_t) k * nblk;
+				row[u] = a0[hi];
+				kdv[u] = kd[me[u].x];
+				sv[u] = sm[lo];
+				pmv[u] = pm[hi];
+				dlast[u] = d0[hi];
+				t0[u] = t[min(bl + 1u, nblk - 1u)];
+				t1[u] = t[bh >= (1u << k) ? bh - (1u << k) : 0u];
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				uint32_t const p = p0 + u * ST;
+				if (p < m)
+				{
+					bool const first = p == 0u || pv[u].x != me[u].x;
+					uint32_t const lo = pv[u].y + 1u, hi = me[u].y;      // (same rank:) max of d0[lo .. hi], lo <= hi
+					uint32_t const bl = lo >> 6, bh = hi >> 6;
+					uint32_t dv = max(sv[u], pmv[u]);
+					if (bh > bl + 1u) dv = max(dv, max(t0[u], t1[u]));
+					if (!first && bl == bh)
+					{
+						dv = dlast[u];
+						for (uint32_t i = lo; i < hi; ++i) dv = max(dv, d0[i]);
+					}
+					a1[p] = row[u];
+					d1[p] = first ? kdv[u] : dv;
+				}
+			}
+		}
+	}
+	(void) L;
+	__syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// phase B, streamed, sorted form (same contract as k_chain_stream).  ws: [gridDim.x][chainsort_ws_words(m)] words.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ST) void k_chain_stream_sort(
+	uint32_t const *__restrict__ rank, uint32_t const *__restrict__ keyd, uint32_t const *__restrict__ nkeys,
+	uint32_t m, uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t *ws,
+	uint32_t const *__restrict__ start_a, uint32_t const *__restrict__ start_d,
+	uint32_t *__restrict__ out_state_a, uint32_t *__restrict__ out_state_d,
+	uint32_t *__restrict__ out_rank, uint32_t *__restrict__ out_keyd, uint32_t *__restrict__ out_nkeys, uint32_t grp0)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	StreamLds &L = *cv.take<StreamLds>(1);
+	ChainSortLds &S = *cv.take<ChainSortLds>(1);
+	uint32_t const tid = threadIdx.x;
+	uint32_t *const w = ws + (size_t) blockIdx.x * chainsort_ws_words(m);
+	uint32_t const grp = blockIdx.x + grp0;                     // chain index (workspaces stay per workgroup)
+	uint32_t const b0 = grp * G;
+	uint32_t const b1 = min(nb_total, b0 + G);
+	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * cols_per_block);
+	for (uint32_t i = tid; i < m; i += ST)
+	{
+		w[i] = start_a ? start_a[(size_t) grp * m + i] : i;
+		w[(size_t) m + i] = start_d ? start_d[(size_t) grp * m + i] : kstart;
+	}
+	__syncthreads();
+	uint32_t cur = 0;
+	for (uint32_t b = b0; b < b1; ++b)
+	{
+		uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
+		if (out_state_a)
+			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = a[i]; out_state_d[(size_t) b * m + i] = d[i]; }
+		chain_step_sorted(m, rank + (size_t) b * m, keyd + (size_t) b * m, nkeys[b], w, cur, S, L);
+		cur ^= 1u;
+	}
+	uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
+	if (out_state_a && b1 == nb_total)
+		for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) nb_total * m + i] = a[i]; out_state_d[(size_t) nb_total * m + i] = d[i]; }
+	if (out_rank)
+		stream_emit_ranks(m, a, d, kstart, out_rank + (size_t) grp * m, out_keyd + (size_t) grp * m, out_nkeys + grp, L);
+}
+
+} // namespace fseq
