@@ -303,6 +303,7 @@ struct Tuning {
 	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
 	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
 	bool chain_stream_passes = false;    // FSEQ_CHAIN_STREAM_PASSES: streamed phase B as two-bit digit passes (the form before fseq_chainsort.hpp)
+	bool chain_stream_single = false;    // FSEQ_CHAIN_STREAM_SINGLE: ... as the sorted step on one workgroup per chain (not spread over the chip)
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
 	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
@@ -341,6 +342,7 @@ struct Tuning {
 		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
 		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
 		else if (n == "FSEQ_CHAIN_STREAM_PASSES") chain_stream_passes = on;
+		else if (n == "FSEQ_CHAIN_STREAM_SINGLE") chain_stream_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
 		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
@@ -366,7 +368,7 @@ struct Tuning {
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
-			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES"};
+			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -459,6 +461,8 @@ struct fseq_ctx {
 	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
 	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
 	uint32_t *d_rank_alloc = nullptr, *d_keyd_alloc = nullptr, *d_nkeys_alloc = nullptr, *d_bstate_a_alloc = nullptr, *d_bstate_d_alloc = nullptr;
+	uint32_t *d_cshist = nullptr;            // streamed phase B spread over the chip (fseq_chainsort.hpp): digit histograms [chain][part][bin]
+	size_t cshist_words = 0;
 	uint32_t *d_ws_c = nullptr;              // streamed phase C: the per-block workspaces, block b at d_ws_c + b * (words per block)
 	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
 	// not sharded: phase B over any number of levels (levels[i - 1] = the composites of chain_fan level-(i - 1) key blocks)
@@ -775,6 +779,7 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_chain_stream<false>, stream_lds_bytes(0, true)));
 		HIP_TRY(c, allow_lds(k_chain_stream<true>, stream_lds_bytes(0, true)));
 		HIP_TRY(c, allow_lds(k_chain_stream_sort, chainsort_lds_bytes()));
+		HIP_TRY(c, allow_lds(k_cm_emit, stream_lds_bytes(0, false)));
 		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
 		// (FSEQ_STREAM2=T,E[,0] picks another configuration [8-byte rows], FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
 		c->s2 = Stream2Config{};
@@ -953,6 +958,14 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		c->ws_words = per_block * std::max<size_t>(bh - bl, 1);
 		if ((rc = dev_alloc(c, &c->d_ws, c->ws_words))) return rc;
 		c->d_ws_c = c->d_ws - bl * columns_stream_ws_words(p.m, c->B);
+		// phase B spread over the chip: the digit histograms of every part of every chain of a launch (the widest launch of the
+		// recursion has a chain per chain_fan blocks; a sharded rank's own range the same)
+		if (!c->tune.chain_stream_passes && !c->tune.chain_stream_single && p.m < (1u << 20))
+		{
+			size_t const chains = std::max<size_t>(1, (bh - bl + std::max(2u, c->chain_fan) - 1) / std::max(2u, c->chain_fan) + 1);
+			c->cshist_words = chains * chainmulti_parts(p.m) * CS_BINS;
+			if ((rc = dev_alloc(c, &c->d_cshist, c->cshist_words))) return rc;
+		}
 	}
 	uint64_t const k_lo = held_lo(c), k_cnt = held_hi(c) - k_lo;      // sharded: lists and stride states of my columns only
 	if (X && (!c->d_ent || c->X != X))
@@ -1044,7 +1057,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
 	dev_free(c, &c->d_cols); dev_free(c, &c->d_grp); dev_free(c, &c->d_src); dev_free(c, &c->d_ss_a_alloc); dev_free(c, &c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
-	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr;
+	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 }
 
@@ -1345,7 +1358,32 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 	if (!grid) return;
 	// streamed rows: a chain step as a radix sort by rank + range maxima (fseq_chainsort.hpp) where the workspace holds its
 	// arrays for every workgroup of the launch; else (and with FSEQ_CHAIN_STREAM_PASSES) the two-bit digit passes
-	if (c->use_stream && !c->tune.chain_stream_passes && (size_t) grid * chainsort_ws_words(c->p.m) <= c->ws_words)
+	if (c->use_stream && !c->tune.chain_stream_passes && c->d_cshist && (size_t) grid * chainsort_ws_words(c->p.m) <= c->ws_words &&
+	    (size_t) grid * chainmulti_parts(c->p.m) * CS_BINS <= c->cshist_words)
+	{
+		// ... every sweep of a step a launch over (parts) x (chains): a chain of G blocks is G rounds of them
+		uint32_t const m = c->p.m, nparts = chainmulti_parts(m), npass = chainmulti_passes(m);
+		ChainMultiArgs A;
+		A.rank = rank; A.keyd = keyd; A.nkeys = nkeys; A.m = m; A.nb_total = nb_total; A.G = G; A.cols_per_block = cols_per_block;
+		A.ws = c->d_ws; A.hist = c->d_cshist; A.start_a = start_a; A.start_d = start_d; A.out_state_a = out_a; A.out_state_d = out_d;
+		A.out_rank = out_rank; A.out_keyd = out_keyd; A.out_nkeys = out_nkeys; A.grp0 = grp0; A.step = 0; A.pass = 0;
+		dim3 const by_row((m + CM_WG - 1u) / CM_WG, grid), by_part((nparts + CM_WG / WAVE - 1u) / (CM_WG / WAVE), grid);
+		hipLaunchKernelGGL(k_cm_init, by_row, dim3(CM_WG), 0, c->stream, A);
+		for (uint32_t s_ = 0; s_ < G; ++s_)
+		{
+			A.step = s_;
+			for (uint32_t ps = 0; ps < npass; ++ps)
+			{
+				A.pass = ps;
+				hipLaunchKernelGGL(k_cm_count, by_part, dim3(CM_WG), 0, c->stream, A);
+				hipLaunchKernelGGL(k_cm_offsets, dim3(grid), dim3(ST), 0, c->stream, A);
+				hipLaunchKernelGGL(k_cm_scatter, by_part, dim3(CM_WG), 0, c->stream, A);
+			}
+			hipLaunchKernelGGL(k_cm_output, by_row, dim3(CM_WG), 0, c->stream, A);
+		}
+		if (out_rank) hipLaunchKernelGGL(k_cm_emit, dim3(grid), dim3(ST), stream_lds_bytes(0, false), c->stream, A, G);
+	}
+	else if (c->use_stream && !c->tune.chain_stream_passes && (size_t) grid * chainsort_ws_words(c->p.m) <= c->ws_words)
 		hipLaunchKernelGGL(k_chain_stream_sort, dim3(grid), dim3(ST), chainsort_lds_bytes(), c->stream, rank, keyd, nkeys, c->p.m, nb_total, G,
 		                   cols_per_block, c->d_ws, start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0);
 	else if (c->use_stream)

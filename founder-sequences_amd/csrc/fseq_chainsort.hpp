@@ -262,4 +262,304 @@ __global__ __launch_bounds__(ST) void k_chain_stream_sort(
 		stream_emit_ranks(m, a, d, kstart, out_rank + (size_t) grp * m, out_keyd + (size_t) grp * m, out_nkeys + grp, L);
 }
 
+// ================================================================================================
+// The same step spread over the chip.  One workgroup per chain leaves 255 CUs idle on the levels of phase B's recursion
+// that matter for its length -- the top ones, a handful of chains of four steps each -- and a step is bound by what ONE
+// CU's texture path takes to gather and scatter 100,000 rows a dozen times (1.6 ms a step: BASELINE C4 phase B 95 -> 61 ms
+// with the single-workgroup form above).  Here every sweep of a step is a launch over (parts of 1,024 positions) x
+// (chains of the level): per radix pass  count  ->  offsets  ->  scatter, then the new order; a chain of G blocks is G
+// such rounds, the chains of a level side by side.  A wave owns a part (16 groups of 64 positions in order); the digit
+// histograms of the parts sit in a table of their own ([chain][part][bin]), whose prefix over (bin, part) one workgroup
+// per chain takes -- it also builds the sparse table of the block maxima the count sweep of the first pass left.
+// The number of passes a block needs (bits of nkeys) is device data: the host always queues the passes m needs and the
+// kernels of a pass the block does not need return at once (the ping-pong of the pair buffers is by the block's own count).
+// Pairs are (rank | row low 12 bits << 20, position | row high bits << 20): rows, positions and ranks are below 2^20.
+// ================================================================================================
+constexpr uint32_t CM_PART = 1024;               // positions per part (one wave: 16 groups of 64)
+constexpr uint32_t CM_WG = 256;                  // threads per workgroup of the part kernels: four parts
+
+struct ChainMultiArgs {
+	uint32_t const *rank, *keyd, *nkeys;         // the key blocks of the level below
+	uint32_t m, nb_total, G;
+	uint64_t cols_per_block;
+	uint32_t *ws;                                // [chains of the launch][chainsort_ws_words(m)]
+	uint32_t *hist;                              // [chains of the launch][parts][CS_BINS]
+	uint32_t const *start_a, *start_d;
+	uint32_t *out_state_a, *out_state_d, *out_rank, *out_keyd, *out_nkeys;
+	uint32_t grp0;
+	uint32_t step;                               // block b0 + step of every chain
+	uint32_t pass;                               // radix pass of the sweep kernels
+};
+
+__host__ __device__ inline uint32_t chainmulti_parts(uint32_t m) { return (m + CM_PART - 1u) / CM_PART; }
+__host__ __device__ inline uint32_t chainmulti_passes(uint32_t m)
+{
+	uint32_t bits = 1;
+	while (bits < 32u && ((m - 1u) >> bits) != 0u) ++bits;
+	return (bits + CS_MAX_DIGIT_BITS - 1u) / CS_MAX_DIGIT_BITS;
+}
+
+struct ChainMultiGeom {
+	uint32_t b, npass, db, nbins;
+	bool active;
+	uint32_t *w;
+	uint32_t const *a0, *d0;
+	uint32_t *a1, *d1;
+	uint2 *pairA, *pairB;
+	uint32_t *pm, *sm, *tab;
+	uint32_t *hist;
+};
+
+__device__ __forceinline__ ChainMultiGeom chainmulti_geom(ChainMultiArgs const &A, uint32_t chain)
+{
+	ChainMultiGeom g;
+	uint32_t const grp = chain + A.grp0;
+	uint32_t const b0 = grp * A.G, b1 = min(A.nb_total, b0 + A.G);
+	g.b = b0 + A.step;
+	g.active = g.b < b1;
+	uint32_t const nk = g.active ? A.nkeys[g.b] : 1u;
+	uint32_t bits = 1;
+	while (bits < 32u && ((nk - 1u) >> bits) != 0u) ++bits;
+	g.npass = (bits + CS_MAX_DIGIT_BITS - 1u) / CS_MAX_DIGIT_BITS;
+	g.db = (bits + g.npass - 1u) / g.npass;
+	g.nbins = 1u << g.db;
+	uint32_t const cur = A.step & 1u, m = A.m;
+	g.w = A.ws + (size_t) chain * chainsort_ws_words(m);
+	g.a0 = g.w + (size_t) cur * 2u * m; g.d0 = g.a0 + m;
+	g.a1 = g.w + (size_t) (cur ^ 1u) * 2u * m; g.d1 = g.a1 + m;
+	g.pairA = reinterpret_cast<uint2 *>(g.a1);
+	g.pairB = reinterpret_cast<uint2 *>(g.w + 4u * (size_t) m);
+	g.pm = g.w + 6u * (size_t) m; g.sm = g.w + 7u * (size_t) m; g.tab = g.w + 8u * (size_t) m;
+	g.hist = A.hist + (size_t) chain * chainmulti_parts(m) * CS_BINS;
+	return g;
+}
+
+__device__ __forceinline__ uint2 cm_pack(uint32_t key, uint32_t pos, uint32_t row) { return make_uint2(key | (row << 20), pos | ((row >> 12) << 20)); }
+__device__ __forceinline__ uint32_t cm_key(uint2 p) { return p.x & 0xFFFFFu; }
+__device__ __forceinline__ uint32_t cm_pos(uint2 p) { return p.y & 0xFFFFFu; }
+__device__ __forceinline__ uint32_t cm_row(uint2 p) { return (p.x >> 20) | ((p.y >> 20) << 12); }
+
+// pair of position i for the sweep kernels of pass p: made on the way in the first pass, else from the pass before
+__device__ __forceinline__ uint2 cm_load(ChainMultiGeom const &g, uint32_t const *rk, uint32_t pass, uint32_t i)
+{
+	if (pass == 0u) { uint32_t const row = g.a0[i]; return cm_pack(rk[row], i, row); }
+	uint2 const *src = ((g.npass - pass) & 1u) ? g.pairA : g.pairB;
+	return src[i];
+}
+
+// start state of every chain of the launch into its workspace (and out_state in front of its first block)
+__global__ __launch_bounds__(CM_WG) void k_cm_init(ChainMultiArgs const A)
+{
+	uint32_t const chain = blockIdx.y, grp = chain + A.grp0, m = A.m;
+	uint32_t const b0 = grp * A.G;
+	if (b0 >= A.nb_total) return;
+	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * A.cols_per_block);
+	uint32_t *w = A.ws + (size_t) chain * chainsort_ws_words(m);
+	uint32_t const i = blockIdx.x * CM_WG + threadIdx.x;
+	if (i >= m) return;
+	uint32_t const av = A.start_a ? A.start_a[(size_t) grp * m + i] : i;
+	uint32_t const dv = A.start_d ? A.start_d[(size_t) grp * m + i] : kstart;
+	w[i] = av; w[(size_t) m + i] = dv;
+	if (A.out_state_a) { A.out_state_a[(size_t) b0 * m + i] = av; A.out_state_d[(size_t) b0 * m + i] = dv; }
+}
+
+// count sweep of pass A.pass: digit histogram of every part; first pass: also prefix / suffix maxima of d inside the
+// 64-blocks of the part and the block maxima (level 0 of the table)
+__global__ __launch_bounds__(CM_WG) void k_cm_count(ChainMultiArgs const A)
+{
+	__shared__ uint32_t hist[CM_WG / WAVE][CS_BINS];
+	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	if (!g.active || A.pass >= g.npass) return;
+	uint32_t const lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint32_t const part = blockIdx.x * (CM_WG / WAVE) + wave, m = A.m;
+	uint32_t const lo = part * CM_PART;
+	if (lo >= m) return;
+	uint32_t const hi = min(m, lo + CM_PART);
+	uint32_t const *rk = A.rank + (size_t) g.b * m;
+	uint32_t const shift = A.pass * g.db;
+	for (uint32_t b = lane; b < g.nbins; b += 64u) hist[wave][b] = 0;
+	constexpr uint32_t U = 4;
+	for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
+	{
+		uint2 pr[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? cm_load(g, rk, A.pass, i) : make_uint2(0u, 0u); }
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u)
+			if (i0 + u * 64u + lane < hi) atomicAdd(&hist[wave][(cm_key(pr[u]) >> shift) & (g.nbins - 1u)], 1u);
+	}
+	if (A.pass == 0u)
+	{
+		uint32_t const nblk = (m + 63u) / 64u;
+		for (uint32_t i0 = lo; i0 < hi; i0 += 64u)
+		{
+			uint32_t const i = i0 + lane;
+			uint32_t const v = i < m ? g.d0[i] : 0u;
+			uint32_t const pre = wave_incl_max(v);
+			uint32_t const rev = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((63u - lane) << 2), (int) v);
+			uint32_t const sufr = wave_incl_max(rev);
+			uint32_t const suf = (uint32_t) __builtin_amdgcn_ds_bpermute((int) ((63u - lane) << 2), (int) sufr);
+			if (i < m) { g.pm[i] = pre; g.sm[i] = suf; }
+			if (lane == 63u && (i0 >> 6) < nblk) g.tab[i0 >> 6] = pre;
+		}
+	}
+	uint32_t *out = g.hist + (size_t) part * CS_BINS;
+	for (uint32_t b = lane; b < g.nbins; b += 64u) out[b] = hist[wave][b];
+}
+
+// one workgroup per chain: the parts' histograms -> their write offsets (bins ascending, inside a bin the parts ascending);
+// first pass: the levels of the sparse table over the block maxima
+__global__ __launch_bounds__(ST) void k_cm_offsets(ChainMultiArgs const A)
+{
+	__shared__ uint32_t scan[ST / WAVE + 1];
+	__shared__ uint32_t start_of[CS_BINS];
+	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.x);
+	if (!g.active || A.pass >= g.npass) return;
+	uint32_t const tid = threadIdx.x, m = A.m;
+	uint32_t const nparts = chainmulti_parts(m);
+	// (a thread per bin walks the parts in batches of independent loads: one load per round trip to L2 made this kernel --
+	// a single workgroup per chain -- the longest of a step)
+	constexpr uint32_t PB = 16;
+	uint32_t tot = 0;
+	if (tid < g.nbins)
+		for (uint32_t p0 = 0; p0 < nparts; p0 += PB)
+		{
+			uint32_t c[PB];
+#pragma unroll
+			for (uint32_t q = 0; q < PB; ++q) c[q] = p0 + q < nparts ? g.hist[(size_t) (p0 + q) * CS_BINS + tid] : 0u;
+#pragma unroll
+			for (uint32_t q = 0; q < PB; ++q) tot += c[q];
+		}
+	uint32_t all;
+	uint32_t const start = block_excl_add<ST>(tid < g.nbins ? tot : 0u, scan, &all);
+	(void) start_of;
+	if (tid < g.nbins)
+	{
+		uint32_t run = start;
+		for (uint32_t p0 = 0; p0 < nparts; p0 += PB)
+		{
+			uint32_t c[PB];
+#pragma unroll
+			for (uint32_t q = 0; q < PB; ++q) c[q] = p0 + q < nparts ? g.hist[(size_t) (p0 + q) * CS_BINS + tid] : 0u;
+#pragma unroll
+			for (uint32_t q = 0; q < PB; ++q)
+			{
+				if (p0 + q < nparts) g.hist[(size_t) (p0 + q) * CS_BINS + tid] = run;
+				run += c[q];
+			}
+		}
+	}
+	if (A.pass == 0u)
+	{
+		uint32_t const nblk = (m + 63u) / 64u;
+		for (uint32_t k = 1; k < CS_LEVELS && (1u << k) <= nblk; ++k)
+		{
+			__syncthreads();
+			uint32_t const *lo = g.tab + (size_t) (k - 1u) * nblk;
+			uint32_t *hi = g.tab + (size_t) k * nblk;
+			for (uint32_t j = tid; j + (1u << k) <= nblk; j += ST) hi[j] = max(lo[j], lo[j + (1u << (k - 1u))]);
+		}
+	}
+}
+
+// scatter sweep of pass A.pass: every part in order, the rows of a 64-row group that share a digit found by ballots
+__global__ __launch_bounds__(CM_WG) void k_cm_scatter(ChainMultiArgs const A)
+{
+	__shared__ uint32_t offs[CM_WG / WAVE][CS_BINS];
+	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	if (!g.active || A.pass >= g.npass) return;
+	uint32_t const lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	uint32_t const part = blockIdx.x * (CM_WG / WAVE) + wave, m = A.m;
+	uint32_t const lo = part * CM_PART;
+	if (lo >= m) return;
+	uint32_t const hi = min(m, lo + CM_PART);
+	uint32_t const *rk = A.rank + (size_t) g.b * m;
+	uint32_t const shift = A.pass * g.db;
+	uint2 *dst = ((g.npass - A.pass) & 1u) ? g.pairB : g.pairA;
+	uint32_t const *in_offs = g.hist + (size_t) part * CS_BINS;
+	for (uint32_t b = lane; b < g.nbins; b += 64u) offs[wave][b] = in_offs[b];
+	constexpr uint32_t U = 4;
+	for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
+	{
+		uint2 pr[U];
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? cm_load(g, rk, A.pass, i) : make_uint2(0u, 0u); }
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u)
+		{
+			bool const in = i0 + u * 64u + lane < hi;
+			uint32_t const dg = (cm_key(pr[u]) >> shift) & (g.nbins - 1u);
+			uint64_t const same = cs_match(dg, in, g.db);
+			uint32_t const below = cs_below(same);
+			uint32_t const base = offs[wave][dg];
+			if (in) dst[base + below] = pr[u];
+			// (the read above and this write are LDS operations of one wave: they execute in order)
+			if (in && below == 0u) offs[wave][dg] = base + (uint32_t) __popcll(same);
+		}
+	}
+}
+
+// the new order of every chain (and out_state behind the block, where the contract asks for it)
+__global__ __launch_bounds__(CM_WG) void k_cm_output(ChainMultiArgs const A)
+{
+	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	if (!g.active) return;
+	uint32_t const m = A.m, p = blockIdx.x * CM_WG + threadIdx.x;
+	if (p >= m) return;
+	uint32_t const nblk = (m + 63u) / 64u;
+	uint32_t const *kd = A.keyd + (size_t) g.b * m;
+	uint2 const *perm = g.pairB;
+	uint2 const me = perm[p], pv = perm[p ? p - 1u : 0u];
+	bool const first = p == 0u || cm_key(pv) != cm_key(me);
+	uint32_t dv;
+	if (first) dv = kd[cm_key(me)];
+	else
+	{
+		uint32_t const lo = cm_pos(pv) + 1u, hi = cm_pos(me);            // max of d0[lo .. hi], lo <= hi
+		uint32_t const bl = lo >> 6, bh = hi >> 6;
+		if (bl == bh)
+		{
+			dv = g.d0[hi];
+			for (uint32_t i = lo; i < hi; ++i) dv = max(dv, g.d0[i]);
+		}
+		else
+		{
+			dv = max(g.sm[lo], g.pm[hi]);
+			if (bh > bl + 1u)
+			{
+				uint32_t const k = 31u - (uint32_t) __builtin_clz(bh - bl - 1u);
+				uint32_t const *t = g.tab + (size_t) k * nblk;
+				dv = max(dv, max(t[bl + 1u], t[bh - (1u << k)]));
+			}
+		}
+	}
+	uint32_t const row = cm_row(me);
+	g.a1[p] = row; g.d1[p] = dv;
+	uint32_t const grp = blockIdx.y + A.grp0;
+	uint32_t const b1 = min(A.nb_total, grp * A.G + A.G);
+	// out_state: the state in front of every block of the chain, and behind the last block of the whole sequence
+	if (A.out_state_a && (g.b + 1u < b1 || g.b + 1u == A.nb_total))
+	{
+		A.out_state_a[(size_t) (g.b + 1u) * m + p] = row; A.out_state_d[(size_t) (g.b + 1u) * m + p] = dv;
+	}
+}
+
+// the chains' composite key blocks (rank / keyd / nkeys of the order behind the last block of every chain)
+__global__ __launch_bounds__(ST) void k_cm_emit(ChainMultiArgs const A, uint32_t steps_done)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	StreamLds &L = *cv.take<StreamLds>(1);
+	uint32_t const chain = blockIdx.x, grp = chain + A.grp0, m = A.m;
+	uint32_t const b0 = grp * A.G;
+	if (b0 >= A.nb_total) return;
+	uint32_t const b1 = min(A.nb_total, b0 + A.G);
+	uint32_t const cur = (b1 - b0) & 1u;                          // the chain made b1 - b0 steps
+	(void) steps_done;
+	uint32_t const *w = A.ws + (size_t) chain * chainsort_ws_words(m);
+	uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
+	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * A.cols_per_block);
+	stream_emit_ranks(m, a, d, kstart, A.out_rank + (size_t) grp * m, A.out_keyd + (size_t) grp * m, A.out_nkeys + grp, L);
+}
+
 } // namespace fseq

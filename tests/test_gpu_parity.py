@@ -191,6 +191,28 @@ def test_phase_b_recursion_with_any_group_size(pkg, monkeypatch, fan):
             assert np.array_equal(a, p.a) and np.array_equal(d, p.d), (m, n, b, fan)
 
 
+@pytest.mark.parametrize("form", ["FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_CHAIN_STREAM_PASSES"])
+def test_streamed_phase_b_forms(pkg, monkeypatch, form):
+    """Streamed rows: a chain step of phase B is a stable radix sort by block rank + range maxima spread over the chip
+    (fseq_chainsort.hpp, the default); the same step on one workgroup per chain, and the two-bit digit passes it replaced,
+    stay as tested alternatives -- block boundary states against the oracle's pBWT in every form, few and many keys per
+    block (a mosaic of few founders; random rows: every row its own key, 15-bit ranks = two radix passes)."""
+    monkeypatch.setenv(form, "1")
+    rng = np.random.default_rng(17)
+    for msa, L, B in [(fso.synth_msa(fso.synth_spec(46, 12, 200, 3e-4, 0), 12000, 900), 10, 12),
+                      ((rng.integers(0, 4, size=(30000, 160)) + 65).astype(np.uint8), 8, 16),
+                      (fso.synth_msa(fso.synth_spec(47, 3, 400, 0.0, 0), 11300, 300), 10, 20)]:
+        ctx, _ = compare_long(pkg, msa, L, check_dp=False, block_len=B)
+        m, n = msa.shape
+        bl = ctx.timings()["block_len"]
+        p = fso.Pbwt(msa)
+        for b in range(0, ctx.timings()["n_blocks"] + 1, max(1, ctx.timings()["n_blocks"] // 6)):
+            while p.idx < min(n, b * bl):
+                p.step()
+            a, d = ctx.debug_block_state(b)
+            assert np.array_equal(a, p.a) and np.array_equal(d, p.d), (form, m, n, b)
+
+
 def test_phase_b_and_pass_2_with_the_plain_scan(pkg, monkeypatch):
     """Phase B and pass 2 scan keys (count << shift | divergence) while n fits the shift of their configuration -- every
     test shape does; FSEQ_PLAIN_SCAN keeps the has-based scan, which long inputs (BASELINE C5: n = 10^6 on the
