@@ -252,15 +252,31 @@ constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column l
 struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
 	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
 	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
-	uint32_t (*resident)(size_t lds); };
+	uint32_t (*resident)(size_t lds);
+	// pass 2 on the same tile step (packed rows only; nullptr otherwise): k_columns_stream2<.., S2_SNAP>
+	void (*launch_snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, S2SnapArgs const &); };
 template <int T, int E, bool PACK>
 struct LaunchS2 {
 	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E, PACK>(colbytes); }
-	static hipError_t prepare(size_t bytes) { return allow_lds(k_columns_stream2<T, E, PACK>, bytes); }
+	static hipError_t prepare(size_t bytes)
+	{
+		hipError_t const e = allow_lds(k_columns_stream2<T, E, PACK>, bytes);
+		if (e != hipSuccess) return e;
+		if constexpr (PACK) return allow_lds(k_columns_stream2<T, E, PACK, S2_SNAP>, bytes);
+		return hipSuccess;
+	}
+	static void launch_snap(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
+	                        uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, S2SnapArgs const &SN)
+	{
+		if constexpr (PACK)
+			hipLaunchKernelGGL((k_columns_stream2<T, E, PACK, S2_SNAP>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, 0u, 0u, 0u, (uint2 *) nullptr, (uint4 *) nullptr,
+			                   snap_stride, ss_a, ss_d, 0u, (uint32_t *) nullptr, 0u, 0u, SN);
+	}
 	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
 	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch, uint32_t ss_pack)
 	{
-		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack);
+		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack, S2SnapArgs{});
 	}
 	static uint32_t resident(size_t bytes)
 	{
@@ -268,7 +284,7 @@ struct LaunchS2 {
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns_stream2<T, E, PACK>, T, bytes) != hipSuccess || nb < 1) nb = 1;
 		return (uint32_t) nb;
 	}
-	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch, &resident}; }
+	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch, &resident, PACK ? &launch_snap : nullptr}; }
 };
 bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out)
 {
@@ -310,6 +326,7 @@ struct Tuning {
 	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
 	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
 	bool ss_unpacked = false;            // FSEQ_SS_UNPACKED: 8-byte stride states in the streamed regime
+	bool ss_absolute = false;            // FSEQ_SS_ABSOLUTE: stride states hold divergences and pass 2 runs the first form's tile step (the form before round 4)
 	int  snap_stride = 0;                // FSEQ_SNAP_STRIDE: first stride tried for the stride states
 	bool poison_lists = false;           // FSEQ_POISON_LISTS: lists and headers filled with 0xFF before phase C
 	bool no_emitter_wave = false;        // FSEQ_NO_EMITTER_WAVE: phase C without the list wave
@@ -349,6 +366,7 @@ struct Tuning {
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
 		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
+		else if (n == "FSEQ_SS_ABSOLUTE") ss_absolute = on;
 		else if (n == "FSEQ_SNAP_STRIDE") snap_stride = on ? std::max(1, iv) : 0;
 		else if (n == "FSEQ_POISON_LISTS") poison_lists = on;
 		else if (n == "FSEQ_NO_EMITTER_WAVE") no_emitter_wave = on;
@@ -368,7 +386,7 @@ struct Tuning {
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
-			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE"};
+			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -493,6 +511,12 @@ struct fseq_ctx {
 	uint32_t snap_stride = 16;            // phase C drops the exact (a,d) every snap_stride columns for pass 2
 	uint32_t *d_ss_a = nullptr, *d_ss_d = nullptr;
 	uint32_t ss_pack = 0;                 // streamed rows: stride states packed to 5 bytes per row (bits of a row id; fseq_stream.hpp)
+	bool ss_ids = false;                  // ... and in ID form: the packed rows of phase C's workspace; pass 2 replays them on the same tile step (fseq_stream2.hpp, S2_SNAP)
+	uint32_t *d_bs_w_alloc = nullptr, *d_bs_w = nullptr;      // ... with every block's start state in the same form (block b at d_bs_w + b * m)
+	uint8_t *d_bs_h_alloc = nullptr, *d_bs_h = nullptr;
+	uint32_t *d_wgblk = nullptr;          // pass 2 on the tile step: block and groups of every workgroup
+	uint2 *d_wggrp = nullptr;
+	size_t wg_cap = 0;
 	uint2 *d_gent = nullptr;
 	uint4 *d_ghdr = nullptr;
 	size_t gather_cap = 0, gather_stride = 0;
@@ -988,6 +1012,26 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
 		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
 		// within [4 GiB, 160 GiB]; the smallest stride >= 16 (8: below) that fits.  (FSEQ_DEBUG prints the choice.)
+		// streamed rows: 5 bytes per row when a row id and a column number fit 40 bits together (fseq_stream.hpp)
+		c->ss_pack = 0;
+		c->ss_ids = false;
+		if (c->use_stream && !c->tune.ss_unpacked)
+		{
+			uint32_t abits = 1, dbits = 1;
+			while ((1ull << abits) < m) ++abits;
+			while ((1ull << dbits) <= p.n) ++dbits;
+			if (abits + dbits <= 40 && abits < 32) c->ss_pack = abits;
+			// second form of the streamed phase C on packed rows: the states in id form (its packed rows as they are: a row id and
+			// a value id below 2^19 always fit 40 bits), pass 2 on the same tile step
+			if (c->s2.T && c->s2.pack && c->s2.launch_snap && !c->tune.ss_absolute) { c->ss_pack = abits; c->ss_ids = true; }
+		}
+		if (c->ss_ids && !c->d_bs_w)
+		{
+			// every block's start state in id form (written by the prologue of phase C): my blocks and the halo block
+			size_t const bl = c->sh.on ? c->sh.b_lo : 0, bh = c->sh.on ? std::min<size_t>(c->nblocks, (size_t) std::max(c->sh.b_hi, c->sh.b_lo) + 1) : c->nblocks;
+			if ((rc = dev_alloc_range(c, &c->d_bs_w_alloc, &c->d_bs_w, bl, std::max(bh, bl + 1), m))) return rc;
+			if ((rc = dev_alloc_range(c, &c->d_bs_h_alloc, &c->d_bs_h, bl, std::max(bh, bl + 1), ss_high_stride(p.m)))) return rc;
+		}
 		uint64_t budget = 4ull << 30;
 		{
 			size_t free_b = 0, total_b = 0;
@@ -1002,15 +1046,6 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 				uint64_t const avail = mine > reserve ? mine - reserve : 0;
 				budget = std::max<uint64_t>(budget, std::min<uint64_t>(avail, 160ull << 30));
 			}
-		}
-		// streamed rows: 5 bytes per row when a row id and a column number fit 40 bits together (fseq_stream.hpp)
-		c->ss_pack = 0;
-		if (c->use_stream && !c->tune.ss_unpacked)
-		{
-			uint32_t abits = 1, dbits = 1;
-			while ((1ull << abits) < m) ++abits;
-			while ((1ull << dbits) <= p.n) ++dbits;
-			if (abits + dbits <= 40 && abits < 32) c->ss_pack = abits;
 		}
 		uint64_t const state_bytes = c->ss_pack ? (uint64_t) m * 4ull + ss_high_stride(p.m) : (uint64_t) m * 8ull;
 		// first stride tried: 16 columns; 8 where a column is two digit passes (pass 2 replays stride / 2 columns per boundary at
@@ -1056,6 +1091,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->dp.M); dev_free(c, &c->dp.LB); dev_free(c, &c->dp.SZ); dev_free(c, &c->dp.K); dev_free(c, &c->dp.Tb); dev_free(c, &c->dp.Tbv);
 	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
 	dev_free(c, &c->d_cols); dev_free(c, &c->d_grp); dev_free(c, &c->d_src); dev_free(c, &c->d_ss_a_alloc); dev_free(c, &c->d_ss_d_alloc); c->d_ss_a = c->d_ss_d = nullptr;
+	dev_free(c, &c->d_bs_w_alloc); dev_free(c, &c->d_bs_h_alloc); c->d_bs_w = nullptr; c->d_bs_h = nullptr; dev_free(c, &c->d_wgblk); dev_free(c, &c->d_wggrp); c->wg_cap = 0;
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
 	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
@@ -2225,9 +2261,10 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		{
 			uint32_t pack_abits = 0;
 			if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
-			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws_c, c->d_bstate_a, c->d_bstate_d, b0, pack_abits);
+			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws_c, c->d_bstate_a, c->d_bstate_d, b0, pack_abits,
+			                   c->ss_ids ? c->d_bs_w : (uint32_t *) nullptr, c->ss_ids ? c->d_bs_h : (uint8_t *) nullptr);
 			c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
-			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
+			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack | (c->ss_ids ? S2_SS_IDS : 0u));
 		}
 		else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !c->tune.stream_plain_scan)
 			hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) c->stream_staged,
@@ -2443,6 +2480,7 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 		std::vector<uint2> grp;
 		uint64_t const sstr = c->snap_stride;
 		std::vector<uint64_t> starts;
+		std::vector<uint32_t> grp_blk;                            // block whose columns a group replays
 		c->snap_slot.assign(S2, -1);
 		for (size_t i = 0; i < S2; ++i)
 		{
@@ -2454,11 +2492,12 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 			}
 			c->snap_slot[i] = (int64_t) rbs.size();
 			rbs.push_back(rb);
-			uint64_t const blk = std::min<uint64_t>(rb / c->B, c->nblocks);
+			// (states in id form belong to the block that made them: the boundary behind the last column starts inside the last block)
+			uint64_t const blk = std::min<uint64_t>(rb / c->B, c->ss_ids ? c->nblocks - 1u : c->nblocks);
 			uint64_t const q = rb / sstr;
 			uint64_t src = blk, p0 = blk * c->B;
 			if (c->d_ss_a && q >= 1 && q * sstr > p0) { src = q | (1ull << 63); p0 = q * sstr; }
-			if (grp.empty() || srcs.back() != src) { grp.push_back(make_uint2((uint32_t) (rbs.size() - 1), 1u)); srcs.push_back(src); starts.push_back(p0); }
+			if (grp.empty() || srcs.back() != src) { grp.push_back(make_uint2((uint32_t) (rbs.size() - 1), 1u)); srcs.push_back(src); starts.push_back(p0); grp_blk.push_back((uint32_t) blk); }
 			else ++grp.back().y;
 		}
 		for (size_t g = 0; g < grp.size(); ++g)
@@ -2490,6 +2529,44 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 		FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
 		if (grp.empty())
 		{
+		}
+		else if (c->use_stream && c->ss_ids)
+		{
+			// pass 2 on phase C's tile step (fseq_stream2.hpp, S2_SNAP): one workgroup per block that has boundaries, the block's
+			// groups one after the other in the block's own workspace (where V and D0 of its id space still are)
+			std::vector<uint32_t> wgb;
+			std::vector<uint2> wgg;
+			std::vector<uint64_t> wgw;                             // columns a workgroup replays
+			for (size_t g = 0; g < grp.size(); ++g)
+			{
+				if (wgb.empty() || wgb.back() != grp_blk[g]) { wgb.push_back(grp_blk[g]); wgg.push_back(make_uint2((uint32_t) g, 1u)); wgw.push_back(0); }
+				else ++wgg.back().y;
+				wgw.back() += rbs[grp[g].x + grp[g].y - 1] - starts[g] + 2;      // (+ the loads of the start state and the snapshots)
+			}
+			{
+				// the longest first: the workgroups are handed out in launch order, and a long one at the end would run alone
+				std::vector<uint32_t> order(wgb.size());
+				for (uint32_t i = 0; i < order.size(); ++i) order[i] = i;
+				std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return wgw[x] > wgw[y]; });
+				std::vector<uint32_t> b2(wgb.size());
+				std::vector<uint2> g2(wgg.size());
+				for (size_t i = 0; i < order.size(); ++i) { b2[i] = wgb[order[i]]; g2[i] = wgg[order[i]]; }
+				wgb.swap(b2); wgg.swap(g2);
+			}
+			if (c->wg_cap < wgb.size())
+			{
+				if ((rc = dev_alloc(c, &c->d_wgblk, wgb.size()))) return rc;
+				if ((rc = dev_alloc(c, &c->d_wggrp, wgb.size()))) return rc;
+				c->wg_cap = wgb.size();
+			}
+			// (pageable sources: the runtime stages them before the call returns)
+			HIP_TRY(c, hipMemcpyAsync(c->d_wgblk, wgb.data(), wgb.size() * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_wggrp, wgg.data(), wgg.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+			S2SnapArgs SN;
+			SN.wg_block = c->d_wgblk; SN.wg_groups = c->d_wggrp; SN.grp_tasks = c->d_grp; SN.grp_src = c->d_src; SN.task_rb = c->d_cols;
+			SN.snap_a = c->d_snap_a; SN.snap_d = c->d_snap_d; SN.bs_w = c->d_bs_w; SN.bs_h = c->d_bs_h;
+			c->s2.launch_snap(st, (uint32_t) wgb.size(), c->s2_lds, c->d_msa, c->ld, m, n, c->B, c->npass, c->bsh, c->d_ws_c, c->snap_stride, c->d_ss_a, c->d_ss_d, SN);
+			HIP_TRY(c, hipStreamSynchronize(st));                 // (wgb / wgg must outlive their copies)
 		}
 		else if (c->use_stream)
 		{

@@ -841,6 +841,11 @@ __device__ __forceinline__ uint32_t bk_symbol(uint8_t const *msa, size_t ld, uin
 // 65,535 distinct keys: returns BK_WIDE (uniformly, nothing written) at the first one that has, and the caller runs
 // the block again with IdT = uint32_t.
 constexpr uint32_t BK_WIDE = 0xFFFFFFFFu;
+// (measured, BASELINE C4: as a function of its own -- __noinline__ -- the 32-bit form halves the spilled SGPRs of the kernel,
+// 435 -> 224, and phase A gets SLOWER, 340 -> 350 ms: the spills were not what bounds it)
+#ifndef FSEQ_BK_WIDE_INLINE
+#define FSEQ_BK_WIDE_INLINE __forceinline__
+#endif
 template <typename IdT>
 __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
@@ -1020,6 +1025,16 @@ __device__ __forceinline__ uint32_t blockkeys_tree_stream(
 	return sliced;
 }
 
+// The same with 32-bit ids: a block takes it only when a range has more than 65,535 distinct keys (rows that are nearly all
+// distinct).  FSEQ_BK_WIDE_INLINE decides whether it is a function of its own (experiment above)
+__device__ FSEQ_BK_WIDE_INLINE uint32_t blockkeys_tree_stream_wide(
+	char *smem, uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t k0, uint64_t kend, uint32_t bsh, uint32_t cap_words,
+	uint32_t *__restrict__ ws_words, uint32_t *__restrict__ rank_out, uint32_t *__restrict__ keyd_out, uint32_t *__restrict__ nkeys_out,
+	bool pair_leaves, bool limited)
+{
+	return blockkeys_tree_stream<uint32_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws_words, rank_out, keyd_out, nkeys_out, pair_leaves, limited);
+}
+
 // Phase A, LDS-resident rows: workgroup i ranks the block of columns starting at col0 + i * B (outputs indexed by i,
 // as k_colblock<MODE_RANK>).  *sliced counts the blocks in which some merge exceeded the LDS bitmap (diagnostic).
 template <int T>
@@ -1061,8 +1076,8 @@ __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 		uint32_t ns = wide ? BK_WIDE : blockkeys_tree_stream<uint16_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
 		                                                               rank + ob, keyd + ob, nkeys + b, pair_leaves, todo != nullptr);
 		if (ns == BK_WIDE)
-			ns = blockkeys_tree_stream<uint32_t>(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
-			                                     rank + ob, keyd + ob, nkeys + b, pair_leaves, todo != nullptr);
+			ns = blockkeys_tree_stream_wide(smem, msa, ld, m, k0, kend, bsh, cap_words, ws + (size_t) blockIdx.x * ws_per_group,
+			                                rank + ob, keyd + ob, nkeys + b, pair_leaves, todo != nullptr);
 		if (ns == BK_ABORT) { if (threadIdx.x == 0) { todo[b] = 1u; if (sliced) atomicAdd(sliced + 1, 1u); } continue; }
 		if (ns && threadIdx.x == 0 && sliced) atomicAdd(sliced, 1u);
 	}

@@ -86,8 +86,10 @@ __host__ __device__ inline size_t stream2_lds_bytes(uint32_t colbytes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0,
-	uint32_t pack_abits)
+	uint32_t pack_abits, uint32_t *__restrict__ bs_w = nullptr, uint8_t *__restrict__ bs_h = nullptr)
 {
+	// bs_w / bs_h (packed rows only): a copy of the block's start state in id form -- what pass 2 replays from when no stride
+	// state of the block lies in front of a boundary (k_columns_stream2<.., S2_SNAP>); block b at bs_w + b * m, bs_h + b * ss_high_stride(m)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	Carver cv{smem};
 	StreamLds &L = *cv.take<StreamLds>(1);
@@ -153,8 +155,11 @@ __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 		}
 		if (pack_abits)
 		{
-			w[i] = sa[i] | (lo << pack_abits);
-			reinterpret_cast<uint8_t *>(w + 2u * (size_t) m)[i] = (uint8_t) (lo >> (32u - pack_abits));
+			uint32_t const pw = sa[i] | (lo << pack_abits);
+			uint8_t const ph = (uint8_t) (lo >> (32u - pack_abits));
+			w[i] = pw;
+			reinterpret_cast<uint8_t *>(w + 2u * (size_t) m)[i] = ph;
+			if (bs_w) { bs_w[(size_t) blk * m + i] = pw; bs_h[(size_t) blk * ss_high_stride(m) + i] = ph; }
 		}
 		else pairs0[i] = make_uint2(sa[i], lo);
 	}
@@ -358,13 +363,33 @@ __device__ __forceinline__ void s2_tile_step(
 // ------------------------------------------------------------------------------------------------
 // (at least four waves per SIMD: two workgroups of 512 threads -- or three to four of 256 -- share a CU, and what one of
 // them waits for at its barriers the others compute)
-template <int T, int E, bool PACK>
+// MODE S2_SNAP: pass 2 with the same tile step -- update_pbwt_task::execute (update_pbwt_task.cc:13-35): the (a, d) at the merged
+// boundaries.  Phase C leaves its stride states (and every block's start state, k_columns_stream2_prologue) in ID form,
+// i.e. as the packed rows of its workspace, so a boundary is reached by replaying the columns from the nearest such state
+// of its block in the block's id space (V and D0 are still in the block's workspace), with nothing but the partition: no
+// histogram, no lists.  One workgroup per block that has boundaries; it takes the block's groups of boundaries (those that
+// share a start state) one after the other in the block's own workspace.  BASELINE C4: pass 2 157 -> see DESIGN.md.
+enum { S2_COLUMNS = 0, S2_SNAP = 1 };
+constexpr uint32_t S2_SS_IDS = 0x80000000u;                   // ss_pack flag: the stride states hold value ids (packed rows), not divergences
+struct S2SnapArgs {
+	uint32_t const *wg_block;            // [grid] block of every workgroup
+	uint2 const *wg_groups;              // [grid] {first group, groups}
+	uint2 const *grp_tasks;              // [groups] {first boundary, boundaries}: the boundaries that share a start state, ascending
+	uint64_t const *grp_src;             // [groups] bit 63 set: stride state q (the state at column q * snap_stride), else the block's start state
+	uint64_t const *task_rb;             // [boundaries] column of every boundary
+	uint32_t *snap_a, *snap_d;           // [boundaries][m]
+	uint32_t const *bs_w;                // block start states in id form: block b at bs_w + b * m, bs_h + b * ss_high_stride(m)
+	uint8_t const *bs_h;
+};
+
+template <int T, int E, bool PACK, int MODE = S2_COLUMNS>
 __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
 	uint32_t Lseg, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch, uint32_t ss_pack)
+	uint32_t *done_host, uint32_t epoch, uint32_t ss_pack, S2SnapArgs const SN)
 {
+	static_assert(MODE == S2_COLUMNS || PACK, "pass 2 on the tile step replays packed rows");
 	constexpr int KS = s2_key_shift(T * E);
 	constexpr uint32_t TILE = (uint32_t) T * E;
 	static_assert(E % 2 == 0, "a thread loads its rows as 16-byte pieces of two (a, d) pairs");
@@ -379,7 +404,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint32_t const tid = threadIdx.x;
 	uint32_t const lane = lane_id();
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	uint32_t const blk = blockIdx.x + block0;
+	uint32_t const blk = MODE == S2_SNAP ? SN.wg_block[blockIdx.x] : blockIdx.x + block0;
 	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
 	uint2 *pairs[2] = {reinterpret_cast<uint2 *>(w), reinterpret_cast<uint2 *>(w + 2u * (size_t) m)};
 	uint32_t *words[2] = {w, w + (size_t) m};                                 // PACK
@@ -402,7 +427,47 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	long long s2_seg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, s2_last = clock64();
 #endif
 
-	for (uint32_t j = 0; j < nb; ++j)
+	// phase C: the block's columns once.  Pass 2: the block's groups of boundaries, each from its start state to its last boundary
+	uint2 const wg_groups = MODE == S2_SNAP ? SN.wg_groups[blockIdx.x] : make_uint2(0u, 1u);
+	for (uint32_t gi = 0; gi < wg_groups.y; ++gi)
+	{
+	uint32_t j_begin = 0, j_end = nb;
+	uint32_t t_first = 0, t_count = 0, t_next = 0;
+	if (MODE == S2_SNAP)
+	{
+		uint2 const gt = SN.grp_tasks[wg_groups.x + gi];
+		t_first = gt.x; t_count = gt.y;
+		uint64_t const src = SN.grp_src[wg_groups.x + gi];
+		uint64_t const sidx = src & ~(1ull << 63);
+		uint32_t const *sw;
+		uint8_t const *sh;
+		if (src >> 63) { j_begin = (uint32_t) (sidx * snap_stride - k0); sw = ss_a + sidx * (size_t) m; sh = reinterpret_cast<uint8_t const *>(ss_d) + sidx * ss_high_stride(m); }
+		else { j_begin = 0; sw = SN.bs_w + (size_t) blk * m; sh = SN.bs_h + (size_t) blk * ss_high_stride(m); }
+		j_end = (uint32_t) (SN.task_rb[t_first + t_count - 1u] - k0);
+		__syncthreads();                                          // (the group before may still be read: its last snapshot)
+		cur = 0;
+		for (uint32_t i = tid; i < m; i += T) { words[0][i] = sw[i]; highs[0][i] = sh[i]; }
+		__syncthreads();
+	}
+	// a boundary at column k (the state in front of it): ids back to divergences, unpacked
+	auto snapshot_if_requested = [&](uint64_t k) {
+		if (MODE == S2_SNAP && t_next < t_count && SN.task_rb[t_first + t_next] == k)
+		{
+			size_t const ob = (size_t) (t_first + t_next) * m;
+			uint32_t const *PW = words[cur];
+			uint8_t const *PH = highs[cur];
+			for (uint32_t i = tid; i < m; i += T)
+			{
+				uint32_t const pw = PW[i];
+				uint32_t const id = (pw >> abits) | ((uint32_t) PH[i] << hshift);
+				SN.snap_a[ob + i] = pw & amask;
+				SN.snap_d[ob + i] = id < D0 ? V[id] : (uint32_t) (k0 + (id - D0) + 1u);
+			}
+			++t_next;
+		}
+	};
+	snapshot_if_requested(k0 + j_begin);
+	for (uint32_t j = j_begin; j < j_end; ++j)
 	{
 		{
 			uint8_t const *col = msa + (k0 + j) * ld;
@@ -492,7 +557,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 							stage_h[lp[e]] = (uint8_t) (dnew[e] >> hshift);
 						}
 						else if (!(FSEQ_S2_SKIP & 16)) stage[lp[e]] = make_uint2(a[e], dnew[e]);
-						if (!(FSEQ_S2_SKIP & 2) && d[e] != dnew[e])
+						if (MODE == S2_COLUMNS && !(FSEQ_S2_SKIP & 2) && d[e] != dnew[e])
 						{
 							(void) __hip_atomic_fetch_add(&cnt[d[e]], 0xFFFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 							(void) __hip_atomic_fetch_add(&cnt[dnew[e]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -519,6 +584,10 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 						uint32_t const j0 = g * 256u;
 						if (!FULL && j0 >= tile_n) break;
 						uint4 const v = *reinterpret_cast<uint4 const *>(stage_w + j0 + 4u * lane);
+						// the high bytes of the same 256 slots: four per lane, one 4-byte store at whatever byte the run stands at (the
+						// memory pipeline takes unaligned dwords; one byte per lane and store instruction was 8 of a thread's 10 stores
+						// per tile, each with its own LDS read and scalar bucket selection)
+						uint32_t const hv = *reinterpret_cast<uint32_t const *>(stage_h + j0 + 4u * lane);
 						if (FULL && g != sg1 && g != sg2 && g != sg3)
 						{
 							uint32_t sh = gsh[0];
@@ -527,6 +596,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 							sh = ge(g, gb3) ? gsh[3] : sh;
 							u32x4 const vv = {v.x, v.y, v.z, v.w};
 							__builtin_amdgcn_raw_buffer_store_b128(vv, rd, lane * 16u, (j0 + sh) * 4u, 0);
+							__builtin_amdgcn_raw_buffer_store_b32(hv, rdh, lane * 4u, j0 + sh, 0);
 						}
 						else
 						{
@@ -540,37 +610,11 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 								sh = jj >= lofs[2] ? gsh[2] : sh;
 								sh = jj >= lofs[3] ? gsh[3] : sh;
 								if (FULL || jj < tile_n)
+								{
 									__builtin_amdgcn_raw_buffer_store_b32(vq[h], rd, (jj + sh) * 4u, 0u, 0);
+									__builtin_amdgcn_raw_buffer_store_b8((uint8_t) (hv >> (8 * h)), rdh, jj + sh, 0u, 0);
+								}
 							}
-						}
-					}
-					uint32_t const hb1 = (lofs[1] + 63u) >> 6, hb2 = (lofs[2] + 63u) >> 6, hb3 = (lofs[3] + 63u) >> 6;
-					uint32_t const hs1 = (lofs[1] & 63u) ? (lofs[1] >> 6) : 0xFFFFFFFFu, hs2 = (lofs[2] & 63u) ? (lofs[2] >> 6) : 0xFFFFFFFFu,
-					               hs3 = (lofs[3] & 63u) ? (lofs[3] >> 6) : 0xFFFFFFFFu;
-#pragma unroll
-					for (int e = 0; e < E; ++e)
-					{
-						uint32_t const g = (uint32_t) e * (T / WAVE) + wave;
-						uint32_t const j0 = g * 64u;
-						if (!FULL && j0 >= tile_n) break;
-						uint8_t const hv = stage_h[j0 + lane];
-						if (FULL && g != hs1 && g != hs2 && g != hs3)
-						{
-							uint32_t sh = gsh[0];
-							sh = ge(g, hb1) ? gsh[1] : sh;
-							sh = ge(g, hb2) ? gsh[2] : sh;
-							sh = ge(g, hb3) ? gsh[3] : sh;
-							__builtin_amdgcn_raw_buffer_store_b8(hv, rdh, lane, j0 + sh, 0);
-						}
-						else
-						{
-							uint32_t const jj = j0 + lane;
-							uint32_t sh = gsh[0];
-							sh = jj >= lofs[1] ? gsh[1] : sh;
-							sh = jj >= lofs[2] ? gsh[2] : sh;
-							sh = jj >= lofs[3] ? gsh[3] : sh;
-							if (FULL || jj < tile_n)
-								__builtin_amdgcn_raw_buffer_store_b8(hv, rdh, jj + sh, 0u, 0);
 						}
 					}
 				}
@@ -633,7 +677,15 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 		uint32_t const *PW = words[cur];
 		uint8_t const *PH = highs[cur];
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)
-		if (ss_a && (k0 + j + 1) % snap_stride == 0)
+		if (MODE == S2_COLUMNS && ss_a && (k0 + j + 1) % snap_stride == 0 && (ss_pack & S2_SS_IDS))
+		{
+			// (id form: the packed rows as they are -- pass 2 replays them in this block's id space)
+			size_t const q = (size_t) ((k0 + j + 1) / snap_stride), ob = q * m;
+			uint8_t *sh = reinterpret_cast<uint8_t *>(ss_d) + q * ss_high_stride(m);
+			if constexpr (PACK)
+				for (uint32_t i = tid; i < m; i += T) { ss_a[ob + i] = PW[i]; sh[i] = PH[i]; }
+		}
+		else if (MODE == S2_COLUMNS && ss_a && (k0 + j + 1) % snap_stride == 0)
 		{
 			size_t const q = (size_t) ((k0 + j + 1) / snap_stride), ob = q * m;
 			uint8_t *sh = reinterpret_cast<uint8_t *>(ss_d) + q * ss_high_stride(m);
@@ -650,7 +702,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 		S2_STAMP(8);
 		// ---- emit the top of the histogram (same list format as k_columns); counters were updated
 		// with device-scope atomics, read them past L1
-		if (wave == 0 && !(FSEQ_S2_SKIP & 4))
+		if (MODE == S2_COLUMNS && wave == 0 && !(FSEQ_S2_SKIP & 4))
 		{
 			// LQ ids per lane and step (the id space is sparse -- one id per column and boundary value, most of them with
 			// count 0 by now -- and every step is a round trip to L2: with one id per lane the list was ~20 % of a column)
@@ -716,8 +768,10 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 			}
 		}
 		S2_STAMP(9);
+		snapshot_if_requested(k0 + j + 1u);
 		__syncthreads();
 		S2_STAMP(10);
+	}
 	}
 #ifdef FSEQ_S2_STAMPS
 	if (lane == 0 && (blockIdx.x == 7 || blockIdx.x == 200) && nb)
@@ -725,7 +779,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 		       "write-out %lld | counts + first load %lld | pass tail barrier %lld | snapshot %lld | list %lld | column end barrier %lld | column staged %lld\n", blockIdx.x, wave,
 		       s2_seg[0] / nb, s2_seg[1] / nb, s2_seg[2] / nb, s2_seg[3] / nb, s2_seg[4] / nb, s2_seg[5] / nb, s2_seg[6] / nb, s2_seg[7] / nb, s2_seg[8] / nb, s2_seg[9] / nb, s2_seg[10] / nb, s2_seg[11] / nb);
 #endif
-	publish_block_done(done_host, blk, epoch);
+	if (MODE == S2_COLUMNS) publish_block_done(done_host, blk, epoch);
 }
 
 } // namespace fseq

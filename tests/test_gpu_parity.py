@@ -213,6 +213,16 @@ def test_streamed_phase_b_forms(pkg, monkeypatch, form):
             assert np.array_equal(a, p.a) and np.array_equal(d, p.d), (form, m, n, b)
 
 
+def test_streamed_pass_2_from_absolute_states(pkg, monkeypatch):
+    """Streamed rows: pass 2 replays the columns from phase C's stride states in id form on phase C's own tile step (the
+    default, every other streamed test); FSEQ_SS_ABSOLUTE keeps the states as divergences and pass 2 on the first form's
+    tile step -- same boundary states, two blocks with many segments, sigma = 16 and a shape with few stride states."""
+    monkeypatch.setenv("FSEQ_SS_ABSOLUTE", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(11300, 2400, 4, 3, 40, 2e-3, 45, 0, 1200), (20000, 300, 15, 16, 100, 2e-4, 42, 1, 50), (12000, 3000, 10, 12, 200, 3e-4, 46, 0, 12)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        compare_long(pkg, msa, L, check_dp=False, block_len=B)
+
+
 def test_phase_b_and_pass_2_with_the_plain_scan(pkg, monkeypatch):
     """Phase B and pass 2 scan keys (count << shift | divergence) while n fits the shift of their configuration -- every
     test shape does; FSEQ_PLAIN_SCAN keeps the has-based scan, which long inputs (BASELINE C5: n = 10^6 on the
