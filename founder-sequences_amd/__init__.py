@@ -79,10 +79,10 @@ EXPORTS = [
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
     "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile", "fseq_debug_set_tuning",
-    "fseq_shard_abort", "fseq_debug_dp_owned",
+    "fseq_shard_abort", "fseq_debug_dp_owned", "fseq_debug_clock",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
-DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_dp_owned", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
+DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_dp_owned", "fseq_debug_clock", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
 
 FSEQ_E_PEER = 6
 STAGE_TRACEBACK, STAGE_MERGE, STAGE_SAMPLES = 0, 1, 2
@@ -161,6 +161,7 @@ def load_library():
     L.fseq_set_memory_budget.argtypes = [vp, u64]
     L.fseq_shard_abort.argtypes = [vp, C.c_int]
     L.fseq_debug_dp_owned.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.fseq_debug_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     _lib = L
     return L
 
@@ -510,6 +511,12 @@ class SegmentationContext:
         f, w = C.c_int(), C.c_int()
         self._check(self.L.fseq_debug_dp_owned(self.h, C.byref(a), C.byref(b), C.byref(f), C.byref(w)))
         return a.value, b.value, bool(f.value), bool(w.value)
+
+    def debug_clock(self):
+        """(GHz, workgroups) of phase C's kernel in the last run -- diagnostic builds (-DFSEQ_CLOCK_STAMPS) only."""
+        g, n = C.c_double(), C.c_uint32()
+        self._check(self.L.fseq_debug_clock(self.h, C.byref(g), C.byref(n)))
+        return g.value, n.value
 
     def debug_block_state(self, b):
         a = np.zeros(self.m, dtype=np.uint32)

@@ -1125,6 +1125,10 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	if ((rc = dev_alloc(c, &d_raw, total + 16))) return rc;
 	if ((rc = dev_alloc(c, &d_present, 8))) { dev_free(c, &d_raw); return rc; }
 	auto cleanup = [&]() { dev_free(c, &d_raw); dev_free(c, &d_present); };
+	// (one copy per row from the caller's pageable memory: the runtime stages them at ~32 GB/s.  Measured and dropped in round 4:
+	// eight host threads filling pinned staging buffers of their own, each with its stream -- BASELINE C3's 2.5 GB in 77 - 86 ms
+	// against 78, C2's 250 MB in 39 against 30: the host copies into the pinned buffers are no faster than the runtime's own
+	// staging, and the buffers cost ~10 ms to pin)
 	for (uint32_t r = 0; r < p.m && nloc; ++r)
 	{
 		hipError_t const e = hipMemcpyAsync(d_raw + (size_t) r * nloc, rows[r] + k_lo, nloc, hipMemcpyHostToDevice, c->stream);
@@ -3178,6 +3182,31 @@ int fseq_debug_dp_owned(fseq_ctx *c, uint64_t *first, uint64_t *last, int *final
 	return FSEQ_OK;
 }
 
+int fseq_debug_clock(fseq_ctx *c, double *ghz, uint32_t *workgroups)
+{
+	if (!c || !ghz) return FSEQ_E_ARG;
+#ifdef FSEQ_CLOCK_STAMPS
+	(void) hipSetDevice(c->p.device);
+	std::vector<unsigned long long> st((size_t) FSEQ_CLOCK_SLOTS * 4);
+	HIP_TRY(c, hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_clock_stamps), st.size() * 8));
+	std::vector<double> f;
+	for (uint32_t i = 0; i < FSEQ_CLOCK_SLOTS; ++i)
+	{
+		unsigned long long const t0 = st[4 * i], r0 = st[4 * i + 1], t1 = st[4 * i + 2], r1 = st[4 * i + 3];
+		if (t1 > t0 && r1 > r0) f.push_back((double) (t1 - t0) / (double) (r1 - r0) * 0.1);      // cycles per 10 ns = GHz x 10
+	}
+	if (f.empty()) return fail(c, FSEQ_E_ARG, "no clock stamps: run a long-path segmentation first");
+	std::nth_element(f.begin(), f.begin() + f.size() / 2, f.end());
+	*ghz = f[f.size() / 2];
+	if (workgroups) *workgroups = (uint32_t) f.size();
+	return FSEQ_OK;
+#else
+	(void) workgroups;
+	*ghz = 0.0;
+	return fail(c, FSEQ_E_UNSUPPORTED, "built without -DFSEQ_CLOCK_STAMPS (the product kernels execute no stamp)");
+#endif
+}
+
 int fseq_debug_block_state(fseq_ctx *c, uint64_t block_idx, uint32_t *a_out, uint32_t *d_out)
 {
 	if (!c || !c->have_result || c->res.short_path || block_idx > c->nblocks) return FSEQ_E_ARG;
@@ -3453,18 +3482,40 @@ int fseq_write_founders(fseq_ctx *c, uint8_t const *const *rows, uint32_t const 
 	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
 	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the founders output file");
 	size_t const X = c->res.max_segment_size, S = c->segments.size();
-	for (size_t row = 0; row < X; ++row)                       // join_context.cc:341-356
+	// join_context.cc:341-356: line r = the segments' substrings of the rows permutations[s][r], one after the other.
+	// The lines are put together in memory -- a batch of them at a time, on a few host threads: a line is S pieces of a
+	// few hundred bytes from S different input rows -- and go out in one write per batch (one fwrite per piece was 41 of a
+	// drop-in BASELINE C3 run's ~150 ms, profiles/r03_e2e_C3_greedy.json).
+	size_t const line = (size_t) c->p.n + 1;
+	size_t const batch = std::max<size_t>(1, std::min<size_t>(X, (size_t) (256u << 20) / line));
+	std::vector<char> buf;
+	try { buf.resize(batch * line); } catch (std::bad_alloc const &) { if (f != stdout) fclose(f); return fail(c, FSEQ_E_OOM, "founders output buffer"); }
+	bool ok = true;
+	for (size_t r0 = 0; r0 < X && ok; r0 += batch)
 	{
-		for (size_t s = 0; s < S; ++s)
-		{
-			uint32_t const idx = permutations[s * X + row];
-			fseq_segment const &sg = c->segments[s];
-			fwrite(rows[idx] + sg.lb, 1, sg.rb - sg.lb, f);
-		}
-		fputc('\n', f);
+		size_t const r1 = std::min(X, r0 + batch);
+		unsigned const nth = (unsigned) std::max<size_t>(1, std::min<size_t>({(size_t) std::thread::hardware_concurrency(), (size_t) 8, r1 - r0}));
+		auto work = [&](unsigned t) {
+			for (size_t row = r0 + t; row < r1; row += nth)
+			{
+				char *out = buf.data() + (row - r0) * line;
+				for (size_t s = 0; s < S; ++s)
+				{
+					fseq_segment const &sg = c->segments[s];
+					memcpy(out + sg.lb, rows[permutations[s * X + row]] + sg.lb, sg.rb - sg.lb);
+				}
+				out[line - 1] = '\n';
+			}
+		};
+		std::vector<std::thread> ths;
+		for (unsigned t = 1; t < nth; ++t) ths.emplace_back(work, t);
+		work(0);
+		for (auto &th : ths) th.join();
+		ok = fwrite(buf.data(), 1, (r1 - r0) * line, f) == (r1 - r0) * line;
 	}
 	fflush(f);
 	if (f != stdout) fclose(f);
+	if (!ok) return fail(c, FSEQ_E_ARG, "writing the founders output file failed");
 	return FSEQ_OK;
 }
 

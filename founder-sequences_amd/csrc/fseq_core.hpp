@@ -868,6 +868,26 @@ __device__ __forceinline__ void partition_step(
 // stores the flag into host-coherent memory.  The consumer is never a running kernel: the host polls the
 // flag and only then launches the kernel that reads the data, whose dispatch carries the acquire
 // (MI355X_MICROARCH.md, inter-workgroup visibility: producer form; HSA memory model for the rest).
+// -DFSEQ_CLOCK_STAMPS (diagnostic build only; the product kernels execute no stamp): the in-kernel clock of phase C's
+// kernels, MI355X_MICROARCH.md "DVFS give-back" item 6 -- every workgroup stamps s_memtime (shader cycles) and
+// s_memrealtime (100 MHz) once at its start and once at its end; clock = d(memtime) / d(memrealtime) x 100 MHz, the median
+// over the workgroups (fseq_debug_clock).  The stamps go to a buffer of their own that nothing else reads.
+#ifdef FSEQ_CLOCK_STAMPS
+constexpr uint32_t FSEQ_CLOCK_SLOTS = 8192;
+__device__ unsigned long long g_clock_stamps[FSEQ_CLOCK_SLOTS][4];
+__device__ __forceinline__ void clock_stamp(uint32_t slot, int which)
+{
+	if (threadIdx.x == 0 && slot < FSEQ_CLOCK_SLOTS)
+	{
+		g_clock_stamps[slot][2 * which] = __builtin_amdgcn_s_memtime();
+		g_clock_stamps[slot][2 * which + 1] = __builtin_amdgcn_s_memrealtime();
+	}
+}
+#define FSEQ_CLOCK_STAMP(slot, which) clock_stamp((slot), (which))
+#else
+#define FSEQ_CLOCK_STAMP(slot, which) do { } while (0)
+#endif
+
 __device__ __forceinline__ void publish_block_done(uint32_t *done_host, uint32_t index, uint32_t epoch)
 {
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

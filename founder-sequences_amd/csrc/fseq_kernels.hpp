@@ -714,6 +714,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint32_t *done_host, uint32_t epoch)
 {
 	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
+	FSEQ_CLOCK_STAMP(blockIdx.x, 0);
 	constexpr uint32_t CAP = T * E;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	// [a_l][d_l][sym0][sym1][cnt_l] are contiguous: the prologue's sort buffer (N2 < 2m words) overlays them
@@ -1021,6 +1022,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	if (lane_id() == 0 && wave_id() == 0 && (blockIdx.x == 100 || blockIdx.x == 3000))
 		printf("kc stamps block %u list: %lld rounds x 100 per column, %lld cycles per column, %lld entries x 100 per column, X %u D0 %u\n", blockIdx.x, kcs.acc[4] * 100 / nb, kcs.acc[5] / nb, kcs.acc[6] * 100 / nb, X, D0);
 #endif
+	FSEQ_CLOCK_STAMP(blockIdx.x, 1);
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
 	publish_block_done(done_host, blockIdx.x + block0, epoch);
 }

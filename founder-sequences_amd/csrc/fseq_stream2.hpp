@@ -390,6 +390,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint32_t *done_host, uint32_t epoch, uint32_t ss_pack, S2SnapArgs const SN)
 {
 	static_assert(MODE == S2_COLUMNS || PACK, "pass 2 on the tile step replays packed rows");
+	if (MODE == S2_COLUMNS) FSEQ_CLOCK_STAMP(blockIdx.x, 0);
 	constexpr int KS = s2_key_shift(T * E);
 	constexpr uint32_t TILE = (uint32_t) T * E;
 	static_assert(E % 2 == 0, "a thread loads its rows as 16-byte pieces of two (a, d) pairs");
@@ -779,6 +780,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 		       "write-out %lld | counts + first load %lld | pass tail barrier %lld | snapshot %lld | list %lld | column end barrier %lld | column staged %lld\n", blockIdx.x, wave,
 		       s2_seg[0] / nb, s2_seg[1] / nb, s2_seg[2] / nb, s2_seg[3] / nb, s2_seg[4] / nb, s2_seg[5] / nb, s2_seg[6] / nb, s2_seg[7] / nb, s2_seg[8] / nb, s2_seg[9] / nb, s2_seg[10] / nb, s2_seg[11] / nb);
 #endif
+	if (MODE == S2_COLUMNS) FSEQ_CLOCK_STAMP(blockIdx.x, 1);
 	if (MODE == S2_COLUMNS) publish_block_done(done_host, blk, epoch);
 }
 

@@ -35,6 +35,11 @@ int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_
 int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
                     uint32_t *index_hbm, uint32_t *index_lds);
 
+/* Diagnostic builds only (-DFSEQ_CLOCK_STAMPS; FSEQ_E_UNSUPPORTED otherwise): the clock phase C's kernel held in the last run,
+ * d(s_memtime) / d(s_memrealtime) x 100 MHz stamped once around every workgroup, the median over the workgroups
+ * (MI355X_MICROARCH.md, "DVFS give-back" item 6).  tools/clock_probe.py. */
+int  fseq_debug_clock(fseq_ctx *ctx, double *ghz, uint32_t *workgroups);
+
 /* The library's diagnostic knobs (FSEQ_* names, listed in csrc/fseq_api.hip `struct Tuning`): a context reads them
  * from the environment once, at fseq_create; this sets one afterwards (value NULL = off).  Every knob selects among
  * exact alternatives; results never depend on them.  Call before the first fseq_run_segmentation (a later call drops the work buffers and
