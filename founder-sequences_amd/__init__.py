@@ -79,10 +79,10 @@ EXPORTS = [
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
     "fseq_set_progress", "fseq_step_max", "fseq_current_step", "fseq_set_memory_budget", "fseq_write_segments_host", "fseq_get_join_profile", "fseq_debug_set_tuning",
-    "fseq_shard_abort", "fseq_debug_dp_owned", "fseq_debug_clock",
+    "fseq_shard_abort", "fseq_debug_dp_owned", "fseq_debug_clock", "fseq_debug_ranges",
 ]
 # ... of which include/fseq_debug.h declares these (intermediate state for tests, not part of the drop-in boundary)
-DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_dp_owned", "fseq_debug_clock", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
+DEBUG_EXPORTS = ["fseq_debug_dp", "fseq_debug_dp_owned", "fseq_debug_clock", "fseq_debug_ranges", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_debug_rmq", "fseq_debug_dp_schedule", "fseq_debug_set_tuning"]
 
 FSEQ_E_PEER = 6
 STAGE_TRACEBACK, STAGE_MERGE, STAGE_SAMPLES = 0, 1, 2
@@ -162,6 +162,7 @@ def load_library():
     L.fseq_shard_abort.argtypes = [vp, C.c_int]
     L.fseq_debug_dp_owned.argtypes = [vp, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.fseq_debug_clock.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.fseq_debug_ranges.argtypes = [C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -187,6 +188,13 @@ def greedy_match_host(m, max_segment_size, lb, rb, a, d):
     if rc != FSEQ_OK:
         raise FseqError(rc, L.fseq_strerror(rc).decode())
     return perm
+
+
+def debug_ranges():
+    """(pushes, pops, built_with_roctx): the phase ranges this process has opened and closed so far."""
+    a, b, w = C.c_uint64(), C.c_uint64(), C.c_int()
+    load_library().fseq_debug_ranges(C.byref(a), C.byref(b), C.byref(w))
+    return a.value, b.value, bool(w.value)
 
 
 def debug_rmq(keys, beg, end, device=0):

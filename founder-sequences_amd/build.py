@@ -24,9 +24,14 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in DEPS)
 
 
+LAST_ACTION = {}        # target -> "compiled" | "reused": what the last build() / build_cli() / build_aux() call did
+
+
 def build(force=False, verbose=False):
     if not force and not needs_build():
+        LAST_ACTION.setdefault("libfseq_hip.so", "reused")       # (a later call in the same process finds it fresh: it stays "compiled")
         return OUT
+    LAST_ACTION["libfseq_hip.so"] = "compiled"
     # FSEQ_HIPCC_FLAGS: extra flags for diagnostic builds (-DFSEQ_DP_STAMPS, -DFSEQ_DP_STATS)
     # roctx ranges per phase when the image has the library (rocprofv3 --marker-trace shows them)
     roctx = ["-DFSEQ_WITH_ROCTX", "-L/opt/rocm/lib", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"] \
@@ -48,7 +53,9 @@ def build_cli(force=False):
     build()
     deps = [CLI_SRC, OUT, os.path.join(HERE, "host", "fseq_shard_rccl.hpp"), os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
     if not force and os.path.exists(CLI_OUT) and os.path.getmtime(CLI_OUT) >= max(os.path.getmtime(d) for d in deps):
+        LAST_ACTION.setdefault("founder_sequences", "reused")
         return CLI_OUT
+    LAST_ACTION["founder_sequences"] = "compiled"
     os.makedirs(os.path.dirname(CLI_OUT), exist_ok=True)
     # --gpus N shards one alignment over the node's GPUs: RCCL (ncclCommInitAll / ncclAllReduce) bound to the C ABI's
     # exchange callback in host/fseq_shard_rccl.hpp, so the front end links librccl and the HIP runtime itself
@@ -72,6 +79,9 @@ def build_aux(force=False):
         deps = [src, os.path.join(HERE, "host", "aux_common.hpp")]
         if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
             subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", src, "-o", out], check=True)
+            LAST_ACTION[name] = "compiled"
+        else:
+            LAST_ACTION.setdefault(name, "reused")
         outs.append(out)
     return outs
 

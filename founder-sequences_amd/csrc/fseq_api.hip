@@ -29,13 +29,16 @@
 #include <unordered_map>
 #include <vector>
 
+// One range per phase (rocprofv3 --marker-trace shows them when the library is built against roctx).  The pushes and pops
+// are counted, so a test can tell that the ranges are there and balanced without a profiler (fseq_debug_ranges).
+static std::atomic<uint64_t> g_range_pushes{0}, g_range_pops{0};
 #ifdef FSEQ_WITH_ROCTX
 #include <rocprofiler-sdk-roctx/roctx.h>
-#define FSEQ_RANGE_PUSH(name) (void) roctxRangePushA(name)
-#define FSEQ_RANGE_POP() (void) roctxRangePop()
+#define FSEQ_RANGE_PUSH(name) do { g_range_pushes.fetch_add(1, std::memory_order_relaxed); (void) roctxRangePushA(name); } while (0)
+#define FSEQ_RANGE_POP() do { g_range_pops.fetch_add(1, std::memory_order_relaxed); (void) roctxRangePop(); } while (0)
 #else
-#define FSEQ_RANGE_PUSH(name) do { } while (0)
-#define FSEQ_RANGE_POP() do { } while (0)
+#define FSEQ_RANGE_PUSH(name) do { g_range_pushes.fetch_add(1, std::memory_order_relaxed); } while (0)
+#define FSEQ_RANGE_POP() do { g_range_pops.fetch_add(1, std::memory_order_relaxed); } while (0)
 #endif
 
 using namespace fseq;
@@ -3179,6 +3182,18 @@ int fseq_debug_dp_owned(fseq_ctx *c, uint64_t *first, uint64_t *last, int *final
 	if (last) *last = hi;
 	if (final_cell) *final_cell = fin;
 	if (whole_arrays) *whole_arrays = whole;
+	return FSEQ_OK;
+}
+
+int fseq_debug_ranges(uint64_t *pushes, uint64_t *pops, int *with_roctx)
+{
+	if (pushes) *pushes = g_range_pushes.load(std::memory_order_relaxed);
+	if (pops) *pops = g_range_pops.load(std::memory_order_relaxed);
+#ifdef FSEQ_WITH_ROCTX
+	if (with_roctx) *with_roctx = 1;
+#else
+	if (with_roctx) *with_roctx = 0;
+#endif
 	return FSEQ_OK;
 }
 

@@ -35,6 +35,10 @@ int  fseq_debug_column_list(fseq_ctx *ctx, uint64_t c, uint32_t *values, uint32_
 int  fseq_debug_rmq(int device, uint32_t const *keys, uint32_t count, uint32_t const *beg, uint32_t const *end, uint32_t n_queries,
                     uint32_t *index_hbm, uint32_t *index_lds);
 
+/* Phase ranges (roctx: rocprofv3 --marker-trace) pushed and popped by this process so far, and whether the library was built
+ * against roctx: a run of the long path adds four of each (phases A + B, phases C + D, traceback + merge, pass 2). */
+int  fseq_debug_ranges(uint64_t *pushes, uint64_t *pops, int *with_roctx);
+
 /* Diagnostic builds only (-DFSEQ_CLOCK_STAMPS; FSEQ_E_UNSUPPORTED otherwise): the clock phase C's kernel held in the last run,
  * d(s_memtime) / d(s_memrealtime) x 100 MHz stamped once around every workgroup, the median over the workgroups
  * (MI355X_MICROARCH.md, "DVFS give-back" item 6).  tools/clock_probe.py. */

@@ -1081,6 +1081,24 @@ def test_progress_counters_and_callback(pkg):
     assert len(seen) == len(stages)
 
 
+def test_phase_ranges_are_pushed_and_balanced(pkg):
+    """Every phase of a long-path run is an roctx range (rocprofv3 --marker-trace): four pushes and four pops per run, by
+    the library's own count; the default build links roctx."""
+    msa = fso.synth_msa(fso.synth_spec(22, 8, 200, 2e-3, 0), 300, 2000)
+    ctx = pkg.SegmentationContext(300, 2000, 25)
+    ctx.set_sequences(msa)
+    p0, q0, with_roctx = pkg.debug_ranges()
+    ctx.run()
+    p1, q1, _ = pkg.debug_ranges()
+    assert p1 - p0 == 4 and q1 - q0 == 4
+    ctx.run()
+    p2, q2, _ = pkg.debug_ranges()
+    assert p2 - p1 == 4 and q2 - q1 == 4 and p2 == q2
+    import os
+    if os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so") and os.path.exists("/opt/rocm/include/rocprofiler-sdk-roctx/roctx.h"):
+        assert with_roctx
+
+
 def test_tuning_is_per_context_and_read_once(pkg, monkeypatch):
     """The FSEQ_* knobs are read from the environment when a context is created (never on the run path) and can be
     set per context: a context created under FSEQ_PHASE_A_CLASSIC keeps the column sweep after the variable is gone,
