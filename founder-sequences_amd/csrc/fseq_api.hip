@@ -245,6 +245,7 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
+constexpr uint64_t STREAM_BLOCK_TARGET = 1600;   // columns per block the streamed regime aims for (prepare_geometry / block_geometry)
 #ifndef FSEQ_X_FLOOR_VALUE
 #define FSEQ_X_FLOOR_VALUE 63u
 #endif
@@ -694,7 +695,9 @@ void block_geometry(fseq_ctx *c)
 		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
 		if (ncu < 1) ncu = 256;
 		uint64_t const cols = (p.n + sh.world - 1) / sh.world;
-		uint64_t k = (cols + (uint64_t) ncu * 4096 - 1) / ((uint64_t) ncu * 4096);
+		// (streamed rows: blocks of ~1,600 columns, see prepare_geometry)
+		uint64_t const per_cu_cols = streamed ? STREAM_BLOCK_TARGET : 4096u;
+		uint64_t k = std::max<uint64_t>(1, (cols + (uint64_t) ncu * per_cu_cols / 2) / ((uint64_t) ncu * per_cu_cols));
 		// (the second form of the streamed phase C runs -- and was tuned for -- two workgroups per CU: a rank's blocks are whole
 		// rounds of 2 x CUs workgroups, also when one workgroup per CU would hold its columns: BASELINE C4 on 8 ranks is 512
 		// blocks of 1,221 columns per rank, not 256 of 2,442 with every CU's second slot empty)
@@ -829,16 +832,20 @@ int prepare_geometry(fseq_ctx *c)
 		// Long inputs (the block length was clamped to 4,096 columns): whole rounds of phase C's workgroups.  BASELINE C4 had
 		// 1,221 blocks on 512 slots -- 2.4 rounds, the last one 38 % full: 2.33 s; 1,536 blocks of 3,256 columns: 2.22 s
 		// (2,048 and 3,072 blocks the same: phase A gains what phase B loses).
-		if (!p.block_len && !c->sh.on && !c->auto_B && c->B == 4096u && c->B < p.n)
+		// [r4] ... and blocks of ~1,600 columns: the streamed key-space tree is cheaper per column in shorter blocks (its merges with
+		// the running prefix see fewer distinct keys), and phase B no longer pays for more blocks what it did (fseq_chainsort.hpp).
+		// BASELINE C4, blocks x columns: 1,536 x 3,256: A 340 + B 32 = 1,823 ms the step; 2,048 x 2,442: 317 + 41 = 1,823;
+		// 3,072 x 1,628: 280 + 50 = 1,791; 4,096 x 1,221: 263 + 64 = 1,793.
+		if (!p.block_len && !c->sh.on && !c->auto_B && c->B > STREAM_BLOCK_TARGET && c->B < p.n)
 		{
 			int ncu = 0;
 			(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, p.device);
 			uint64_t const slots = (uint64_t) std::max(ncu, 1) * (c->s2.T ? c->s2.resident(c->s2_lds) : 1u);
-			uint64_t const rounds = (c->nblocks + slots - 1) / slots;
+			uint64_t const rounds = std::max<uint64_t>(1, (p.n + slots * STREAM_BLOCK_TARGET / 2) / (slots * STREAM_BLOCK_TARGET));
 			uint64_t const b = (p.n + rounds * slots - 1) / (rounds * slots);
 			if (c->tune.debug) fprintf(stderr, "[fseq] streamed phase C: %u blocks on %llu workgroup slots -> %llu rounds of %llu columns\n", c->nblocks, (unsigned long long) slots,
 			                           (unsigned long long) rounds, (unsigned long long) b);
-			if (b >= 1024 && b < 4096)
+			if (b >= 256 && b < c->B)
 			{
 				c->auto_B = (uint32_t) b;
 				block_geometry(c);
