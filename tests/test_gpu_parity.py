@@ -510,6 +510,36 @@ def test_config_c3_full_size_matches_oracle(pkg):
         assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
 
 
+def test_config_c3_shape_at_high_diversity_matches_oracle(pkg):
+    """BASELINE C3's shape at FULL length (m = 2,504 x n = 1,000,000, L = 100) with 1,024 founders and ten times the bench's
+    mutation rate -- a point of profiles/r04_diversity_sweep.txt where the per-column lists grow to ~1,500 entries, most
+    merges of the key-space tree would slice (its blocks go to the column sweep) and the maximum segment size is ~1,200
+    instead of 68: the whole run against the CPU oracle (traceback, merged segments, sampled boundary states)."""
+    c = fso.CONFIGS["C3"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], 1024, c["B"], 1e-3, c["kind"])
+    res = ctx.run()
+    t = ctx.timings()
+    assert t["phase_a_given_up"] > 0 and t["list_cap_used"] > 1000, t
+    tb = ctx.traceback()
+    red = ctx.reduced_traceback()
+    assert tb["lb"][0] == 0 and tb["rb"][-1] == n and np.array_equal(tb["lb"][1:], tb["rb"][:-1]) and (tb["rb"] - tb["lb"]).min() >= L
+    assert 500 < res.max_segment_size < m
+    msa = ctx.get_sequences()
+    ref = fso.segment_long(msa, L, threads=8)
+    assert ref["max_segment_size"] == res.max_segment_size
+    for f in ("lb", "rb", "segment_max_size", "segment_size"):
+        assert np.array_equal(tb[f], ref["traceback"][f]), f
+    for f in ("lb", "rb", "segment_size"):
+        assert np.array_equal(red[f], ref["reduced"][f])
+    for i in (0, len(red) // 7, len(red) // 2, len(red) - 1):
+        a, d = ctx.boundary_state(i)
+        assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
+    ctx.run()                                                 # (the second run launches what the first one learned: same result)
+    assert np.array_equal(ctx.traceback(), tb)
+
+
 @pytest.mark.parametrize("name", ["one_symbol", "identical_rows", "two_rows", "two_groups", "column_of_gaps"])
 def test_degenerate_alignments(pkg, name):
     """Alphabets of one symbol, identical rows, two rows, two constant groups, a rare symbol in one column."""
