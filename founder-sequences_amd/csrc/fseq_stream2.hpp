@@ -52,6 +52,10 @@ constexpr int s2_key_shift(int tile)
 #ifndef FSEQ_S2_SKIP
 #define FSEQ_S2_SKIP 0
 #endif
+// -DFSEQ_S2_PW=0: the thread's own rows with four running maxima per row (the form before round 4's pairwise halves)
+#ifndef FSEQ_S2_PW
+#define FSEQ_S2_PW 1
+#endif
 // -DFSEQ_S2_STAMPS: per-wave cycle stamps of the tile loop (diagnostic build), printed for two blocks
 #ifdef FSEQ_S2_STAMPS
 #define S2_STAMP(i) do { long long const t_ = clock64(); s2_seg[i] += t_ - s2_last; s2_last = t_; } while (0)
@@ -241,6 +245,72 @@ __device__ __forceinline__ void s2_tile_step(
 	uint32_t run[4] = {0u, 0u, 0u, 0u};
 	uint32_t lcp = 0, pend = 0;
 	uint32_t lidx[E];
+#if FSEQ_S2_PW
+	if constexpr (E == 8)
+	{
+		// [r4] The pairwise form in two halves of four rows (partition_step's PW / TWO, fseq_core.hpp): a row's value is the
+		// maximum since the NEAREST earlier row of its half with its symbol -- six compares and selects per half over the chain
+		// maxima -- instead of four running maxima per row (a max, a compare and two selects per row AND symbol: 128 of the
+		// tile's ~520 vector instructions per thread); the tail maximum behind the last row of every symbol, which the scan
+		// needs, goes through the thread's run slots (L.sel[x][thread]: conflict-free, rewritten by the resolve below).
+		constexpr int E0 = 4;
+		uint32_t const t_ = threadIdx.x;
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			uint32_t const sh = s[e] * 4u;
+			lidx[e] = (lcp >> sh) & 15u;
+			pend |= ((FULL || s[e] < 4u) && lidx[e] == 0u) ? (1u << e) : 0u;
+			lcp += 1u << sh;
+		}
+		uint32_t pre[E], suf[E];
+		pre[0] = d[0];
+#pragma unroll
+		for (int e = 1; e < E; ++e) pre[e] = (e == E0) ? d[e] : max(pre[e - 1], d[e]);      // per half
+		suf[E0 - 1] = 0u; suf[E - 1] = 0u;
+#pragma unroll
+		for (int j = E0 - 2; j >= 0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
+#pragma unroll
+		for (int j = E - 2; j >= E0; --j) suf[j] = max(suf[j + 1], d[j + 1]);
+		// tail maximum per symbol after the first half: the whole half if the symbol does not occur, else what follows its last row
+#pragma unroll
+		for (int x = 0; x < 4; ++x) L.sel[x][t_] = pre[E0 - 1];
+#pragma unroll
+		for (int e = 0; e < E0; ++e) if (FULL || s[e] < 4u) L.sel[s[e] & 3u][t_] = suf[e];      // (a position without a row, s = 4, writes nothing)
+		uint32_t t0s[E - E0], t0x[4];
+#pragma unroll
+		for (int e = E0; e < E; ++e) t0s[e - E0] = L.sel[s[e] & 3u][t_];
+#pragma unroll
+		for (int x = 0; x < 4; ++x) t0x[x] = L.sel[x][t_];
+		// ... and after the second: the first half's tail joined with the whole second half, or what follows the last row there
+#pragma unroll
+		for (int x = 0; x < 4; ++x) L.sel[x][t_] = max(t0x[x], pre[E - 1]);
+#pragma unroll
+		for (int e = E0; e < E; ++e) if (FULL || s[e] < 4u) L.sel[s[e] & 3u][t_] = suf[e];
+		// the rows' own values: the nearest earlier row of the half with the same symbol, else the half's prefix (second half:
+		// joined with the first half's tail of the symbol)
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+		{
+			int const lo = (e >= E0) ? E0 : 0;
+			uint32_t o = (e >= E0) ? max(t0s[e >= E0 ? e - E0 : 0], pre[e]) : pre[e];
+			uint32_t ch[E];                                      // ch[j] = max d(j, e]
+			if (e >= lo + 1)
+			{
+				ch[e - 1] = d[e];
+#pragma unroll
+				for (int j = e - 2; j >= lo; --j) ch[j] = max(ch[j + 1], d[j + 1]);
+#pragma unroll
+				for (int j = lo; j < e; ++j) o = (s[j] == s[e]) ? ch[j] : o;      // the nearest earlier one wins (ascending j)
+			}
+			dnew[e] = o;
+			asm volatile("" : "+v"(dnew[e]));
+		}
+#pragma unroll
+		for (int x = 0; x < 4; ++x) run[x] = L.sel[x][t_];
+	}
+	else
+#endif
 #pragma unroll
 	for (int e = 0; e < E; ++e)
 	{
