@@ -4,10 +4,14 @@ import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SRC = os.path.join(HERE, "csrc", "fseq_api.hip")
+# translation units of the library: the path (kernels, geometry, phases, sharding, ABI) and the joiners / writers
+SRCS = [os.path.join(HERE, "csrc", "fseq_api.hip"), os.path.join(HERE, "csrc", "fseq_api_join.hip")]
+SRC = SRCS[0]
 import glob
-DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "fseq.h")]
+DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "fseq.h"),
+                                                             os.path.join(os.path.dirname(HERE), "include", "fseq_debug.h")]
 OUT = os.path.join(HERE, "libfseq_hip.so")
+OBJ_DIR = os.path.join(HERE, "build")
 
 
 def hipcc():
@@ -34,10 +38,24 @@ def build(force=False, verbose=False):
     LAST_ACTION["libfseq_hip.so"] = "compiled"
     # FSEQ_HIPCC_FLAGS: extra flags for diagnostic builds (-DFSEQ_DP_STAMPS, -DFSEQ_DP_STATS)
     # roctx ranges per phase when the image has the library (rocprofv3 --marker-trace shows them)
-    roctx = ["-DFSEQ_WITH_ROCTX", "-L/opt/rocm/lib", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"] \
-        if os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so") and os.path.exists("/opt/rocm/include/rocprofiler-sdk-roctx/roctx.h") else []
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"] + os.environ.get("FSEQ_HIPCC_FLAGS", "").split() \
-        + ["-o", OUT, SRC] + roctx
+    have_roctx = os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so") and os.path.exists("/opt/rocm/include/rocprofiler-sdk-roctx/roctx.h")
+    cflags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FSEQ_HIPCC_FLAGS", "").split() + (["-DFSEQ_WITH_ROCTX"] if have_roctx else [])
+    ldflags = ["-L/opt/rocm/lib", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"] if have_roctx else []
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    # the translation units side by side (the kernel TU is ~50 s of hipcc, the joiners a few)
+    procs = []
+    objs = []
+    for src in SRCS:
+        obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [hipcc()] + cflags + ["-c", "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ldflags
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

@@ -5,8 +5,9 @@
 // and only the O(S) pieces (traceback walk lp.cc:191-224, segment merge lp.cc:335-390) on the CPU.
 // There is deliberately NO CPU fallback for the column work: if the device or a kernel shape is
 // unavailable the call fails with an error code.
-#include "../../include/fseq.h"
-#include "../../include/fseq_debug.h"
+// The context and the helpers shared with the other translation unit are in fseq_ctx.hpp; the host joiners, their device
+// front and the output writers are csrc/fseq_api_join.hip.
+#include "fseq_ctx.hpp"
 #include "fseq_kernels.hpp"
 #include "fseq_dp.hpp"
 #include "fseq_dpspec.hpp"
@@ -15,8 +16,6 @@
 #include "fseq_chainsort.hpp"
 #include "fseq_blockkeys.hpp"
 #include "fseq_rowshard.hpp"
-#include "fseq_join.hpp"
-#include "fseq_joinprep.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -44,35 +43,6 @@ static std::atomic<uint64_t> g_range_pushes{0}, g_range_pops{0};
 using namespace fseq;
 
 namespace {
-
-struct KernelSet {
-	uint32_t T, E, sigma, cap;
-	size_t lds_colblock, lds_snap;
-	uint32_t scan_shift;                     // partition steps of this configuration may scan keys while every divergence is < 2^scan_shift
-	void (*rank)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
-	             uint32_t *, uint32_t *, uint32_t *, uint64_t col0, uint32_t const *only);
-	void (*snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t npass, uint32_t bsh,
-	             uint32_t const *, uint32_t const *, uint64_t const *, uint2 const *, uint32_t *, uint32_t *,
-	             uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d, uint32_t keyed);
-	size_t (*columns_lds)(uint32_t B);
-	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
-	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
-	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch);
-	uint32_t (*columns_resident)(size_t lds);                 // workgroups of k_columns one CU holds
-	size_t lds_chain;
-	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
-	              uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	              uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0, uint32_t keyed);
-	hipError_t (*prepare)(size_t lds_columns);
-	hipError_t (*prepare_columns)(size_t lds_columns);
-};
-
-template <typename K>
-hipError_t allow_lds(K kernel, size_t bytes)
-{
-	if (bytes <= 64 * 1024) return hipSuccess;
-	return hipFuncSetAttribute(reinterpret_cast<void const *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
-}
 
 // EW: phase C keeps wave 0 free of rows for the per-column list (k_columns, fseq_kernels.hpp): m <= (T - 64) * E
 template <int T, int E, int SIGMA, bool PK, bool EW = false>
@@ -253,13 +223,6 @@ constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column l
 
 // phase C, streamed rows, second form (fseq_stream2.hpp): <threads, rows per thread, 5-byte rows>
 #define FSEQ_S2_CONFIGS(X) X(512, 8, true) X(1024, 4, true) X(1024, 8, true) X(256, 8, true) X(256, 12, true) X(512, 8, false) X(1024, 6, false) X(1024, 8, false) X(256, 8, false) X(256, 12, false)
-struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
-	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
-	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
-	uint32_t (*resident)(size_t lds);
-	// pass 2 on the same tile step (packed rows only; nullptr otherwise): k_columns_stream2<.., S2_SNAP>
-	void (*launch_snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, S2SnapArgs const &); };
 template <int T, int E, bool PACK>
 struct LaunchS2 {
 	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E, PACK>(colbytes); }
@@ -298,323 +261,9 @@ bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out)
 	return false;
 }
 
-double now_ms()
-{
-	using namespace std::chrono;
-	return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
-
 } // namespace
 
-// Diagnostic / test knobs of the library.  They are read from the environment ONCE, when a context is created
-// (fseq_create), and can be set per context with fseq_debug_set_tuning (include/fseq_debug.h); nothing on the run
-// path looks at the environment.  Every knob selects among exact alternatives (results never depend on them).
-struct Tuning {
-	bool debug = false;                  // FSEQ_DEBUG: progress notes on stderr
-	bool host_flags = false, no_host_flags = false;   // FSEQ_HOST_FLAGS / FSEQ_NO_HOST_FLAGS: the serial DP beside phase C, fed by host-visible flags
-	int  c_parts = 0;                    // FSEQ_C_PARTS: phase C in this many launches with the serial DP in between
-	int  dp_chunks = 0;                  // FSEQ_DP_CHUNKS: the serial DP in this many resumed launches
-	bool dp_serial = false;              // FSEQ_DP_SERIAL: the serial DP instead of the speculative sweeps
-	int  dp_spec_win = 0, dp_spec_rounds = 0, dp_spec_max_sweeps = 0;      // FSEQ_DP_SPEC_*: tail window, chunk length, sweep budget
-	bool stream_plain_scan = false;      // FSEQ_STREAM_PLAIN_SCAN: streamed phase C with the has-based scan (first form)
-	bool plain_scan = false;             // FSEQ_PLAIN_SCAN: phase B / pass 2 never scan keys
-	bool occurrence_keys = false;        // FSEQ_OCCURRENCE_KEYS: ... scan occurrence keys even where row counts fit the keys
-	bool phase_a_classic = false;        // FSEQ_PHASE_A_CLASSIC: phase A as a column sweep
-	int  chain_fan = 0;                  // FSEQ_CHAIN_FAN: group size of phase B's recursion
-	bool two_level_chain = false;        // FSEQ_TWO_LEVEL_CHAIN
-	bool chain_stream_passes = false;    // FSEQ_CHAIN_STREAM_PASSES: streamed phase B as two-bit digit passes (the form before fseq_chainsort.hpp)
-	bool chain_stream_single = false;    // FSEQ_CHAIN_STREAM_SINGLE: ... as the sorted step on one workgroup per chain (not spread over the chip)
-	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
-	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
-	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
-	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
-	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
-	bool ss_unpacked = false;            // FSEQ_SS_UNPACKED: 8-byte stride states in the streamed regime
-	bool ss_absolute = false;            // FSEQ_SS_ABSOLUTE: stride states hold divergences and pass 2 runs the first form's tile step (the form before round 4)
-	int  snap_stride = 0;                // FSEQ_SNAP_STRIDE: first stride tried for the stride states
-	bool poison_lists = false;           // FSEQ_POISON_LISTS: lists and headers filled with 0xFF before phase C
-	bool no_emitter_wave = false;        // FSEQ_NO_EMITTER_WAVE: phase C without the list wave
-	bool join_host = false;              // FSEQ_JOIN_HOST: the greedy joiner's class tables and edges on the host
-	bool shard_dp_full = false;          // FSEQ_SHARD_DP_FULL: the sharded DP gathers the whole key array after every sweep (round 2-3 form)
-	int  shard_dp_window = 0;            // FSEQ_SHARD_DP_WINDOW: entries of the other ranks a rank holds in front of its own (tests: small windows)
-	int  inject_failure_rank = -1;       // FSEQ_INJECT_FAILURE_RANK: this rank of a sharded run fails after phase A
-	std::string sync_phases;             // FSEQ_SYNC_PHASES: "ABC": synchronise after these phases (a fault shows where it happened)
-	bool check_phase_a = false;          // FSEQ_CHECK_PHASE_A: validate the key blocks on the host before phase B
-
-	// returns false for a name it does not know
-	bool set(char const *name, char const *value)
-	{
-		std::string const n(name), v(value ? value : "");
-		bool const on = value != nullptr;
-		int const iv = atoi(v.c_str());
-		if (n == "FSEQ_DEBUG") debug = on;
-		else if (n == "FSEQ_HOST_FLAGS") host_flags = on;
-		else if (n == "FSEQ_NO_HOST_FLAGS") no_host_flags = on;
-		else if (n == "FSEQ_C_PARTS") c_parts = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_DP_CHUNKS") dp_chunks = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_DP_SERIAL") dp_serial = on;
-		else if (n == "FSEQ_DP_SPEC_WIN") dp_spec_win = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_DP_SPEC_ROUNDS") dp_spec_rounds = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_DP_SPEC_MAX_SWEEPS") dp_spec_max_sweeps = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_STREAM_PLAIN_SCAN") stream_plain_scan = on;
-		else if (n == "FSEQ_PLAIN_SCAN") plain_scan = on;
-		else if (n == "FSEQ_OCCURRENCE_KEYS") occurrence_keys = on;
-		else if (n == "FSEQ_PHASE_A_CLASSIC") phase_a_classic = on;
-		else if (n == "FSEQ_CHAIN_FAN") chain_fan = on ? std::max(2, iv) : 0;
-		else if (n == "FSEQ_TWO_LEVEL_CHAIN") two_level_chain = on;
-		else if (n == "FSEQ_CHAIN_STREAM_PASSES") chain_stream_passes = on;
-		else if (n == "FSEQ_CHAIN_STREAM_SINGLE") chain_stream_single = on;
-		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
-		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
-		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
-		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
-		else if (n == "FSEQ_STREAM2") stream2 = v;
-		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
-		else if (n == "FSEQ_SS_ABSOLUTE") ss_absolute = on;
-		else if (n == "FSEQ_SNAP_STRIDE") snap_stride = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_POISON_LISTS") poison_lists = on;
-		else if (n == "FSEQ_NO_EMITTER_WAVE") no_emitter_wave = on;
-		else if (n == "FSEQ_JOIN_HOST") join_host = on;
-		else if (n == "FSEQ_SHARD_DP_FULL") shard_dp_full = on;
-		else if (n == "FSEQ_SHARD_DP_WINDOW") shard_dp_window = on ? std::max(64, iv) : 0;
-		else if (n == "FSEQ_INJECT_FAILURE_RANK") inject_failure_rank = on ? iv : -1;
-		else if (n == "FSEQ_SYNC_PHASES") sync_phases = v;
-		else if (n == "FSEQ_CHECK_PHASE_A") check_phase_a = on;
-		else return false;
-		return true;
-	}
-
-	void from_environment()
-	{
-		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
-			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
-			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
-			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
-			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE"};
-		for (char const *nm : names)
-			if (char const *v = getenv(nm)) (void) set(nm, v);
-	}
-};
-
-// One alignment over several ranks (include/fseq.h, fseq_set_shard): which blocks / columns / DP chunks are mine
-struct Shard {
-	bool on = false;
-	uint32_t rank = 0, world = 1;
-	uint32_t *xbuf = nullptr;               // caller-owned exchange buffer (device)
-	uint64_t xwords = 0;
-	fseq_allreduce_fn fn = nullptr;
-	void *user = nullptr;
-	uint32_t bpr = 0;                       // blocks per rank = shard_q * chain_fan^shard_k (a rank is one hyper-block of phase B)
-	uint32_t active = 1;                    // ranks that own blocks
-	uint32_t b_lo = 0, b_hi = 0;            // my blocks
-	uint64_t c_lo = 0, c_hi = 0, c_end = 0; // my columns [c_lo, c_hi); held: [c_lo, c_end) (halo for my last DP round)
-	bool posted = false;                    // this rank has told the others that it failed (once per context)
-	bool closed = false;                    // the run's last exchange is done: nobody is left to hear of a failure
-};
-
-struct fseq_ctx {
-	fseq_params p{};
-	Tuning tune;                             // read from the environment once, at fseq_create
-	std::unordered_map<void *, size_t> alloc_sizes;   // device allocations of this context (dev_alloc / dev_free)
-	size_t alloc_total = 0;
-	uint64_t mem_budget = 0;                  // fseq_set_memory_budget: 0 = whatever is free on the device
-	std::atomic<uint64_t> step_max{0}, current_step{0};      // fseq_step_max / fseq_current_step (segmentation_lp_context.hh:122-127)
-	fseq_join_profile jp{};                  // the last joiner call (fseq_get_join_profile)
-	fseq_progress_fn progress_fn = nullptr;
-	void *progress_user = nullptr;
-	hipStream_t stream = nullptr;
-	std::string err;
-	Shard sh;
-	uint8_t *d_msa_alloc = nullptr;          // what was allocated; d_msa = d_msa_alloc - c_lo * ld (column k at d_msa + k * ld)
-	uint2 *d_ent_alloc = nullptr;
-	uint32_t *d_ss_a_alloc = nullptr, *d_ss_d_alloc = nullptr;
-	uint32_t *d_bkws = nullptr;              // ... streamed rows: per-workgroup workspace (id arrays, group ids)
-	size_t bkws_words = 0;
-	uint16_t *d_bk = nullptr;                // phase A in key space (fseq_blockkeys.hpp): per-block scratch (leaf words, group ids)
-	size_t bk_per_block = 0, bk_blocks = 0;
-	uint32_t bk_cap_words = 0;
-	uint32_t bk_T = 0;                       // threads of k_blockkeys (LDS-resident rows)
-	uint32_t *d_todo = nullptr;              // phase A: blocks the key-space tree gave up on (the column sweep does them)
-	size_t todo_cap = 0;
-	int bk_given_up = -1;                    // ... in the last run on this input (-1: not run yet): later runs skip the sweep's launch when
-	                                         // it was none, and the tree altogether when it was most blocks
-	size_t bk_lds = 0;
-	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
-	uint32_t chunk_cap = 0;
-	uint2 *d_tau = nullptr;                  // merge thresholds (k_seg_tau) / counts
-	size_t tau_cap = 0;
-	std::vector<int64_t> snap_slot;          // segment index -> slot in d_snap_* (-1: another rank's)
-	// sharded DP (run_dp_spec): the DP entries [own_lo[g], own_hi[g]) belong to rank g (the last active rank also owns the
-	// final cell's); dp_window_mode: a rank holds its own entries and a window of the others' in front of them, not the
-	// whole arrays (the traceback then runs rank by rank, follow_traceback_sharded)
-	std::vector<uint32_t> own_lo, own_hi;
-	bool dp_window_mode = false;
-	bool shard_dp_full_sticky = false;       // a sweep of this input read below its window once: whole-array exchanges from then on
-	uint64_t dp_exchange_words = 0;          // words the DP's sweep exchanges moved in the last run (diagnostics)
-
-	// input
-	uint8_t *d_msa = nullptr;
-	size_t ld = 0;
-	bool own_msa = false;
-	bool have_input = false;
-	uint32_t sigma = 0;
-	uint8_t code_to_byte[256]{};
-
-	// geometry
-	uint32_t B = 0, nblocks = 0, N2 = 0, npass = 1;
-	uint32_t auto_B = 0;                     // block length fitted to whole rounds of phase C's workgroups (short inputs)
-	Stream2Config s2{};                      // streamed phase C, second form (T = 0: not in use)
-	size_t s2_lds = 0;
-	bool stream_staged = false;              // streamed kernels lay tiles out in LDS before writing them (needs 64 KiB more)
-	uint32_t bsh = 0;                        // alignment packing: 8 >> bsh bits per symbol (fseq_kernels.hpp sym_bytes)
-	KernelSet ks{};
-	bool kernels_ready = false;
-	bool use_stream = false;             // m too large for an LDS-resident order: HBM-streamed kernels (fseq_stream.hpp)
-	size_t tb_guess = 0;                 // traceback entries of the last run (sizes the speculative copy of the next)
-	std::vector<uint2> tau_host;         // merge thresholds that came back with the traceback (not sharded)
-	uint32_t *d_ws = nullptr;            // their per-block workspaces
-	size_t ws_words = 0;
-	size_t lds_columns = 0;
-
-	// device work buffers
-	// per column block: key blocks (phase A) and boundary states (phase B), indexed by the block's place in the whole
-	// alignment.  A rank of a sharded run allocates its own blocks [b_lo, b_hi] only (*_alloc) and shifts the pointer
-	// (block b at d_rank + b * m as before): memory per rank falls with the rank count
-	uint32_t *d_rank = nullptr, *d_keyd = nullptr, *d_nkeys = nullptr;
-	uint32_t *d_bstate_a = nullptr, *d_bstate_d = nullptr;
-	uint32_t *d_rank_alloc = nullptr, *d_keyd_alloc = nullptr, *d_nkeys_alloc = nullptr, *d_bstate_a_alloc = nullptr, *d_bstate_d_alloc = nullptr;
-	uint32_t *d_cshist = nullptr;            // streamed phase B spread over the chip (fseq_chainsort.hpp): digit histograms [chain][part][bin]
-	size_t cshist_words = 0;
-	uint32_t *d_ws_c = nullptr;              // streamed phase C: the per-block workspaces, block b at d_ws_c + b * (words per block)
-	uint32_t *d_hrank = nullptr, *d_hkeyd = nullptr, *d_hnkeys = nullptr, *d_hstate_a = nullptr, *d_hstate_d = nullptr;
-	// not sharded: phase B over any number of levels (levels[i - 1] = the composites of chain_fan level-(i - 1) key blocks)
-	struct ChainLevel { uint32_t count = 0; uint64_t cols = 0; uint32_t *rank = nullptr, *keyd = nullptr, *nkeys = nullptr, *state_a = nullptr, *state_d = nullptr;
-	                    uint32_t *rank_alloc = nullptr, *keyd_alloc = nullptr, *nkeys_alloc = nullptr, *state_a_alloc = nullptr, *state_d_alloc = nullptr; };
-	std::vector<ChainLevel> levels;
-	uint32_t chain_fan = 0;
-	uint32_t shard_k = 0, shard_q = 0;       // sharded: a rank's hyper-block = shard_q groups of chain_fan^shard_k blocks
-	uint32_t chain_G = 0, n_super = 0;       // sharded: super-blocks of chain_G blocks
-	uint32_t chain_G2 = 0, n_hyper = 0;      // third level: hyper-blocks of chain_G2 super-blocks (0 = two levels only)
-	uint2 *d_ent = nullptr;
-	uint4 *d_hdr = nullptr;
-	uint32_t X = 0, stride = 0;
-	uint32_t X_hint = 0;                     // list capacity that worked on the last run of this input
-	DpArrays dp{};
-	uint32_t *d_Mprev = nullptr;             // chunk-speculative DP: the iterate the last sweep started from
-	uint32_t *d_spec = nullptr;              // its per-chunk words (active, changed, tailmin, floor, lift, 2 x ovf) + SpecCtl
-	uint32_t spec_cap = 0;
-	uint32_t *d_flags = nullptr;
-	uint32_t *d_recent = nullptr;            // k_boundary_recent counts, one per block boundary
-	uint64_t dp_size = 0;
-	uint64_t *d_cols = nullptr;           // scratch: column / rb lists
-	size_t cols_cap = 0;
-	uint2 *d_grp = nullptr;
-	size_t grp_cap = 0;
-	uint64_t *d_src = nullptr;
-	size_t src_cap = 0;
-	uint32_t snap_stride = 16;            // phase C drops the exact (a,d) every snap_stride columns for pass 2
-	uint32_t *d_ss_a = nullptr, *d_ss_d = nullptr;
-	uint32_t ss_pack = 0;                 // streamed rows: stride states packed to 5 bytes per row (bits of a row id; fseq_stream.hpp)
-	bool ss_ids = false;                  // ... and in ID form: the packed rows of phase C's workspace; pass 2 replays them on the same tile step (fseq_stream2.hpp, S2_SNAP)
-	uint32_t *d_bs_w_alloc = nullptr, *d_bs_w = nullptr;      // ... with every block's start state in the same form (block b at d_bs_w + b * m)
-	uint8_t *d_bs_h_alloc = nullptr, *d_bs_h = nullptr;
-	uint32_t *d_wgblk = nullptr;          // pass 2 on the tile step: block and groups of every workgroup
-	uint2 *d_wggrp = nullptr;
-	size_t wg_cap = 0;
-	uint2 *d_gent = nullptr;
-	uint4 *d_ghdr = nullptr;
-	size_t gather_cap = 0, gather_stride = 0;
-	uint32_t *d_snap_a = nullptr, *d_snap_d = nullptr;
-	size_t snap_cap = 0;
-
-	// results
-	bool have_result = false;
-	fseq_result res{};
-	uint4 *d_tb = nullptr;                   // the traceback kernels' output {entry, lb, key, size} per segment, window heads, counts
-	size_t tb_cap = 0;
-	uint32_t tb_win = 0;
-	std::vector<fseq_dp_arg> traceback;
-	std::vector<fseq_segment> segments;
-	std::vector<uint32_t> sp_first, sp_len;
-	fseq_timings tm{};
-	hipEvent_t ev[8]{};
-	hipStream_t stream2 = nullptr;           // the DP, while phase C is still producing lists for later columns
-	hipEvent_t ev_part[16]{};                // part c of phase C done
-	hipEvent_t ev_dp[2]{};                   // DP begin / end on stream2
-	uint8_t *h_pin = nullptr;                // pinned host staging of a step's small transfers (pin_reserve / pin_take)
-	size_t pin_cap = 0, pin_used = 0;
-	uint32_t *h_done = nullptr, *d_done = nullptr;   // per-block "lists are in memory" flags in host-coherent memory (host / device view)
-	uint32_t done_cap = 0, epoch = 0;
-};
-
 namespace {
-
-int fail(fseq_ctx *c, int code, char const *what, hipError_t e = hipSuccess)
-{
-	char buf[512];
-	if (e != hipSuccess)
-		snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
-	else
-		snprintf(buf, sizeof(buf), "%s", what);
-	c->err = buf;
-	return code;
-}
-
-// progress (include/fseq.h, fseq_set_progress): counters another thread may poll + the caller's callback
-void progress(fseq_ctx *c, int stage, uint64_t current, uint64_t max)
-{
-	c->step_max.store(max, std::memory_order_relaxed);
-	c->current_step.store(current, std::memory_order_relaxed);
-	if (c->progress_fn) c->progress_fn(c->progress_user, stage, current, max);
-}
-
-#define HIP_TRY(c, expr)                                                   \
-	do {                                                                   \
-		hipError_t e_ = (expr);                                            \
-		if (e_ != hipSuccess) return fail((c), FSEQ_E_HIP, #expr, e_);     \
-	} while (0)
-
-template <typename U>
-void dev_free(fseq_ctx *c, U **p)
-{
-	if (!*p) return;
-	auto it = c->alloc_sizes.find(static_cast<void *>(*p));
-	if (it != c->alloc_sizes.end()) { c->alloc_total -= it->second; c->alloc_sizes.erase(it); }
-	(void) hipFree(*p);
-	*p = nullptr;
-}
-
-// every device allocation of a context goes through here: alloc_total is what the context holds (the memory plan of
-// the stride states stays inside fseq_set_memory_budget's figure when ranks share a card)
-template <typename U>
-int dev_alloc(fseq_ctx *c, U **p, size_t count)
-{
-	dev_free(c, p);
-	size_t const bytes = std::max<size_t>(count, 1) * sizeof(U);
-	hipError_t e = hipMalloc(reinterpret_cast<void **>(p), bytes);
-	if (e != hipSuccess)
-	{
-		*p = nullptr;
-		size_t free_b = 0, total_b = 0;
-		(void) hipMemGetInfo(&free_b, &total_b);
-		char what[160];
-		snprintf(what, sizeof(what), "hipMalloc of %zu bytes (%zu of %zu bytes free on the device)", bytes, free_b, total_b);
-		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, what, e);
-	}
-	c->alloc_sizes[static_cast<void *>(*p)] = bytes;
-	c->alloc_total += bytes;
-	return FSEQ_OK;
-}
-
-// items [lo, hi) of an array of `per` words per item: *alloc owns the memory, *view is shifted so that item i sits at
-// *view + i * per (a rank of a sharded run holds its own column blocks only, addressed by their place in the whole alignment)
-template <typename U>
-int dev_alloc_range(fseq_ctx *c, U **alloc, U **view, size_t lo, size_t hi, size_t per)
-{
-	int const rc = dev_alloc(c, alloc, (hi > lo ? hi - lo : 0) * per);
-	*view = rc ? nullptr : *alloc - lo * per;
-	return rc;
-}
 
 // Pinned host staging.  A copy between the device and pageable host memory is staged by the runtime -- one blocking round
 // trip of 20-50 microseconds each, and a step had a dozen of them (flags, counts, the traceback, thresholds: a fifth of a
@@ -3090,13 +2739,6 @@ int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
 	return FSEQ_OK;
 }
 
-int fseq_get_join_profile(fseq_ctx const *c, fseq_join_profile *out)
-{
-	if (!c || !out) return FSEQ_E_ARG;
-	*out = c->jp;
-	return FSEQ_OK;
-}
-
 int fseq_set_progress(fseq_ctx *c, fseq_progress_fn fn, void *user)
 {
 	if (!c) return FSEQ_E_ARG;
@@ -3257,287 +2899,6 @@ int fseq_debug_column_list(fseq_ctx *c, uint64_t col, uint32_t *values, uint32_t
 	if (n_entries) *n_entries = h.x;
 	if (cnt0) *cnt0 = h.y;
 	if (complete) *complete = h.z;
-	return FSEQ_OK;
-}
-
-int fseq_join_greedy(fseq_ctx *c, uint32_t *permutations)
-{
-	if (!c || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
-	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use fseq_greedy_match_host");
-	(void) hipSetDevice(c->p.device);
-	size_t const m = c->p.m, S = c->segments.size();
-	double const t0 = now_ms();
-	uint32_t const X = c->res.max_segment_size;
-	// class tables and co-occurrence edges where the boundary states are (fseq_joinprep.hpp); the host hands out
-	// the copies and draws the edges (the serial part of greedy_matcher.cc).  Falls through to the all-host joiner
-	// below when the edge array cannot be allocated or the tables come back implausible.
-	while (X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && !c->tune.join_host)
-	{
-		hipStream_t st = c->stream;
-		uint16_t *d_of = nullptr;
-		uint32_t *d_rep = nullptr, *d_size = nullptr, *d_count = nullptr, *d_off = nullptr, *d_ne = nullptr;
-		uint64_t *d_rb = nullptr;
-		uint2 *d_edges = nullptr;
-		unsigned long long *d_cursor = nullptr;
-		// (offsets into the edge array are 32-bit words on the way to the host: the capacity stays below 2^32)
-		uint64_t const cap_total = std::min<uint64_t>((uint64_t) (S > 1 ? S - 1 : 0) * std::min<uint64_t>(m, (uint64_t) X * X) + 1, 0xFFFFFFFFull);
-		int rc;
-		auto cleanup = [&]() { dev_free(c, &d_of); dev_free(c, &d_rep); dev_free(c, &d_size); dev_free(c, &d_count); dev_free(c, &d_off); dev_free(c, &d_ne);
-		                       dev_free(c, &d_rb); dev_free(c, &d_edges); dev_free(c, &d_cursor); };
-		if ((rc = dev_alloc(c, &d_of, S * m)) || (rc = dev_alloc(c, &d_rep, S * X)) || (rc = dev_alloc(c, &d_size, S * X)) || (rc = dev_alloc(c, &d_count, S)) ||
-		    (rc = dev_alloc(c, &d_off, S)) || (rc = dev_alloc(c, &d_ne, S)) || (rc = dev_alloc(c, &d_rb, S)) || (rc = dev_alloc(c, &d_edges, cap_total)) ||
-		    (rc = dev_alloc(c, &d_cursor, 1)))
-		{
-			cleanup();
-			if (rc == FSEQ_E_OOM) { c->err.clear(); break; }       // no room for the device front: the host joiner needs none
-			return rc;
-		}
-		std::vector<uint64_t> rbs(S);
-		for (size_t i = 0; i < S; ++i) rbs[i] = c->segments[i].rb;
-		hipError_t e = hipMemcpyAsync(d_rb, rbs.data(), S * 8, hipMemcpyHostToDevice, st);
-		if (e == hipSuccess) e = hipMemsetAsync(d_cursor, 0, 8, st);
-		if (e == hipSuccess) e = hipMemsetAsync(d_rep, 0, S * X * 4, st);
-		size_t const lds = (size_t) X * X * 4;
-		if (e == hipSuccess) e = allow_lds(k_join_edges, lds);
-		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "join preparation", e); }
-		hipLaunchKernelGGL(k_join_classes, dim3((uint32_t) S), dim3(JP_T), 0, st, c->d_snap_a, c->d_snap_d, d_rb, (uint32_t) m, X, d_of, d_rep, d_size, d_count);
-		if (S > 1)
-			hipLaunchKernelGGL(k_join_edges, dim3((uint32_t) (S - 1)), dim3(JP_T), lds, st, d_of, d_count, (uint32_t) m, X, d_edges, cap_total, d_off, d_ne, d_cursor);
-		std::vector<uint32_t> count(S), rep(S * X), size(S * X), off(S), ne(S);
-		unsigned long long total = 0;
-		e = hipMemcpyAsync(count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipMemcpyAsync(rep.data(), d_rep, S * X * 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipMemcpyAsync(size.data(), d_size, S * X * 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess && S > 1) e = hipMemcpyAsync(off.data(), d_off, (S - 1) * 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess && S > 1) e = hipMemcpyAsync(ne.data(), d_ne, (S - 1) * 4, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipMemcpyAsync(&total, d_cursor, 8, hipMemcpyDeviceToHost, st);
-		if (e == hipSuccess) e = hipStreamSynchronize(st);
-		if (e == hipSuccess) e = hipGetLastError();
-		bool sane = e == hipSuccess && total < cap_total && total <= 0xFFFFFFFFull;
-		for (size_t i = 0; sane && i < S; ++i) sane = count[i] >= 1 && count[i] <= X;
-		std::vector<uint32_t> edge_words(sane ? 2 * (size_t) total + 2 : 2);
-		if (sane && total) e = hipMemcpy(edge_words.data(), d_edges, (size_t) total * 8, hipMemcpyDeviceToHost);
-		cleanup();
-		if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "join preparation", e);
-		if (!sane) break;                                         // (the host joiner builds its own tables from the boundary states)
-		double const t1 = now_ms();
-		JoinProfile prof;
-		greedy_match_prepared(c->p.m, X, S, count.data(), rep.data(), size.data(), edge_words.data(), off.data(), ne.data(), permutations, &prof);
-		c->jp = fseq_join_profile{t1 - t0, prof.ms_classes, prof.ms_edges, prof.ms_draw, now_ms() - t0,
-		                          (uint64_t) S * (2ull * X + 3) * 4 + (uint64_t) total * 8};
-		return FSEQ_OK;
-	}
-	std::vector<uint32_t> A(S * m), D(S * m);
-	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
-	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
-	double const t1 = now_ms();
-	std::vector<JoinSegment> segs(S);
-	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
-	JoinProfile prof;
-	greedy_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations, &prof);
-	c->jp = fseq_join_profile{t1 - t0, prof.ms_classes, prof.ms_edges, prof.ms_draw, now_ms() - t0, (uint64_t) S * m * 8ull};
-	return FSEQ_OK;
-}
-
-// boundary states of all merged segments on the host (what join_context reads from the pbwt samples)
-static int fetch_boundary_states(fseq_ctx *c, std::vector<uint32_t> &A, std::vector<uint32_t> &D, std::vector<JoinSegment> &segs)
-{
-	if (!c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
-	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: collect the boundary states (fseq_boundary_state on their owners) and use the *_match_host entry points");
-	(void) hipSetDevice(c->p.device);
-	size_t const m = c->p.m, S = c->segments.size();
-	double const t0 = now_ms();
-	A.resize(S * m); D.resize(S * m);
-	HIP_TRY(c, hipMemcpy(A.data(), c->d_snap_a, S * m * 4, hipMemcpyDeviceToHost));
-	HIP_TRY(c, hipMemcpy(D.data(), c->d_snap_d, S * m * 4, hipMemcpyDeviceToHost));
-	c->jp = fseq_join_profile{now_ms() - t0, 0, 0, 0, 0, (uint64_t) S * m * 8ull};
-	segs.resize(S);
-	for (size_t i = 0; i < S; ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
-	return FSEQ_OK;
-}
-
-int fseq_join_bipartite(fseq_ctx *c, uint32_t *permutations)
-{
-	if (!c || !permutations) return FSEQ_E_ARG;
-	std::vector<uint32_t> A, D;
-	std::vector<JoinSegment> segs;
-	int const rc = fetch_boundary_states(c, A, D, segs);
-	if (rc) return rc;
-	double const t0 = now_ms();
-	bipartite_match(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), permutations);
-	c->jp.ms_draw = now_ms() - t0; c->jp.ms_total = c->jp.ms_d2h + c->jp.ms_draw;
-	return FSEQ_OK;
-}
-
-int fseq_join_random(fseq_ctx *c, uint32_t seed, uint32_t *permutations)
-{
-	if (!c || !permutations) return FSEQ_E_ARG;
-	std::vector<uint32_t> A, D;
-	std::vector<JoinSegment> segs;
-	int const rc = fetch_boundary_states(c, A, D, segs);
-	if (rc) return rc;
-	double const t0 = now_ms();
-	random_join(c->p.m, c->res.max_segment_size, segs, A.data(), D.data(), seed, permutations);
-	c->jp.ms_draw = now_ms() - t0; c->jp.ms_total = c->jp.ms_d2h + c->jp.ms_draw;
-	return FSEQ_OK;
-}
-
-int fseq_bipartite_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
-                              uint32_t const *a, uint32_t const *d, uint32_t *permutations, int64_t *weights)
-{
-	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
-	std::vector<JoinSegment> segs(n_segments);
-	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
-	std::vector<int64_t> w;
-	bipartite_match(m, max_segment_size, segs, a, d, permutations, nullptr, &w);
-	if (weights) std::copy(w.begin(), w.end(), weights);
-	return FSEQ_OK;
-}
-
-int fseq_random_join_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
-                          uint32_t const *a, uint32_t const *d, uint32_t seed, uint32_t *permutations)
-{
-	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
-	std::vector<JoinSegment> segs(n_segments);
-	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
-	random_join(m, max_segment_size, segs, a, d, seed, permutations);
-	return FSEQ_OK;
-}
-
-static int write_segments_impl(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *A_, uint32_t const *D_,
-                               std::vector<JoinSegment> const &segs, char const *path);
-
-int fseq_write_segments(fseq_ctx *c, uint8_t const *const *rows, int joining, char const *path)
-{
-	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	if (joining != FSEQ_JOIN_GREEDY && !rows) return FSEQ_E_ARG;
-	std::vector<uint32_t> A, D;
-	std::vector<JoinSegment> segs;
-	if (joining != FSEQ_JOIN_GREEDY)
-	{
-		int const rc = fetch_boundary_states(c, A, D, segs);
-		if (rc) return rc;
-	}
-	return write_segments_impl(c, rows, joining, A.data(), D.data(), segs, path);
-}
-
-// the same with the boundary states supplied by the caller (a sharded run: collected from their owners)
-int fseq_write_segments_host(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *a, uint32_t const *d, char const *path)
-{
-	if (!c || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	if (joining != FSEQ_JOIN_GREEDY && (!rows || !a || !d)) return FSEQ_E_ARG;
-	std::vector<JoinSegment> segs;
-	if (joining != FSEQ_JOIN_GREEDY)
-	{
-		segs.resize(c->segments.size());
-		for (size_t i = 0; i < segs.size(); ++i) { segs[i].lb = c->segments[i].lb; segs[i].rb = c->segments[i].rb; }
-	}
-	return write_segments_impl(c, rows, joining, a, d, segs, path);
-}
-
-static int write_segments_impl(fseq_ctx *c, uint8_t const *const *rows, int joining, uint32_t const *A_, uint32_t const *D_,
-                               std::vector<JoinSegment> const &segs, char const *path)
-{
-	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
-	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the segments output file");
-	size_t const m = c->p.m, S = segs.size();
-	uint32_t const X = c->res.max_segment_size;
-	if (FSEQ_JOIN_BIPARTITE == joining)
-	{
-		// segmentation_dp_arg.cc:59-104
-		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE\tSEQUENCES\tCOPIED_FROM\n", f);
-		for (size_t s = 0; s < S; ++s)
-		{
-			uint32_t const *a = A_ + s * m, *d = D_ + s * m;
-			auto const texts = create_segment_texts((uint32_t) m, X, a, prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, true));
-			for (size_t i = 0; i < texts.size(); ++i)
-			{
-				SegmentText const &tx = texts[i];
-				fprintf(f, "%zu\t%llu\t%llu\t%u\t", s, (unsigned long long) segs[s].lb, (unsigned long long) segs[s].rb, c->segments[s].segment_size);
-				uint32_t const rep = texts[tx.row_number(i)].sequence_indices.front();    // segment_text::write_text
-				fwrite(rows[rep] + segs[s].lb, 1, segs[s].rb - segs[s].lb, f);
-				fputc('\t', f);
-				for (size_t k = 0; k < tx.sequence_indices.size(); ++k) fprintf(f, k ? ",%u" : "%u", tx.sequence_indices[k]);
-				if (tx.is_copied()) fprintf(f, "\t%zu\n", tx.copied_from); else fputs("\t-\n", f);
-			}
-		}
-	}
-	else
-	{
-		// segmentation_dp_arg.cc:13-56; with greedy joining the copy-number matrix is empty
-		fputs("SEGMENT\tLB\tRB\tSIZE\tSUBSEQUENCE_NUMBER\tCOPY_NUMBER\tSUBSEQUENCE\n", f);
-		for (size_t s = 0; FSEQ_JOIN_RANDOM == joining && s < S; ++s)
-		{
-			uint32_t const *a = A_ + s * m, *d = D_ + s * m;
-			auto const cn = prepare_copy_numbers((uint32_t) m, X, segs[s].lb, a, d, false);
-			uint32_t prev = 0;
-			for (auto const &x : cn)
-			{
-				fprintf(f, "%zu\t%llu\t%llu\t%u\t%u\t%u\t", s, (unsigned long long) segs[s].lb, (unsigned long long) segs[s].rb, c->segments[s].segment_size,
-				        x.substring_idx, x.copy_number - prev);
-				prev = x.copy_number;
-				fwrite(rows[x.substring_idx] + segs[s].lb, 1, segs[s].rb - segs[s].lb, f);
-				fputc('\n', f);
-			}
-		}
-	}
-	fflush(f);
-	if (f != stdout) fclose(f);
-	return FSEQ_OK;
-}
-
-int fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_segments, uint64_t const *lb, uint64_t const *rb,
-                           uint32_t const *a, uint32_t const *d, uint32_t *permutations)
-{
-	if (!m || !max_segment_size || !lb || !rb || !a || !d || !permutations) return FSEQ_E_ARG;
-	std::vector<JoinSegment> segs(n_segments);
-	for (uint64_t i = 0; i < n_segments; ++i) { segs[i].lb = lb[i]; segs[i].rb = rb[i]; }
-	greedy_match(m, max_segment_size, segs, a, d, permutations);
-	return FSEQ_OK;
-}
-
-int fseq_write_founders(fseq_ctx *c, uint8_t const *const *rows, uint32_t const *permutations, char const *path)
-{
-	if (!c || !rows || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
-	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
-	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the founders output file");
-	size_t const X = c->res.max_segment_size, S = c->segments.size();
-	// join_context.cc:341-356: line r = the segments' substrings of the rows permutations[s][r], one after the other.
-	// The lines are put together in memory -- a batch of them at a time, on a few host threads: a line is S pieces of a
-	// few hundred bytes from S different input rows -- and go out in one write per batch (one fwrite per piece was 41 of a
-	// drop-in BASELINE C3 run's ~150 ms, profiles/r03_e2e_C3_greedy.json).
-	size_t const line = (size_t) c->p.n + 1;
-	size_t const batch = std::max<size_t>(1, std::min<size_t>(X, (size_t) (256u << 20) / line));
-	std::vector<char> buf;
-	try { buf.resize(batch * line); } catch (std::bad_alloc const &) { if (f != stdout) fclose(f); return fail(c, FSEQ_E_OOM, "founders output buffer"); }
-	bool ok = true;
-	for (size_t r0 = 0; r0 < X && ok; r0 += batch)
-	{
-		size_t const r1 = std::min(X, r0 + batch);
-		unsigned const nth = (unsigned) std::max<size_t>(1, std::min<size_t>({(size_t) std::thread::hardware_concurrency(), (size_t) 8, r1 - r0}));
-		auto work = [&](unsigned t) {
-			for (size_t row = r0 + t; row < r1; row += nth)
-			{
-				char *out = buf.data() + (row - r0) * line;
-				for (size_t s = 0; s < S; ++s)
-				{
-					fseq_segment const &sg = c->segments[s];
-					memcpy(out + sg.lb, rows[permutations[s * X + row]] + sg.lb, sg.rb - sg.lb);
-				}
-				out[line - 1] = '\n';
-			}
-		};
-		std::vector<std::thread> ths;
-		for (unsigned t = 1; t < nth; ++t) ths.emplace_back(work, t);
-		work(0);
-		for (auto &th : ths) th.join();
-		ok = fwrite(buf.data(), 1, (r1 - r0) * line, f) == (r1 - r0) * line;
-	}
-	fflush(f);
-	if (f != stdout) fclose(f);
-	if (!ok) return fail(c, FSEQ_E_ARG, "writing the founders output file failed");
 	return FSEQ_OK;
 }
 

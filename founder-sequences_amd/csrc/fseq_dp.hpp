@@ -5,6 +5,7 @@
 #pragma once
 
 #include "fseq_kernels.hpp"
+#include "fseq_types.hpp"
 
 namespace fseq {
 
@@ -20,11 +21,7 @@ namespace fseq {
 // The first minimum of [b, t] inside one block (std::min_element, rmq.hh:116) is the lowest set
 // bit of K[t] at or above b -- every partial-block scan of rmq.hh in O(1).
 // Tb[p][j] / Tbv[p][j]: sparse-table sample (index / key) of rmq.hh's m_precalc[p][j].
-struct DpArrays {
-	uint32_t *M, *LB, *SZ, *Tb, *Tbv;
-	unsigned long long *K;
-	uint32_t tstride;
-};
+// (struct DpArrays {M, LB, SZ, Tb, Tbv, K, tstride}: fseq_types.hpp)
 
 // One workgroup of 16 waves, specialised: 14 compute waves that touch LDS only, one loader wave
 // that streams the per-column lists (and the old sparse-table samples the update needs) into LDS

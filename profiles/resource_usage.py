@@ -8,10 +8,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r02"
-src = os.path.join(ROOT, "founder-sequences_amd", "csrc", "fseq_api.hip")
-r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Rpass-analysis=kernel-resource-usage",
-                    "-o", "/dev/null", src], capture_output=True, text=True)
-txt = r.stderr
+# the library's translation units (founder-sequences_amd/build.py SRCS)
+units = ["fseq_api.hip", "fseq_api_join.hip"]
+txt = ""
+for u in units:
+    src = os.path.join(ROOT, "founder-sequences_amd", "csrc", u)
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-Rpass-analysis=kernel-resource-usage",
+                        "-o", "/dev/null", src], capture_output=True, text=True)
+    txt += r.stderr
 rows = []
 for b in re.split(r"(?=remark: Function Name:)", txt):
     m = re.match(r"remark: Function Name: (\S+)", b)
@@ -25,7 +29,7 @@ for b in re.split(r"(?=remark: Function Name:)", txt):
     dem = re.sub(r"^void ", "", re.sub(r"\(.*", "", dem))
     rows.append([dem, g("VGPRs"), g("AGPRs"), g("TotalSGPRs"), g("ScratchSize [bytes/lane]"), g("Occupancy [waves/SIMD]"),
                  g("VGPRs Spill"), g("SGPRs Spill"), g("LDS Size [bytes/block]")])
-out = ["# hipcc --offload-arch=gfx950 -O3 -std=c++17 -Rpass-analysis=kernel-resource-usage founder-sequences_amd/csrc/fseq_api.hip",
+out = ["# hipcc --offload-arch=gfx950 -O3 -std=c++17 -Rpass-analysis=kernel-resource-usage founder-sequences_amd/csrc/{fseq_api,fseq_api_join}.hip",
        "# kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | occupancy waves/SIMD | VGPR spill | SGPR spill | static LDS B (dynamic LDS not included)"]
 out += [" | ".join(r_) for r_ in sorted(rows)]
 path = os.path.join(ROOT, "profiles", "%s_kernel_resource_usage.txt" % prefix)
