@@ -15,6 +15,7 @@
 #include "fseq_stream2.hpp"
 #include "fseq_chainsort.hpp"
 #include "fseq_blockkeys.hpp"
+#include "fseq_blocktrie.hpp"
 #include "fseq_rowshard.hpp"
 
 #include <algorithm>
@@ -746,6 +747,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr; dev_free(c, &c->d_hdr); dev_free(c, &c->d_flags); dev_free(c, &c->d_recent);
 	dev_free(c, &c->d_chunk_r0); c->chunk_cap = 0; dev_free(c, &c->d_tau); c->tau_cap = 0;
 	dev_free(c, &c->d_bk); c->bk_blocks = 0; dev_free(c, &c->d_bkws); c->bkws_words = 0; dev_free(c, &c->d_todo); c->todo_cap = 0;
+	dev_free(c, &c->d_btws); c->btws_words = 0; dev_free(c, &c->d_only); c->only_cap = 0;
 	dev_free(c, &c->d_tb); c->tb_cap = 0; c->tb_win = 0;
 	dev_free(c, &c->dp.M); dev_free(c, &c->dp.LB); dev_free(c, &c->dp.SZ); dev_free(c, &c->dp.K); dev_free(c, &c->dp.Tb); dev_free(c, &c->dp.Tbv);
 	dev_free(c, &c->d_Mprev); dev_free(c, &c->d_spec); c->spec_cap = 0;
@@ -832,7 +834,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1;
 	return FSEQ_OK;
 }
 
@@ -873,7 +875,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1;
 	return FSEQ_OK;
 }
 
@@ -1509,6 +1511,7 @@ struct LongRun {
 	bool keyspace = false;
 	bool tree_ran = false;                   // phase A ran the key-space tree at all (else: the column sweep did every block, as last time)
 	bool tree_alone = false;                 // phase A ran the key-space tree without the column sweep behind it (no block was given up last time)
+	bool trie_ran = false, trie_alone = false;   // ... the trie over 16-column words (streamed rows); ... without the key-space tree behind it
 };
 
 // the aliases every phase uses
@@ -1554,8 +1557,44 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		todo = c->d_todo;
 		HIP_TRY(c, hipMemsetAsync(todo, tree ? 0 : 0x01, (size_t) my_blocks * 4, st));     // (no tree: every block is the sweep's)
 	}
-	if (keyspace) HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 8, st));
-	if (tree && c->use_stream)
+	if (keyspace) HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 12, st));
+	// Streamed rows, 2 bits per symbol: the trie over 16-column words first (fseq_blocktrie.hpp) -- it reads the block once and
+	// ranks only its distinct keys -- and the key-space tree for the blocks it gives up (too many distinct keys for its table).
+	// As with the tree and the sweep, what the last run on this input saw decides what is launched: nothing given up -> the
+	// trie alone; most blocks -> no trie.  The tests of the tree's slices (FSEQ_BLOCKKEYS_CAP, _NO_LIMIT) keep the tree.
+	bool const trie = tree && limited && c->use_stream && c->bsh == 2 && m <= 16u * 1024u * 8u && c->B < 65536u && !c->tune.no_blocktrie
+	                  && (c->ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(c->d_msa) & 3u) == 0
+	                  && !(c->bt_given_up >= 0 && 2u * (uint32_t) c->bt_given_up > my_blocks);
+	bool const tree_after = tree && !(trie && c->bt_given_up == 0);
+	R.trie_ran = trie;
+	R.trie_alone = trie && !tree_after;
+	uint32_t const *only = nullptr;
+	if (trie)
+	{
+		int ncu = 0;
+		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+		uint32_t const groups = std::min<uint32_t>(my_blocks, (uint32_t) std::max(1, ncu));
+		size_t const per = (blocktrie_ws_words(c->B) + 15) & ~size_t(15);
+		if (c->btws_words < per * groups)
+		{
+			if ((rc = dev_alloc(c, &c->d_btws, per * groups))) return rc;
+			c->btws_words = per * groups;
+		}
+		if (c->only_cap < my_blocks) { if ((rc = dev_alloc(c, &c->d_only, my_blocks))) return rc; c->only_cap = my_blocks; }
+		HIP_TRY(c, hipMemsetAsync(c->d_only, 0, (size_t) my_blocks * 4, st));
+		uint32_t const nwords = (m + 15u) / 16u;
+		auto launch = [&](auto kern) {
+			(void) allow_lds(kern, BT_LDS_BYTES);
+			hipLaunchKernelGGL(kern, dim3(groups), dim3(BT_T), BT_LDS_BYTES, st, c->d_msa, c->ld, m, n, c->B, my_blocks,
+			                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
+			                   c->d_btws, per, c->d_flags + 66, c->d_only);
+		};
+		if (nwords <= 2u * 1024u) launch(k_blocktrie<2>);
+		else if (nwords <= 4u * 1024u) launch(k_blocktrie<4>);
+		else launch(k_blocktrie<8>);
+		only = c->d_only;
+	}
+	if (tree_after && c->use_stream)
 	{
 		// phase A in key space, streamed rows: one workgroup per CU with its own workspace, blocks round-robin
 		int ncu = 0;
@@ -1569,9 +1608,9 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		}
 		hipLaunchKernelGGL(k_blockkeys_stream, dim3(groups), dim3(1024), c->bk_lds, st, c->d_msa, c->ld, m, n, c->B, c->bsh, my_blocks,
 		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u), todo);
+		                   c->d_bkws, per, c->bk_cap_words, c->d_flags + 64, (c->tune.blockkeys_wide ? 1u : 0u) | (c->tune.blockkeys_single ? 2u : 0u), todo, only);
 	}
-	else if (tree)
+	else if (tree_after)
 	{
 		// phase A in key space (fseq_blockkeys.hpp)
 		size_t const per = (blockkeys_scratch_halfwords(m, c->B, c->bsh) + 7) & ~size_t(7);
@@ -2064,7 +2103,8 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	h_flags[4] = 0;
 	HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
 	h_flags[5] = 0;
-	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 8, hipMemcpyDeviceToHost, st));
+	h_flags[6] = 0;
+	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 12, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	if (keyspace)
 	{
@@ -2074,6 +2114,12 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		// (the tree ran alone because no block was given up last time; the same input gives the same outcome)
 		if (R.tree_alone && h_flags[5] != 0u) return fail(c, FSEQ_E_HIP, "internal: the key-space tree gave up blocks it ranked in the run before");
 		c->bk_given_up = (int) h_flags[5];
+		if (R.trie_ran)
+		{
+			if (R.trie_alone && h_flags[6] != 0u) return fail(c, FSEQ_E_HIP, "internal: the block trie gave up blocks it ranked in the run before");
+			c->bt_given_up = (int) h_flags[6];
+			c->tm.phase_a_trie_given_up = h_flags[6];
+		}
 	}
 	{
 		float f = 0;
@@ -2551,7 +2597,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2575,7 +2621,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2679,7 +2725,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1;
 	return FSEQ_OK;
 }
 

@@ -1061,15 +1061,17 @@ __global__ __launch_bounds__(T) void k_blockkeys(
 __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
-	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide, uint32_t *__restrict__ todo)
+	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide, uint32_t *__restrict__ todo,
+	uint32_t const *__restrict__ only = nullptr)
 {
-	// (todo, sliced[1]: as in k_blockkeys)
+	// (todo, sliced[1]: as in k_blockkeys); only: the blocks with a non-zero entry (what the trie of fseq_blocktrie.hpp gave up)
 	// wide bit 0: 32-bit ids from the start (tests; else a block is tried with halfword ids first); bit 1: leaves one by one
 	bool const pair_leaves = !(wide & 2u);
 	wide &= 1u;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x)
 	{
+		if (only && only[b] == 0u) continue;
 		uint64_t const k0 = col0 + (uint64_t) b * B;
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		size_t const ob = (size_t) b * m;

@@ -88,6 +88,7 @@ struct Tuning {
 	bool chain_stream_single = false;    // FSEQ_CHAIN_STREAM_SINGLE: ... as the sorted step on one workgroup per chain (not spread over the chip)
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
+	bool no_blocktrie = false;           // FSEQ_NO_BLOCKTRIE: the streamed phase A without the trie over 16-column words (fseq_blocktrie.hpp): the key-space tree on every block
 	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
 	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
 	std::string stream2;                 // FSEQ_STREAM2: "T,E[,pack]" configuration of the streamed phase C, "0" = first form
@@ -129,6 +130,7 @@ struct Tuning {
 		else if (n == "FSEQ_BLOCKKEYS_WIDE") blockkeys_wide = on;
 		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
+		else if (n == "FSEQ_NO_BLOCKTRIE") no_blocktrie = on;
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
 		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
@@ -201,6 +203,11 @@ struct fseq_ctx {
 	int bk_given_up = -1;                    // ... in the last run on this input (-1: not run yet): later runs skip the sweep's launch when
 	                                         // it was none, and the tree altogether when it was most blocks
 	size_t bk_lds = 0;
+	uint32_t *d_btws = nullptr;              // phase A, streamed rows, the trie (fseq_blocktrie.hpp): per-workgroup workspace (the nodes of the levels)
+	size_t btws_words = 0;
+	uint32_t *d_only = nullptr;              // ... blocks the trie gave up on (the key-space tree does them)
+	size_t only_cap = 0;
+	int bt_given_up = -1;                    // ... in the last run on this input (-1: not run yet)
 	uint32_t *d_chunk_r0 = nullptr;          // speculative DP: first round of every chunk (+ the end)
 	uint32_t chunk_cap = 0;
 	uint2 *d_tau = nullptr;                  // merge thresholds (k_seg_tau) / counts

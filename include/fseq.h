@@ -25,7 +25,8 @@ extern "C" {
 /* 2: fseq_timings grew (dp_chunks .. reserved), FSEQ_E_PEER, fseq_set_memory_budget, fseq_set_progress /
  *    fseq_step_max / fseq_current_step; the fseq_debug_* entry points moved to include/fseq_debug.h */
 /* 3: fseq_shard_abort */
-#define FSEQ_ABI_VERSION 3
+/* 4: fseq_timings.phase_a_trie_given_up (the struct keeps its size: the field lies in what was tail padding) */
+#define FSEQ_ABI_VERSION 4
 
 enum {
 	FSEQ_OK             = 0,
@@ -101,6 +102,7 @@ typedef struct fseq_timings {
 	uint32_t dp_sweeps;             /* sweeps it compared until no key changed (>= 1000: serial fallback took over) */
 	uint32_t phase_a_fallbacks;     /* blocks in which a merge of the key-space tree exceeded the LDS bitmap and ran in slices */
 	uint32_t phase_a_given_up;      /* blocks the key-space tree handed to the column sweep (their merges would have sliced past the budget) */
+	uint32_t phase_a_trie_given_up; /* streamed rows: blocks the trie over 16-column words handed to the key-space tree (too many distinct keys) */
 } fseq_timings;
 
 uint32_t    fseq_abi_version(void);

@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(pkg):
     lib = pkg.load_library()
     for name in _declared_symbols() + _declared_symbols("fseq_debug.h"):
         assert hasattr(lib, name), name
-    assert lib.fseq_abi_version() == 3
+    assert lib.fseq_abi_version() == 4
     assert lib.fseq_strerror(pkg.FSEQ_E_PEER).decode().startswith("another rank")
     assert lib.fseq_strerror(2).decode().startswith("unable to reduce")
 

@@ -136,6 +136,7 @@ def test_streamed_phase_a_id_width(pkg, monkeypatch, wide):
     """The streamed key-space tree keeps its ids as halfwords and runs a block again with 32-bit ids once a range has
     more than 65,536 distinct keys: 70,000 random rows are all distinct after a dozen columns (the fallback), a
     mosaic of few founders never gets there; FSEQ_BLOCKKEYS_WIDE forces 32 bits from the start."""
+    monkeypatch.setenv("FSEQ_NO_BLOCKTRIE", "1")             # (the mosaic would be the trie's otherwise)
     if wide:
         monkeypatch.setenv("FSEQ_BLOCKKEYS_WIDE", "1")
     rng = np.random.default_rng(11)
@@ -149,6 +150,7 @@ def test_streamed_phase_a_leaves_one_by_one(pkg, monkeypatch):
     """The streamed key-space tree ranks two leaves (16 columns of 2-bit symbols) at once from the packed columns
     (bk_pair_leaf); FSEQ_BLOCKKEYS_SINGLE keeps the leaves one by one, which is also what a pair falls back to when its
     D_lo x D_hi bitmap does not fit (random rows: 4^8 distinct words per leaf) and what wider symbols use."""
+    monkeypatch.setenv("FSEQ_NO_BLOCKTRIE", "1")
     monkeypatch.setenv("FSEQ_BLOCKKEYS_SINGLE", "1")
     msa = fso.synth_msa(fso.synth_spec(48, 20, 64, 1e-4, 0), 30000, 200)
     compare_long(pkg, msa, 8, block_len=72)
@@ -169,6 +171,75 @@ def test_streamed_phase_a_with_more_rows_than_bitmap_bits(pkg, monkeypatch):
     msa = (rng.integers(0, 4, size=(70000, 48)) + 65).astype(np.uint8)
     ctx, _ = compare_long(pkg, msa, 8, block_len=24)
     assert ctx.timings()["phase_a_fallbacks"] == 0           # (the key-space kernel did not run at all)
+
+
+def _block_states_match(ctx, msa, every=1):
+    n = msa.shape[1]
+    bl, nbk = ctx.timings()["block_len"], ctx.timings()["n_blocks"]
+    p = fso.Pbwt(msa)
+    for b in range(0, nbk + 1, every):
+        while p.idx < min(n, b * bl):
+            p.step()
+        a, d = ctx.debug_block_state(b)
+        assert np.array_equal(a, p.a) and np.array_equal(d, p.d), b
+
+
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed,B,given_up", [
+    (12000, 500, 20, 12, 120, 3e-4, 41, 64, 0),           # SL = 2 (750 words of 16 rows), blocks of four groups
+    (20003, 330, 15, 16, 100, 2e-4, 61, 50, 0),           # m not a multiple of 16, a last group of 2 columns, a last block of 30
+    (40000, 260, 12, 20, 1000, 1e-4, 62, 100, 0),         # SL = 4
+    (40000, 260, 12, 20, 64, 1e-4, 62, 100, 0),           # ... every row changes its founder at column 128: 8,000 nodes with siblings in that level
+    (100000, 200, 10, 64, 50, 5e-5, 0x5EED0004, 0, None), # BASELINE C4's rows: SL = 8, the library's own block length
+    (131072, 96, 8, 30, 1000, 5e-5, 63, 37, 0),           # the most rows the trie takes
+])
+def test_streamed_phase_a_trie(pkg, monkeypatch, m, n, L, K, Brec, mu, seed, B, given_up):
+    """Streamed rows at 2 bits per symbol: phase A sorts the rows into their key classes with a trie over 16-column words
+    (an exact hash table of (class, word) pairs per level) and ranks the trie instead of the rows (fseq_blocktrie.hpp).
+    Every block boundary state against the oracle's pBWT, the run against the oracle, the same again without the trie; the
+    second run on a context launches the trie alone (nothing was given up)."""
+    msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, 0), m, n)
+    ctx, ref = compare_long(pkg, msa, L, block_len=B)
+    t = ctx.timings()
+    assert (given_up is None or t["phase_a_trie_given_up"] == given_up) and t["phase_a_given_up"] == 0, t
+    _block_states_match(ctx, msa)
+    tb = ctx.traceback().copy()
+    ctx.run()                                                # the trie alone (if nothing was given up)
+    assert np.array_equal(ctx.traceback(), tb) and ctx.timings()["phase_a_trie_given_up"] == t["phase_a_trie_given_up"]
+    _block_states_match(ctx, msa, every=3)
+    monkeypatch.setenv("FSEQ_NO_BLOCKTRIE", "1")
+    ctx2 = run_gpu(pkg, msa, L, block_len=B)
+    assert np.array_equal(ctx2.traceback(), tb)
+
+
+def test_streamed_phase_a_trie_gives_blocks_up(pkg):
+    """What does not fit the trie's table goes to the key-space tree, block by block: columns 0..95 of 30,000 rows are a
+    mosaic of few founders (the trie's), columns 96..191 random (every row its own key after eight columns: more than 12,288
+    nodes in a level), then a mosaic again.  A level with thousands of siblings under one parent (~2,900 distinct words in the last
+    group of a block, each row otherwise like its founder) is ranked by the trie: its list goes through LDS in pieces."""
+    m = 30000
+    rng = np.random.default_rng(71)
+    a = fso.synth_msa(fso.synth_spec(72, 10, 40, 2e-4, 0), m, 288)
+    msa = a.copy()
+    codes = np.unique(a)
+    msa[:, 96:192] = codes[rng.integers(0, len(codes), size=(m, 96))]
+    ctx, _ = compare_long(pkg, msa, 8, block_len=48)
+    t = ctx.timings()
+    assert t["n_blocks"] == 6 and t["phase_a_trie_given_up"] == 2, t
+    _block_states_match(ctx, msa)
+    tb = ctx.traceback().copy()
+    try:
+        ctx.run()                                            # (trie, then the tree on the two blocks, as the first time)
+    except pkg.NoReduction:
+        pass
+    assert np.array_equal(ctx.traceback(), tb) and ctx.timings()["phase_a_trie_given_up"] == 2
+    # many siblings under one parent
+    msa = fso.synth_msa(fso.synth_spec(73, 6, 400, 0.0, 0), m, 96)
+    codes = np.unique(msa)
+    words = rng.integers(0, len(codes), size=(3000, 8))
+    msa[:3000, 88:96] = codes[words]
+    ctx, _ = compare_long(pkg, msa, 8, block_len=96)
+    assert ctx.timings()["phase_a_trie_given_up"] == 0
+    _block_states_match(ctx, msa)
 
 
 @pytest.mark.parametrize("fan", [0, 2, 3, 5, 64])
