@@ -1562,7 +1562,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 	// ranks only its distinct keys -- and the key-space tree for the blocks it gives up (too many distinct keys for its table).
 	// As with the tree and the sweep, what the last run on this input saw decides what is launched: nothing given up -> the
 	// trie alone; most blocks -> no trie.  The tests of the tree's slices (FSEQ_BLOCKKEYS_CAP, _NO_LIMIT) keep the tree.
-	bool const trie = tree && limited && c->use_stream && c->bsh == 2 && m <= 16u * 1024u * 8u && c->B < 65536u && !c->tune.no_blocktrie
+	bool const trie = tree && limited && c->use_stream && c->bsh == 2 && m <= 16u * 1024u * 32u && c->B < 65536u && !c->tune.no_blocktrie
 	                  && (c->ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(c->d_msa) & 3u) == 0
 	                  && !(c->bt_given_up >= 0 && 2u * (uint32_t) c->bt_given_up > my_blocks);
 	bool const tree_after = tree && !(trie && c->bt_given_up == 0);
@@ -1574,7 +1574,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		int ncu = 0;
 		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
 		uint32_t const groups = std::min<uint32_t>(my_blocks, (uint32_t) std::max(1, ncu));
-		size_t const per = (blocktrie_ws_words(c->B) + 15) & ~size_t(15);
+		size_t const per = (blocktrie_ws_words(m, c->B) + 15) & ~size_t(15);
 		if (c->btws_words < per * groups)
 		{
 			if ((rc = dev_alloc(c, &c->d_btws, per * groups))) return rc;
@@ -1582,16 +1582,10 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		}
 		if (c->only_cap < my_blocks) { if ((rc = dev_alloc(c, &c->d_only, my_blocks))) return rc; c->only_cap = my_blocks; }
 		HIP_TRY(c, hipMemsetAsync(c->d_only, 0, (size_t) my_blocks * 4, st));
-		uint32_t const nwords = (m + 15u) / 16u;
-		auto launch = [&](auto kern) {
-			(void) allow_lds(kern, BT_LDS_BYTES);
-			hipLaunchKernelGGL(kern, dim3(groups), dim3(BT_T), BT_LDS_BYTES, st, c->d_msa, c->ld, m, n, c->B, my_blocks,
-			                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-			                   c->d_btws, per, c->d_flags + 66, c->d_only);
-		};
-		if (nwords <= 2u * 1024u) launch(k_blocktrie<2>);
-		else if (nwords <= 4u * 1024u) launch(k_blocktrie<4>);
-		else launch(k_blocktrie<8>);
+		(void) allow_lds(k_blocktrie, BT_LDS_BYTES);
+		hipLaunchKernelGGL(k_blocktrie, dim3(groups), dim3(BT_T), BT_LDS_BYTES, st, c->d_msa, c->ld, m, n, c->B, my_blocks,
+		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
+		                   c->d_btws, per, c->d_flags + 66, c->d_only);
 		only = c->d_only;
 	}
 	if (tree_after && c->use_stream)

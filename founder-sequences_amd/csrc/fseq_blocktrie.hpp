@@ -8,45 +8,51 @@
 //   phase 1  the block's columns are read ONCE, sixteen at a time from the LAST group to the first (the later column is
 //            the more significant one: libbio's pbwt sorts by reversed prefixes).  A thread holds the class ids of its
 //            16 * SL rows in registers; per group it transposes 16 packed words (16 rows x 16 columns of 2 bits) into the
-//            rows' 32-bit group words and looks (class so far, word) up in a hash table in LDS that holds the FULL 46-bit
-//            pair -- equal pairs meet in one slot, different pairs never do, so the classes are exact, no fingerprints
-//            to verify -- the slot number is the row's new class id.  After a group the occupied slots are the nodes of
-//            that trie level, {slot, parent slot, word}; they go to a per-workgroup workspace (L2 / HBM).
+//            rows' 32-bit group words.  A class keeps its id while it does not split: `direct[id]` holds the word of the
+//            first row of the class that got there in this group (one compare-and-swap); a row with that word keeps its id
+//            -- one LDS read and one compare, no hashing, no collisions: nearly every row, a class splits only where a row
+//            first differs.  A row with another word looks (class, word) up in a hash table that holds the FULL pair --
+//            equal pairs meet in one slot, different pairs never do, so the classes are exact, no fingerprints to verify
+//            -- and whoever creates the entry draws a new id from a counter.  After a group the live ids are the nodes
+//            of that trie level, {id, parent id, word}; they go to a per-workgroup workspace (L2 / HBM).
 //   phase 2  the trie is ranked level by level in LDS: the nodes of a level in the order of (rank of the parent, word).
-//            Nearly every parent has one child (a new class appears only where a row first differs): count the children
-//            per parent rank, prefix sum, single children take their parent's place and divergence; the few nodes with
-//            siblings are collected in a list and ranked among them by comparing words; a sibling's divergence is the
-//            last column in which it differs from the next smaller one.
+//            Nearly every parent has one child: count the children per parent rank, prefix sum, single children take
+//            their parent's place and divergence; the nodes with siblings are collected in a list and ranked among them by
+//            comparing words; a sibling's divergence is the last column in which it differs from the next smaller one.
 //   output   rank of a row = rank of its last class (registers -> 16 words per thread and slot), keyd, nkeys: exactly
 //            what blockkeys_tree_stream writes.
-// Whatever does not fit (a level with more than BT_NK_MAX nodes, more than BT_LIST nodes with siblings in one level:
-// diverse data) is given up: todo[b] = 1, and the key-space tree does that block.  One workgroup of 1024 threads per
-// CU, blocks round-robin; 2 bits per symbol (sigma <= 4) and m <= 16 * 1024 * SL rows.
+// Whatever does not fit (more than BT_NK_MAX classes, more than BT_OVF new ones in one group: diverse data) is given up:
+// todo[b] = 1, and the key-space tree does that block.  One workgroup of 1024 threads per CU, blocks round-robin; 2 bits
+// per symbol (sigma <= 4) and m <= 16 * 1024 * SL rows.
 #pragma once
 
 #include "fseq_blockkeys.hpp"
 
 namespace fseq {
 
-constexpr uint32_t BT_SLOTS = 16384;              // hash table: 16,384 pairs of 8 bytes = 128 KB of LDS
-constexpr uint32_t BT_NK_MAX = 12288;             // nodes per trie level (load <= 0.75)
-constexpr uint32_t BT_LIST = 2048;                // nodes with siblings per level
-constexpr uint32_t BT_MAXPROBE = BT_SLOTS;        // (a full turn: whether a level fits never depends on the order of the inserts)
+constexpr uint32_t BT_NK_MAX = 12288;             // classes (ids) of a block
+constexpr uint32_t BT_OVF = 8192;                 // slots of the pair table: the classes one group can add
+constexpr uint32_t BT_LIST = 2048;                // nodes with siblings per piece of the list
+constexpr uint32_t BT_SENT = 0xFFFFFFFFu;         // direct[]: nobody here yet (a row whose word is this value goes to the pair table)
+constexpr uint32_t BT_FLAG = 0x8000u;             // a row's id until the end of the group: FLAG | slot of its pair (the creator of the entry writes the id)
 constexpr int BT_T = 1024;
-constexpr int BT_PER = BT_NK_MAX / BT_T;          // entries of the rank-indexed arrays per thread (12)
+constexpr int BT_PER = BT_NK_MAX / BT_T;          // entries of the id- / rank-indexed arrays per thread (12)
 
-// LDS (bytes): phase 1 = the table; phase 2 = rank by slot (two), divergence by rank (two), children per rank, the list
-constexpr size_t BT_OFF_RP = 0, BT_OFF_RC = 32768, BT_OFF_DP = 65536, BT_OFF_DC = BT_OFF_DP + 2 * BT_NK_MAX,
-                 BT_OFF_CNT = BT_OFF_DC + 2 * BT_NK_MAX, BT_OFF_LIST = BT_OFF_CNT + 2 * BT_NK_MAX,
+// LDS (bytes): phase 1 = direct[] + the pair table; phase 2 = rank by id (two), divergence by rank (two), children per rank, the list
+constexpr size_t BT_OFF_DIRECT = 0, BT_OFF_PAIRS = 4 * (size_t) BT_NK_MAX;
+constexpr size_t BT_OFF_RP = 0, BT_OFF_RC = 2 * (size_t) BT_NK_MAX, BT_OFF_DP = 4 * (size_t) BT_NK_MAX, BT_OFF_DC = 6 * (size_t) BT_NK_MAX,
+                 BT_OFF_CNT = 8 * (size_t) BT_NK_MAX, BT_OFF_LIST = 10 * (size_t) BT_NK_MAX,
                  BT_OFF_VARS = BT_OFF_LIST + 8 * BT_LIST;
-static_assert(BT_OFF_VARS >= 8 * (size_t) BT_SLOTS, "the small variables lie behind the table");
+static_assert(BT_OFF_VARS >= BT_OFF_PAIRS + 8 * (size_t) BT_OVF, "the small variables lie behind the tables");
 constexpr size_t BT_LDS_BYTES = BT_OFF_VARS + 256;
 
-// words per WORKGROUP of the workspace: node counts per level, the nodes (two words each), the nodes with siblings of one level
+// words per WORKGROUP of the workspace: the rows' ids (two to a word), node counts per level, the nodes (two words each), the nodes
+// with siblings of one level
 __host__ __device__ inline uint32_t blocktrie_levels(uint32_t B) { return (B + 15u) / 16u; }
-__host__ __device__ inline size_t blocktrie_ws_words(uint32_t B)
+__host__ __device__ inline size_t blocktrie_ws_words(uint32_t m, uint32_t B)
 {
-	return (size_t) blocktrie_levels(B) * (1u + 2u * (size_t) BT_NK_MAX) + 2u * (size_t) BT_NK_MAX + 64;
+	size_t const nslots = ((m + 15u) / 16u + BT_T - 1u) / BT_T;
+	return 8u * nslots * BT_T + (size_t) blocktrie_levels(B) * (1u + 2u * (size_t) BT_NK_MAX) + 2u * (size_t) BT_NK_MAX + 64;
 }
 
 // 16 x 16 matrix of 2-bit elements: x[c] bits [2r, 2r + 1]  ->  x[r] bits [2c, 2c + 1]  (four stages, written out: as a loop
@@ -72,31 +78,46 @@ __device__ __forceinline__ void bt_transpose16(uint32_t (&x)[16])
 	bt_transpose_stage<1>(x);
 }
 
-// 14 bits out of (class so far, word): 24-bit multiplies (full rate; a 32-bit multiply is a quarter-rate instruction here)
+// 13 bits out of (class, word): 24-bit multiplies (full rate; a 32-bit multiply is a quarter-rate instruction here)
 __device__ __forceinline__ uint32_t bt_hash(uint32_t parent, uint32_t word)
 {
 	uint32_t const x = __umul24(word, 0x9E3779u) ^ __umul24(word >> 8, 0x85EBCBu) ^ __umul24(parent, 0xC2B2AFu);
-	return (x >> 12) & (BT_SLOTS - 1u);
+	return (x >> 12) & (BT_OVF - 1u);
 }
 
-// slot of the pair in the table (inserted if new); BT_SLOTS: the table is full
-__device__ __forceinline__ uint32_t bt_find(unsigned long long *tab, uint32_t parent, uint32_t word, uint32_t h, unsigned long long first)
+// A row whose word is not what direct[] holds for its class: the class's first row of this group registers its word there and
+// keeps the id; every other word of the class goes through the pair table -- entry = {word, class | id << 14 | ready}: whoever
+// creates it draws the id (returned); who finds it gets BT_FLAG | slot and reads the id behind the group's barrier.
+// vars[5]: the next id; *full: no room (ids or slots).
+__device__ __forceinline__ uint32_t bt_other_word(uint32_t *direct, unsigned long long *pairs, uint32_t *vars, uint32_t p, uint32_t w, uint32_t e, uint32_t &full)
 {
-	unsigned long long const key = ((unsigned long long) parent << 32) | word;
-	unsigned long long cur = first;
-#pragma unroll 1
-	for (uint32_t probe = 0; probe < BT_MAXPROBE; ++probe)
+	if (e == BT_SENT && w != BT_SENT)
 	{
-		if (cur == key) return h;
+		uint32_t const old = atomicCAS(direct + p, BT_SENT, w);
+		if (old == BT_SENT || old == w) return p;
+	}
+	unsigned long long const fresh = ((unsigned long long) p << 32) | w;
+	uint32_t h = bt_hash(p, w);
+#pragma unroll 1
+	for (uint32_t probe = 0; probe < BT_OVF; ++probe)
+	{
+		unsigned long long cur = pairs[h];
 		if (cur == ~0ull)
 		{
-			unsigned long long const old = atomicCAS(tab + h, ~0ull, key);
-			if (old == ~0ull || old == key) return h;
+			cur = atomicCAS(pairs + h, ~0ull, fresh);
+			if (cur == ~0ull)
+			{
+				uint32_t id = atomicAdd(vars + 5, 1u);
+				if (id >= BT_NK_MAX) { full = 1u; id = 0u; }
+				reinterpret_cast<uint32_t *>(pairs + h)[1] = p | (id << 14) | (1u << 28);
+				return id;
+			}
 		}
-		h = (h + 1u) & (BT_SLOTS - 1u);
-		cur = tab[h];
+		if ((uint32_t) cur == w && ((uint32_t) (cur >> 32) & 0x3FFFu) == p) return BT_FLAG | h;
+		h = (h + 1u) & (BT_OVF - 1u);
 	}
-	return BT_SLOTS;
+	full = 1u;
+	return 0u;
 }
 
 #ifdef FSEQ_BT_STAMPS
@@ -105,14 +126,31 @@ __device__ __forceinline__ uint32_t bt_find(unsigned long long *tab, uint32_t pa
 #define BT_STAMP(i) do {} while (0)
 #endif
 
-template <int SL>
+// the 16 packed words of a slot's group (zero behind the block's last column) and the ids of its 16 rows
+__device__ __forceinline__ void bt_fetch(uint8_t const *__restrict__ msa, size_t ld, uint64_t kc, uint64_t kend, uint32_t wi, uint32_t nwords,
+                                         uint4 const *__restrict__ idw, bool with_ids, uint32_t (&x)[16], uint32_t (&cur)[8])
+{
+	if (wi < nwords)
+	{
+#pragma unroll
+		for (int c = 0; c < 16; ++c)
+			x[c] = (kc + (uint64_t) c < kend) ? *reinterpret_cast<uint32_t const *>(msa + (kc + (uint64_t) c) * ld + 4ull * wi) : 0u;
+		if (with_ids)
+		{
+			uint4 const a = idw[2u * (size_t) wi], b = idw[2u * (size_t) wi + 1u];
+			cur[0] = a.x; cur[1] = a.y; cur[2] = a.z; cur[3] = a.w; cur[4] = b.x; cur[5] = b.y; cur[6] = b.z; cur[7] = b.w;
+		}
+	}
+}
+
 __global__ __launch_bounds__(BT_T) void k_blocktrie(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
 	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t *__restrict__ given_up /* [0]: blocks given up */, uint32_t *__restrict__ todo)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
-	unsigned long long *const tab = reinterpret_cast<unsigned long long *>(smem);
+	uint32_t *const direct = reinterpret_cast<uint32_t *>(smem + BT_OFF_DIRECT);
+	unsigned long long *const pairs = reinterpret_cast<unsigned long long *>(smem + BT_OFF_PAIRS);
 	uint16_t *const RA = reinterpret_cast<uint16_t *>(smem + BT_OFF_RP);
 	uint16_t *const RB = reinterpret_cast<uint16_t *>(smem + BT_OFF_RC);
 	uint16_t *const DA = reinterpret_cast<uint16_t *>(smem + BT_OFF_DP);
@@ -120,18 +158,22 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 	uint16_t *const cnt = reinterpret_cast<uint16_t *>(smem + BT_OFF_CNT);
 	uint32_t *const cnt32 = reinterpret_cast<uint32_t *>(smem + BT_OFF_CNT);
 	uint2 *const list = reinterpret_cast<uint2 *>(smem + BT_OFF_LIST);
-	uint32_t *const vars = reinterpret_cast<uint32_t *>(smem + BT_OFF_VARS);      // [0 .. 2]: node counters of the levels (in turn); [3]: no room; [4]: list entries; [8 ..]: scan scratch
-	uint32_t const tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+	// vars: [0 .. 2]: node counters of the levels (in turn); [3]: no room; [4]: list entries; [5]: the next id; [8 ..]: scan scratch
+	uint32_t *const vars = reinterpret_cast<uint32_t *>(smem + BT_OFF_VARS);
+	uint32_t const tid = threadIdx.x, lane = lane_id();
 	uint32_t const nwords = (m + 15u) / 16u;
+	uint32_t const nslots = (nwords + BT_T - 1u) / BT_T;                  // <= 32 (the host checks m)
 	uint32_t *const wsg = ws + (size_t) blockIdx.x * ws_per_group;
+	uint4 *const idw = reinterpret_cast<uint4 *>(wsg);                      // ids of the rows, two to a word: 8 words per packed word of 16 rows
+	uint32_t *const wst = wsg + 8u * (size_t) nslots * BT_T;               // the trie: node counts per level, nodes, the list
 
 	for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x)
 	{
 		uint64_t const k0 = col0 + (uint64_t) b * B;
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 		uint32_t const levels = ((uint32_t) (kend - k0) + 15u) / 16u;
-		uint32_t *const hdr = wsg;
-		uint2 *const nodes = reinterpret_cast<uint2 *>(wsg + ((levels + 1u) & ~1u));
+		uint32_t *const hdr = wst;
+		uint2 *const nodes = reinterpret_cast<uint2 *>(wst + ((levels + 3u) & ~3u));
 		uint2 *const glist = nodes + (size_t) levels * BT_NK_MAX;      // the nodes with siblings of the level at hand
 		size_t const ob = (size_t) b * m;
 
@@ -139,50 +181,44 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 		long long bt_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, bt_last = clock64();
 #endif
 		// ---------------- phase 1: the classes, group by group from the last one
-		uint32_t ids[SL][8];
-#pragma unroll
-		for (int s = 0; s < SL; ++s)
-#pragma unroll
-			for (int q = 0; q < 8; ++q) ids[s][q] = 0u;
-		if (tid == 0) { vars[0] = 0u; vars[1] = 0u; vars[2] = 0u; vars[3] = 0u; }
+		if (tid == 0) { vars[0] = 0u; vars[1] = 0u; vars[2] = 0u; vars[3] = 0u; vars[5] = 1u; }      // (id 0: every row, before the first group)
 		uint32_t level_base = 0;
 		bool bad = false;
 		for (uint32_t t = 0; t < levels; ++t)
 		{
 			uint32_t const g = levels - 1u - t;
 			uint64_t const kc = k0 + 16ull * g;
+			// (the first slot's words are on their way while the tables are cleared)
+			uint32_t xn[16], curn[8];
+#pragma unroll
+			for (int q = 0; q < 8; ++q) curn[q] = 0u;
+			bt_fetch(msa, ld, kc, kend, tid, nwords, idw, t != 0u, xn, curn);
 			{
 				uint4 *const t4 = reinterpret_cast<uint4 *>(smem);
 				uint4 const ones = make_uint4(~0u, ~0u, ~0u, ~0u);
 #pragma unroll
-				for (int i = 0; i < (int) (BT_SLOTS * 8 / 16 / BT_T); ++i) t4[tid + i * BT_T] = ones;
+				for (int i = 0; i < (int) ((4 * BT_NK_MAX + 8 * BT_OVF) / 16 / BT_T); ++i) t4[tid + i * BT_T] = ones;
 			}
 			if (tid == 0) vars[(t + 1u) % 3u] = 0u;            // (the counter of the level before is still being read)
 			__syncthreads();
 			BT_STAMP(0);
 			uint32_t full = 0;
-			// (the slots in a loop that stays a loop -- unrolled, the kernel is 280 KB of code and lives in the instruction
-			// cache's misses: the ids of the slot at hand are picked out of the register array and put back with selects)
+			uint32_t flagged = 0;                              // the slots in which one of my rows holds FLAG | slot of a pair
 #pragma unroll 1
-			for (int s = 0; s < SL; ++s)
+			for (uint32_t s = 0; s < nslots; ++s)
 			{
-				uint32_t const wi = (uint32_t) s * BT_T + tid;
+				uint32_t const wi = s * BT_T + tid;
+				uint32_t x[16], cur[8];
+#pragma unroll
+				for (int c = 0; c < 16; ++c) x[c] = xn[c];
+#pragma unroll
+				for (int q = 0; q < 8; ++q) cur[q] = curn[q];
+				// the next slot's words and ids are loaded while this one is looked up
+				if (s + 1u < nslots) bt_fetch(msa, ld, kc, kend, wi + BT_T, nwords, idw, t != 0u, xn, curn);
 				if (wi < nwords)
 				{
-					uint32_t cur[8];
-#pragma unroll
-					for (int s2 = 0; s2 < SL; ++s2)
-						if (s == s2)
-						{
-							asm volatile("" ::: "memory");          // (a branch on the uniform s, not eight selects per slot)
-#pragma unroll
-							for (int q = 0; q < 8; ++q) cur[q] = ids[s2][q];
-						}
-					uint32_t x[16];
-#pragma unroll
-					for (int c = 0; c < 16; ++c)
-						x[c] = (kc + (uint64_t) c < kend) ? *reinterpret_cast<uint32_t const *>(msa + (kc + (uint64_t) c) * ld + 4ull * wi) : 0u;
 					bt_transpose16(x);
+					BT_STAMP(6);
 					if (wi * 16u + 16u > m)
 					{
 						// the last word of a column: the positions behind row m - 1 follow its first row (same class throughout)
@@ -190,54 +226,81 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 #pragma unroll
 						for (int r = 1; r < 16; ++r) x[r] = ((uint32_t) r < valid) ? x[r] : x[0];
 					}
+					bool changed = t == 0u;
+					uint32_t fl = 0;
 #pragma unroll
 					for (int q4 = 0; q4 < 4; ++q4)
 					{
-						// four rows at a time, no branch while every look-up finds its pair where the hash points
-						uint32_t par[4], hh[4];
-						unsigned long long val[4];
+						// four rows at a time; no branch, and no new ids, while every row carries the word registered for its class
+						uint32_t par[4], e[4];
 #pragma unroll
 						for (int u = 0; u < 4; ++u)
 						{
 							int const r = q4 * 4 + u;
 							par[u] = (r & 1) ? (cur[r >> 1] >> 16) : (cur[r >> 1] & 0xFFFFu);
-							hh[u] = bt_hash(par[u], x[r]);
-							val[u] = tab[hh[u]];
+							e[u] = direct[par[u]];
 						}
 						bool miss = false;
 #pragma unroll
-						for (int u = 0; u < 4; ++u) miss |= val[u] != (((unsigned long long) par[u] << 32) | x[q4 * 4 + u]);
+						for (int u = 0; u < 4; ++u) miss |= e[u] != x[q4 * 4 + u] || e[u] == BT_SENT;
 						if (miss)
 						{
 #pragma unroll
 							for (int u = 0; u < 4; ++u)
 							{
-								hh[u] = bt_find(tab, par[u], x[q4 * 4 + u], hh[u], val[u]);
-								if (hh[u] == BT_SLOTS) { full = 1u; hh[u] = 0u; }
+								int const r = q4 * 4 + u;
+								if (e[u] != x[r] || e[u] == BT_SENT)
+								{
+									uint32_t const id = bt_other_word(direct, pairs, vars, par[u], x[r], e[u], full);
+									changed |= id != par[u];
+									par[u] = id;
+									fl |= id & BT_FLAG;
+								}
 							}
+							cur[2 * q4] = par[0] | (par[1] << 16);
+							cur[2 * q4 + 1] = par[2] | (par[3] << 16);
 						}
-						cur[2 * q4] = hh[0] | (hh[1] << 16);
-						cur[2 * q4 + 1] = hh[2] | (hh[3] << 16);
 					}
-#pragma unroll
-					for (int s2 = 0; s2 < SL; ++s2)
-						if (s == s2)
-						{
-							asm volatile("" ::: "memory");
-#pragma unroll
-							for (int q = 0; q < 8; ++q) ids[s2][q] = cur[q];
-						}
+					if (changed)
+					{
+						idw[2u * (size_t) wi] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+						idw[2u * (size_t) wi + 1u] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+					}
+					flagged |= fl ? (1u << s) : 0u;
+					BT_STAMP(1);
 				}
 			}
 			if (full) vars[3] = 1u;
 			BT_STAMP(1);
 			__syncthreads();
 			BT_STAMP(2);
-			// the occupied slots are the nodes of this level
+			// the rows that found a pair somebody else created: its id is in the table by now
+			while (flagged)
+			{
+				uint32_t const s = (uint32_t) __ffs((int) flagged) - 1u;
+				flagged &= flagged - 1u;
+				size_t const wi = (size_t) s * BT_T + tid;
+				uint4 const a = idw[2u * wi], c4 = idw[2u * wi + 1u];
+				uint32_t cur[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+				for (int q = 0; q < 8; ++q)
+				{
+					uint32_t v = cur[q];
+					if (v & BT_FLAG) v = (v & 0xFFFF0000u) | ((reinterpret_cast<uint32_t const *>(pairs + (v & (BT_OVF - 1u)))[1] >> 14) & 0x3FFFu);
+					if (v & (BT_FLAG << 16)) v = (v & 0x0000FFFFu) | (((reinterpret_cast<uint32_t const *>(pairs + ((v >> 16) & (BT_OVF - 1u)))[1] >> 14) & 0x3FFFu) << 16);
+					cur[q] = v;
+				}
+				idw[2u * wi] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
+				idw[2u * wi + 1u] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+			}
+			BT_STAMP(7);
+			// the live ids are the nodes of this level: who kept its id (direct[]), who got a new one (the pair table)
 			{
 				uint32_t mine = 0;
 #pragma unroll
-				for (int i = 0; i < (int) (BT_SLOTS / BT_T); ++i) mine += tab[tid + i * BT_T] != ~0ull ? 1u : 0u;
+				for (int i = 0; i < BT_PER; ++i) mine += direct[tid + i * BT_T] != BT_SENT ? 1u : 0u;
+#pragma unroll
+				for (int i = 0; i < (int) (BT_OVF / BT_T); ++i) mine += pairs[tid + i * BT_T] != ~0ull ? 1u : 0u;
 				uint32_t const inc = wave_incl_add(mine);
 				uint32_t base = 0;
 				if (lane == 63) base = atomicAdd(vars + t % 3u, inc);
@@ -245,13 +308,20 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 				if (level_base + base + mine <= (size_t) levels * BT_NK_MAX)
 				{
 #pragma unroll 4
-					for (int i = 0; i < (int) (BT_SLOTS / BT_T); ++i)
+					for (int i = 0; i < BT_PER; ++i)
 					{
-						unsigned long long const e = tab[tid + i * BT_T];
+						uint32_t const id = tid + i * BT_T;
+						uint32_t const w = direct[id];
+						if (w != BT_SENT) { nodes[level_base + base] = make_uint2(id | (id << 16), w); ++base; }
+					}
+#pragma unroll 4
+					for (int i = 0; i < (int) (BT_OVF / BT_T); ++i)
+					{
+						unsigned long long const e = pairs[tid + i * BT_T];
 						if (e != ~0ull)
 						{
-							uint32_t const slot = tid + i * BT_T;
-							nodes[level_base + base] = make_uint2(slot | ((uint32_t) (e >> 32) << 16), (uint32_t) e);
+							uint32_t const hi = (uint32_t) (e >> 32);
+							nodes[level_base + base] = make_uint2(((hi >> 14) & 0x3FFFu) | ((hi & 0x3FFFu) << 16), (uint32_t) e);
 							++base;
 						}
 					}
@@ -273,7 +343,7 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 
 		// ---------------- phase 2: the trie ranked level by level
 		uint16_t *Rp = RA, *Rc = RB, *Dp = DA, *Dc = DB;
-		__syncthreads();                                       // (the table is history: its LDS is the arrays of phase 2 now)
+		__syncthreads();                                       // (the tables are history: their LDS is the arrays of phase 2 now)
 		if (tid == 0) { Rp[0] = 0; Dp[0] = (uint16_t) (kend - k0); }
 		uint32_t nprev = 1;
 		level_base = 0;
@@ -316,14 +386,14 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 			for (int k = 0; k < BT_PER; ++k)
 				if (tid + k * BT_T < nt)
 				{
-					uint32_t const slot = mynd[k].x & 0x3FFFu;
+					uint32_t const id = mynd[k].x & 0x3FFFu;
 					uint32_t const r = myr[k];
 					uint32_t const e = cnt[r];
-					if (!(e & 0x8000u)) { Rc[slot] = (uint16_t) e; Dc[e] = Dp[r]; }
+					if (!(e & 0x8000u)) { Rc[id] = (uint16_t) e; Dc[e] = Dp[r]; }
 					else
 					{
 						uint32_t const at = atomicAdd(vars + 4, 1u);
-						uint2 const v = make_uint2(r | (slot << 16), mynd[k].y);
+						uint2 const v = make_uint2(r | (id << 16), mynd[k].y);
 						if (at < BT_LIST) list[at] = v;                   // (the first piece is in place already)
 						glist[at] = v;
 					}
@@ -333,96 +403,69 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 			// is a hundred entries but for a level in which many rows change (every row, where a recombination block of the
 			// founders ends) -- through LDS in pieces of BT_LIST
 			uint32_t const nl = vars[4];
-			if (nl)
+#pragma unroll 1
+			for (uint32_t k0_ = 0; k0_ < nl; k0_ += BT_T)
 			{
-				uint2 me[BT_PER];
-				uint32_t pos[BT_PER], pred[BT_PER];
-#pragma unroll
-				for (int k = 0; k < BT_PER; ++k)
-				{
-					me[k] = (tid + k * BT_T < nl) ? (tid + k * BT_T < BT_LIST ? list[tid + k * BT_T] : glist[tid + k * BT_T]) : make_uint2(0xFFFFu, 0u);      // (no such parent rank)
-					pos[k] = 0u; pred[k] = 0u;
-				}
+				uint32_t const i = k0_ + tid;
+				// (a list longer than one piece is staged over list[]: read from the workspace then)
+				uint2 const me = (i < nl) ? (nl <= BT_LIST ? list[i] : glist[i]) : make_uint2(0xFFFFu, 0u);      // (else: no such parent rank)
+				uint32_t const r = me.x & 0xFFFFu, w = me.y;
+				uint32_t pos = 0, pred = 0;
+#pragma unroll 1
 				for (uint32_t c0 = 0; c0 < nl; c0 += BT_LIST)
 				{
 					uint32_t const cn = min(BT_LIST, nl - c0);
-					if (c0)
+					if (nl > BT_LIST)
 					{
+						// (the list in pieces; the first one is in place for k0_ = 0 only)
 						__syncthreads();
 						for (uint32_t j = tid; j < cn; j += BT_T) list[j] = glist[c0 + j];
 						__syncthreads();
 					}
-#pragma unroll
-					for (int k = 0; k < BT_PER; ++k)
+#pragma unroll 4
+					for (uint32_t j = 0; j < cn; ++j)
 					{
-						if ((uint32_t) k * BT_T >= nl) break;                 // (uniform)
-						uint32_t const r = me[k].x & 0xFFFFu, w = me[k].y;
-						uint32_t p_ = pos[k], q_ = pred[k];
-						for (uint32_t j = 0; j < cn; ++j)
-						{
-							uint2 const o = list[j];
-							bool const below = (o.x & 0xFFFFu) == r && o.y < w;
-							p_ += below ? 1u : 0u;
-							q_ = (below && o.y >= q_) ? o.y : q_;
-						}
-						pos[k] = p_; pred[k] = q_;
+						uint2 const o = list[j];
+						bool const below = (o.x & 0xFFFFu) == r && o.y < w;
+						pos += below ? 1u : 0u;
+						pred = (below && o.y >= pred) ? o.y : pred;
 					}
 				}
-#pragma unroll
-				for (int k = 0; k < BT_PER; ++k)
-					if (tid + k * BT_T < nl)
-					{
-						uint32_t const r = me[k].x & 0xFFFFu;
-						uint32_t const at = (cnt[r] & 0x7FFFu) + pos[k];
-						Rc[me[k].x >> 16] = (uint16_t) at;
-						// the last column in which this word differs from the next smaller sibling (later columns in the higher bits)
-						Dc[at] = pos[k] == 0u ? Dp[r] : (uint16_t) (16u * g + ((31u - (uint32_t) __clz((int) (me[k].y ^ pred[k]))) >> 1) + 1u);
-					}
+				if (i < nl)
+				{
+					uint32_t const at = (cnt[r] & 0x7FFFu) + pos;
+					Rc[me.x >> 16] = (uint16_t) at;
+					// the last column in which this word differs from the next smaller sibling (later columns in the higher bits)
+					Dc[at] = pos == 0u ? Dp[r] : (uint16_t) (16u * g + ((31u - (uint32_t) __clz((int) (w ^ pred))) >> 1) + 1u);
+				}
 			}
 			__syncthreads();
 			{ uint16_t *x_ = Rp; Rp = Rc; Rc = x_; x_ = Dp; Dp = Dc; Dc = x_; }
 			nprev = nt;
 			level_base += nt;
 		}
-		if (bad)
-		{
-			if (tid == 0) { todo[b] = 1u; atomicAdd(given_up, 1u); }
-			__syncthreads();
-			continue;
-		}
 
 		BT_STAMP(4);
 		// ---------------- outputs
 #pragma unroll 1
-		for (int s = 0; s < SL; ++s)
+		for (uint32_t wi = tid; wi < nwords; wi += BT_T)
 		{
-			uint32_t const wi = (uint32_t) s * BT_T + tid;
-			if (wi < nwords)
-			{
-				uint32_t cur[8];
+			uint4 const a = idw[2u * (size_t) wi], c4 = idw[2u * (size_t) wi + 1u];
+			uint32_t const cur[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+			uint32_t const r0 = wi * 16u;
 #pragma unroll
-				for (int s2 = 0; s2 < SL; ++s2)
-					if (s == s2)
-					{
-						asm volatile("" ::: "memory");
-#pragma unroll
-						for (int q = 0; q < 8; ++q) cur[q] = ids[s2][q];
-					}
-				uint32_t const r0 = wi * 16u;
-#pragma unroll
-				for (int r = 0; r < 16; ++r)
-					if (r0 + (uint32_t) r < m) rank[ob + r0 + r] = Rp[(cur[r >> 1] >> (16 * (r & 1))) & 0x3FFFu];
-			}
+			for (int r = 0; r < 16; ++r)
+				if (r0 + (uint32_t) r < m) rank[ob + r0 + r] = Rp[(cur[r >> 1] >> (16 * (r & 1))) & 0x3FFFu];
 		}
 		for (uint32_t j = tid; j < nprev; j += BT_T) keyd[ob + j] = (uint32_t) (k0 + Dp[j]);
 		if (tid == 0) nkeys[b] = nprev;
-		__syncthreads();
+		__syncthreads();                                       // (LDS and the workspace are the next block's)
 #ifdef FSEQ_BT_STAMPS
 		BT_STAMP(5);
 		if ((tid == 0 || tid == 1000) && (b == 0 || b == 100 || b == 6))
-			printf("bt stamps block %u thread %u: clear %lld | slots %lld | wait %lld | dump %lld | phase 2 %lld | outputs %lld | keys %u\n",
-			       b, tid, bt_acc[0], bt_acc[1], bt_acc[2], bt_acc[3], bt_acc[4], bt_acc[5], nprev);
-#endif                                       // (LDS and the workspace are the next block's)
+			printf("bt stamps block %u thread %u: clear %lld | loads + transpose %lld | look-ups %lld | wait %lld | ids of found pairs %lld | dump %lld | phase 2 %lld | outputs %lld | keys %u\n",
+			       b, tid, bt_acc[0], bt_acc[6], bt_acc[1], bt_acc[2], bt_acc[7], bt_acc[3], bt_acc[4], bt_acc[5], nprev);
+#endif
 	}
 }
 
