@@ -113,12 +113,12 @@ struct Launch {
 #define FSEQ_BK_SIZES(X) X(256) X(320) X(512) X(768) X(1024)
 void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
                       uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
-                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced, uint32_t *todo)
+                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced, uint32_t *todo, uint32_t const *only = nullptr)
 {
 	switch (T)
 	{
 #define X(T_) case T_: hipLaunchKernelGGL((k_blockkeys<T_>), dim3(grid), dim3(T_), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0, \
-	                                          scratch, scratch_per_block, cap_words, sliced, todo); break;
+	                                          scratch, scratch_per_block, cap_words, sliced, todo, only); break;
 		FSEQ_BK_SIZES(X)
 #undef X
 		default: break;
@@ -145,6 +145,27 @@ hipError_t prepare_blockkeys(uint32_t T, size_t lds, bool debug)
 #undef X
 		default: return hipErrorInvalidValue;
 	}
+}
+
+// phase A, the trie over 32-bit group words (fseq_blocktrie.hpp): T threads by the row count (12 T classes fit), bits per symbol
+uint32_t blocktrie_threads(uint32_t m, bool stream) { return stream || m > 12u * 512u ? 1024u : m > 12u * 256u ? 512u : 256u; }
+size_t blocktrie_lds(uint32_t T) { return T == 256u ? BtGeom<256>::LDS_BYTES : T == 512u ? BtGeom<512>::LDS_BYTES : BtGeom<1024>::LDS_BYTES; }
+hipError_t launch_blocktrie(uint32_t bits, uint32_t T, hipStream_t st, uint32_t groups, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+                            uint32_t nblk, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0, uint32_t *ws, size_t per, uint32_t *given_up, uint32_t *todo)
+{
+#define FSEQ_BT_CASE(BITS_, T_) \
+	if (bits == BITS_ && T == T_) \
+	{ \
+		hipError_t const e = allow_lds(k_blocktrie<BITS_, T_>, BtGeom<T_>::LDS_BYTES); \
+		if (e != hipSuccess) return e; \
+		hipLaunchKernelGGL((k_blocktrie<BITS_, T_>), dim3(groups), dim3(T_), BtGeom<T_>::LDS_BYTES, st, msa, ld, m, n, B, nblk, rank_, keyd, nkeys, col0, ws, per, given_up, todo); \
+		return hipSuccess; \
+	}
+	FSEQ_BT_CASE(2, 256) FSEQ_BT_CASE(2, 512) FSEQ_BT_CASE(2, 1024)
+	FSEQ_BT_CASE(4, 256) FSEQ_BT_CASE(4, 512) FSEQ_BT_CASE(4, 1024)
+	FSEQ_BT_CASE(8, 256) FSEQ_BT_CASE(8, 512) FSEQ_BT_CASE(8, 1024)
+#undef FSEQ_BT_CASE
+	return hipErrorInvalidValue;
 }
 
 // phase C from another configuration than phases A, B and pass 2 (the emitter-wave kernels give their threads one
@@ -1558,11 +1579,15 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		HIP_TRY(c, hipMemsetAsync(todo, tree ? 0 : 0x01, (size_t) my_blocks * 4, st));     // (no tree: every block is the sweep's)
 	}
 	if (keyspace) HIP_TRY(c, hipMemsetAsync(c->d_flags + 64, 0, 12, st));
-	// Streamed rows, 2 bits per symbol: the trie over 16-column words first (fseq_blocktrie.hpp) -- it reads the block once and
-	// ranks only its distinct keys -- and the key-space tree for the blocks it gives up (too many distinct keys for its table).
-	// As with the tree and the sweep, what the last run on this input saw decides what is launched: nothing given up -> the
-	// trie alone; most blocks -> no trie.  The tests of the tree's slices (FSEQ_BLOCKKEYS_CAP, _NO_LIMIT) keep the tree.
-	bool const trie = tree && limited && c->use_stream && c->bsh == 2 && m <= 16u * 1024u * 32u && c->B < 65536u && !c->tune.no_blocktrie
+	// The trie over 32-bit group words first (fseq_blocktrie.hpp) -- it reads the block once and ranks only its distinct keys --
+	// and the key-space tree for the blocks it gives up (too many distinct keys for its tables).  As with the tree and the
+	// sweep, what the last run on this input saw decides what is launched: nothing given up -> the trie alone; most blocks ->
+	// no trie.  The tests of the tree's slices (FSEQ_BLOCKKEYS_CAP, _NO_LIMIT) keep the tree.
+	uint32_t const bt_bits = 8u >> c->bsh, bt_T = blocktrie_threads(m, c->use_stream);
+	// (LDS-resident rows: from 6,145 rows on -- BASELINE C5's 10,000: phase A 7.3 -> 5.9 ms; on C3's 2,504 rows a level of the trie is
+	// a dozen barriers for 157 busy threads and the tree is as fast, 1.31 against 1.36 ms; FSEQ_BLOCKTRIE_ALWAYS: tests)
+	bool const trie = tree && limited && (uint64_t) m <= (uint64_t) (32u / bt_bits) * bt_T * 32u && c->B < 65536u && !c->tune.no_blocktrie
+	                  && (c->use_stream || m > 12u * 512u || c->tune.blocktrie_always)
 	                  && (c->ld & 3u) == 0 && (reinterpret_cast<uintptr_t>(c->d_msa) & 3u) == 0
 	                  && !(c->bt_given_up >= 0 && 2u * (uint32_t) c->bt_given_up > my_blocks);
 	bool const tree_after = tree && !(trie && c->bt_given_up == 0);
@@ -1573,8 +1598,9 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 	{
 		int ncu = 0;
 		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
-		uint32_t const groups = std::min<uint32_t>(my_blocks, (uint32_t) std::max(1, ncu));
-		size_t const per = (blocktrie_ws_words(m, c->B) + 15) & ~size_t(15);
+		uint32_t const per_cu = (uint32_t) std::max<size_t>(1, std::min<size_t>(2048u / bt_T, (160u * 1024u) / blocktrie_lds(bt_T)));
+		uint32_t const groups = std::min<uint32_t>(my_blocks, (uint32_t) std::max(1, ncu) * per_cu);
+		size_t const per = (blocktrie_ws_words(m, c->B, bt_bits, bt_T) + 15) & ~size_t(15);
 		if (c->btws_words < per * groups)
 		{
 			if ((rc = dev_alloc(c, &c->d_btws, per * groups))) return rc;
@@ -1582,10 +1608,9 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 		}
 		if (c->only_cap < my_blocks) { if ((rc = dev_alloc(c, &c->d_only, my_blocks))) return rc; c->only_cap = my_blocks; }
 		HIP_TRY(c, hipMemsetAsync(c->d_only, 0, (size_t) my_blocks * 4, st));
-		(void) allow_lds(k_blocktrie, BT_LDS_BYTES);
-		hipLaunchKernelGGL(k_blocktrie, dim3(groups), dim3(BT_T), BT_LDS_BYTES, st, c->d_msa, c->ld, m, n, c->B, my_blocks,
-		                   c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
-		                   c->d_btws, per, c->d_flags + 66, c->d_only);
+		HIP_TRY(c, launch_blocktrie(bt_bits, bt_T, st, groups, c->d_msa, c->ld, m, n, c->B, my_blocks,
+		                            c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,
+		                            c->d_btws, per, c->d_flags + 66, c->d_only));
 		only = c->d_only;
 	}
 	if (tree_after && c->use_stream)
@@ -1614,7 +1639,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 			c->bk_per_block = per; c->bk_blocks = my_blocks;
 		}
 		launch_blockkeys(c->bk_T, st, my_blocks, c->bk_lds, c->d_msa, c->ld, m, n, c->B, c->bsh, c->d_rank + (size_t) b_lo * m,
-		                 c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64, todo);
+		                 c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B, c->d_bk, per, c->bk_cap_words, c->d_flags + 64, todo, only);
 	}
 	if (!keyspace || sweep_after)
 		launch_rank(c, my_blocks, c->B, c->nblocks, c->d_rank + (size_t) b_lo * m, c->d_keyd + (size_t) b_lo * m, c->d_nkeys + b_lo, (uint64_t) b_lo * c->B,

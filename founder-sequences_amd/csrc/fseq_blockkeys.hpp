@@ -1041,8 +1041,11 @@ template <int T>
 __global__ __launch_bounds__(T) void k_blockkeys(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
-	uint16_t *__restrict__ scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t *__restrict__ todo)
+	uint16_t *__restrict__ scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t *__restrict__ todo,
+	uint32_t const *__restrict__ only = nullptr)
 {
+	// only: the blocks with a non-zero entry (what the trie of fseq_blocktrie.hpp gave up)
+	if (only && only[blockIdx.x] == 0u) return;
 	// todo (per block, zeroed by the host): set to 1 for a block the tree gave up on (BK_ABORT) -- the column sweep that
 	// follows does those; sliced[0] counts the blocks that sliced some merge, sliced[1] the blocks given up.  todo ==
 	// nullptr: no limit on the slices.

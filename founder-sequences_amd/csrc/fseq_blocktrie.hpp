@@ -30,65 +30,75 @@
 
 namespace fseq {
 
-constexpr uint32_t BT_NK_MAX = 12288;             // classes (ids) of a block
-constexpr uint32_t BT_OVF = 8192;                 // slots of the pair table: the classes one group can add
-constexpr uint32_t BT_LIST = 2048;                // nodes with siblings per piece of the list
 constexpr uint32_t BT_SENT = 0xFFFFFFFFu;         // direct[]: nobody here yet (a row whose word is this value goes to the pair table)
 constexpr uint32_t BT_FLAG = 0x8000u;             // a row's id until the end of the group: FLAG | slot of its pair (the creator of the entry writes the id)
-constexpr int BT_T = 1024;
-constexpr int BT_PER = BT_NK_MAX / BT_T;          // entries of the id- / rank-indexed arrays per thread (12)
+constexpr int BT_PER = 12;                        // entries of the id- / rank-indexed arrays per thread
 
-// LDS (bytes): phase 1 = direct[] + the pair table; phase 2 = rank by id (two), divergence by rank (two), children per rank, the list
-constexpr size_t BT_OFF_DIRECT = 0, BT_OFF_PAIRS = 4 * (size_t) BT_NK_MAX;
-constexpr size_t BT_OFF_RP = 0, BT_OFF_RC = 2 * (size_t) BT_NK_MAX, BT_OFF_DP = 4 * (size_t) BT_NK_MAX, BT_OFF_DC = 6 * (size_t) BT_NK_MAX,
-                 BT_OFF_CNT = 8 * (size_t) BT_NK_MAX, BT_OFF_LIST = 10 * (size_t) BT_NK_MAX,
-                 BT_OFF_VARS = BT_OFF_LIST + 8 * BT_LIST;
-static_assert(BT_OFF_VARS >= BT_OFF_PAIRS + 8 * (size_t) BT_OVF, "the small variables lie behind the tables");
-constexpr size_t BT_LDS_BYTES = BT_OFF_VARS + 256;
+// T threads (256, 512, 1024): 12 T classes (ids) per block, 8 T slots in the pair table (the classes one group can add), the
+// nodes with siblings in pieces of 2 T.  LDS (bytes): phase 1 = direct[] + the pair table; phase 2 = rank by id (two),
+// divergence by rank (two), children per rank, the list -- 34 KB at T = 256 (four workgroups per CU), 136 KB at T = 1024.
+template <int T>
+struct BtGeom {
+	static constexpr uint32_t NK = (uint32_t) BT_PER * T, OVF = 8u * T, LIST = 2u * T;
+	static constexpr size_t OFF_DIRECT = 0, OFF_PAIRS = 4 * (size_t) NK;
+	static constexpr size_t OFF_RP = 0, OFF_RC = 2 * (size_t) NK, OFF_DP = 4 * (size_t) NK, OFF_DC = 6 * (size_t) NK,
+	                        OFF_CNT = 8 * (size_t) NK, OFF_LIST = 10 * (size_t) NK, OFF_VARS = OFF_LIST + 8 * (size_t) LIST;
+	static constexpr size_t LDS_BYTES = OFF_VARS + 256;
+	static_assert(OFF_VARS >= OFF_PAIRS + 8 * (size_t) OVF, "the small variables lie behind the tables");
+	static_assert(NK <= 0x3FFFu && OVF <= 0x2000u, "ids are 14 bits, pair slots 13");
+};
 
 // words per WORKGROUP of the workspace: the rows' ids (two to a word), node counts per level, the nodes (two words each), the nodes
-// with siblings of one level
-__host__ __device__ inline uint32_t blocktrie_levels(uint32_t B) { return (B + 15u) / 16u; }
-__host__ __device__ inline size_t blocktrie_ws_words(uint32_t m, uint32_t B)
+// with siblings of one level.  bits per symbol 2 / 4 / 8: a packed word holds N = 32 / bits rows, a group is N columns.
+__host__ __device__ inline uint32_t blocktrie_levels(uint32_t B, uint32_t bits) { uint32_t const N = 32u / bits; return (B + N - 1u) / N; }
+__host__ __device__ inline size_t blocktrie_ws_words(uint32_t m, uint32_t B, uint32_t bits, uint32_t T)
 {
-	size_t const nslots = ((m + 15u) / 16u + BT_T - 1u) / BT_T;
-	return 8u * nslots * BT_T + (size_t) blocktrie_levels(B) * (1u + 2u * (size_t) BT_NK_MAX) + 2u * (size_t) BT_NK_MAX + 64;
+	uint32_t const N = 32u / bits;
+	size_t const nslots = ((m + N - 1u) / N + T - 1u) / T;
+	size_t const NK = (size_t) BT_PER * T;
+	return (N / 2u) * nslots * T + (size_t) blocktrie_levels(B, bits) * (1u + 2u * NK) + 2u * NK + 64;
 }
 
-// 16 x 16 matrix of 2-bit elements: x[c] bits [2r, 2r + 1]  ->  x[r] bits [2c, 2c + 1]  (four stages, written out: as a loop
-// over the stage the compiler indexed the registers at run time)
-template <int J>
-__device__ __forceinline__ void bt_transpose_stage(uint32_t (&x)[16])
+// N x N matrix of BITS-bit elements (N = 32 / BITS): x[c] element r  ->  x[r] element c  (the stages written out: as a loop over
+// the stage the compiler indexed the registers at run time)
+template <int BITS, int J>
+__device__ __forceinline__ void bt_transpose_stage(uint32_t (&x)[32 / BITS])
 {
-	constexpr uint32_t mask = J == 8 ? 0x0000FFFFu : J == 4 ? 0x00FF00FFu : J == 2 ? 0x0F0F0F0Fu : 0x33333333u;
+	constexpr int N = 32 / BITS;
+	// the elements whose position has bit J clear
+	constexpr uint32_t mask = BITS * J == 16 ? 0x0000FFFFu : BITS * J == 8 ? 0x00FF00FFu : BITS * J == 4 ? 0x0F0F0F0Fu : 0x33333333u;
 #pragma unroll
-	for (int i = 0; i < 16; ++i)
+	for (int i = 0; i < N; ++i)
 		if (!(i & J))
 		{
-			uint32_t const t = ((x[i] >> (2 * J)) ^ x[i + J]) & mask;
+			uint32_t const t = ((x[i] >> (BITS * J)) ^ x[i + J]) & mask;
 			x[i + J] ^= t;
-			x[i] ^= t << (2 * J);
+			x[i] ^= t << (BITS * J);
 		}
 }
-__device__ __forceinline__ void bt_transpose16(uint32_t (&x)[16])
+template <int BITS>
+__device__ __forceinline__ void bt_transpose(uint32_t (&x)[32 / BITS])
 {
-	bt_transpose_stage<8>(x);
-	bt_transpose_stage<4>(x);
-	bt_transpose_stage<2>(x);
-	bt_transpose_stage<1>(x);
+	constexpr int N = 32 / BITS;
+	if constexpr (N >= 16) bt_transpose_stage<BITS, 8>(x);
+	if constexpr (N >= 8) bt_transpose_stage<BITS, 4>(x);
+	bt_transpose_stage<BITS, 2>(x);
+	bt_transpose_stage<BITS, 1>(x);
 }
 
-// 13 bits out of (class, word): 24-bit multiplies (full rate; a 32-bit multiply is a quarter-rate instruction here)
+// a slot out of (class, word): 24-bit multiplies (full rate; a 32-bit multiply is a quarter-rate instruction here)
+template <uint32_t OVF>
 __device__ __forceinline__ uint32_t bt_hash(uint32_t parent, uint32_t word)
 {
 	uint32_t const x = __umul24(word, 0x9E3779u) ^ __umul24(word >> 8, 0x85EBCBu) ^ __umul24(parent, 0xC2B2AFu);
-	return (x >> 12) & (BT_OVF - 1u);
+	return (x >> 12) & (OVF - 1u);
 }
 
 // A row whose word is not what direct[] holds for its class: the class's first row of this group registers its word there and
 // keeps the id; every other word of the class goes through the pair table -- entry = {word, class | id << 14 | ready}: whoever
 // creates it draws the id (returned); who finds it gets BT_FLAG | slot and reads the id behind the group's barrier.
 // vars[5]: the next id; *full: no room (ids or slots).
+template <int T>
 __device__ __forceinline__ uint32_t bt_other_word(uint32_t *direct, unsigned long long *pairs, uint32_t *vars, uint32_t p, uint32_t w, uint32_t e, uint32_t &full)
 {
 	if (e == BT_SENT && w != BT_SENT)
@@ -97,9 +107,10 @@ __device__ __forceinline__ uint32_t bt_other_word(uint32_t *direct, unsigned lon
 		if (old == BT_SENT || old == w) return p;
 	}
 	unsigned long long const fresh = ((unsigned long long) p << 32) | w;
-	uint32_t h = bt_hash(p, w);
+	constexpr uint32_t OVF = BtGeom<T>::OVF;
+	uint32_t h = bt_hash<OVF>(p, w);
 #pragma unroll 1
-	for (uint32_t probe = 0; probe < BT_OVF; ++probe)
+	for (uint32_t probe = 0; probe < OVF; ++probe)
 	{
 		unsigned long long cur = pairs[h];
 		if (cur == ~0ull)
@@ -108,13 +119,13 @@ __device__ __forceinline__ uint32_t bt_other_word(uint32_t *direct, unsigned lon
 			if (cur == ~0ull)
 			{
 				uint32_t id = atomicAdd(vars + 5, 1u);
-				if (id >= BT_NK_MAX) { full = 1u; id = 0u; }
+				if (id >= BtGeom<T>::NK) { full = 1u; id = 0u; }
 				reinterpret_cast<uint32_t *>(pairs + h)[1] = p | (id << 14) | (1u << 28);
 				return id;
 			}
 		}
 		if ((uint32_t) cur == w && ((uint32_t) (cur >> 32) & 0x3FFFu) == p) return BT_FLAG | h;
-		h = (h + 1u) & (BT_OVF - 1u);
+		h = (h + 1u) & (OVF - 1u);
 	}
 	full = 1u;
 	return 0u;
@@ -126,28 +137,59 @@ __device__ __forceinline__ uint32_t bt_other_word(uint32_t *direct, unsigned lon
 #define BT_STAMP(i) do {} while (0)
 #endif
 
-// the 16 packed words of a slot's group (zero behind the block's last column) and the ids of its 16 rows
+// the N packed words of a slot's group (zero behind the block's last column) and the ids of its N rows
+template <int BITS>
 __device__ __forceinline__ void bt_fetch(uint8_t const *__restrict__ msa, size_t ld, uint64_t kc, uint64_t kend, uint32_t wi, uint32_t nwords,
-                                         uint4 const *__restrict__ idw, bool with_ids, uint32_t (&x)[16], uint32_t (&cur)[8])
+                                         uint32_t const *__restrict__ idw, bool with_ids, uint32_t (&x)[32 / BITS], uint32_t (&cur)[16 / BITS])
 {
+	constexpr int N = 32 / BITS, IW = N / 2;
 	if (wi < nwords)
 	{
 #pragma unroll
-		for (int c = 0; c < 16; ++c)
+		for (int c = 0; c < N; ++c)
 			x[c] = (kc + (uint64_t) c < kend) ? *reinterpret_cast<uint32_t const *>(msa + (kc + (uint64_t) c) * ld + 4ull * wi) : 0u;
 		if (with_ids)
 		{
-			uint4 const a = idw[2u * (size_t) wi], b = idw[2u * (size_t) wi + 1u];
-			cur[0] = a.x; cur[1] = a.y; cur[2] = a.z; cur[3] = a.w; cur[4] = b.x; cur[5] = b.y; cur[6] = b.z; cur[7] = b.w;
+			if constexpr (IW >= 4)
+			{
+#pragma unroll
+				for (int q = 0; q < IW / 4; ++q)
+				{
+					uint4 const a = reinterpret_cast<uint4 const *>(idw + (size_t) IW * wi)[q];
+					cur[4 * q] = a.x; cur[4 * q + 1] = a.y; cur[4 * q + 2] = a.z; cur[4 * q + 3] = a.w;
+				}
+			}
+			else
+			{
+				uint2 const a = *reinterpret_cast<uint2 const *>(idw + (size_t) IW * wi);
+				cur[0] = a.x; cur[1] = a.y;
+			}
 		}
 	}
 }
+template <int IW>
+__device__ __forceinline__ void bt_store_ids(uint32_t *__restrict__ idw, size_t wi, uint32_t const (&cur)[IW])
+{
+	if constexpr (IW >= 4)
+	{
+#pragma unroll
+		for (int q = 0; q < IW / 4; ++q)
+			reinterpret_cast<uint4 *>(idw + (size_t) IW * wi)[q] = make_uint4(cur[4 * q], cur[4 * q + 1], cur[4 * q + 2], cur[4 * q + 3]);
+	}
+	else *reinterpret_cast<uint2 *>(idw + (size_t) IW * wi) = make_uint2(cur[0], cur[1]);
+}
 
+template <int BITS, int BT_T>
 __global__ __launch_bounds__(BT_T) void k_blocktrie(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
 	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t *__restrict__ given_up /* [0]: blocks given up */, uint32_t *__restrict__ todo)
 {
+	using G = BtGeom<BT_T>;
+	constexpr int N = 32 / BITS, IW = N / 2;                               // rows per packed word = columns per group; id words per packed word
+	constexpr uint32_t BT_NK_MAX = G::NK, BT_OVF = G::OVF, BT_LIST = G::LIST;
+	constexpr size_t BT_OFF_DIRECT = G::OFF_DIRECT, BT_OFF_PAIRS = G::OFF_PAIRS, BT_OFF_RP = G::OFF_RP, BT_OFF_RC = G::OFF_RC, BT_OFF_DP = G::OFF_DP,
+	                 BT_OFF_DC = G::OFF_DC, BT_OFF_CNT = G::OFF_CNT, BT_OFF_LIST = G::OFF_LIST, BT_OFF_VARS = G::OFF_VARS;
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	uint32_t *const direct = reinterpret_cast<uint32_t *>(smem + BT_OFF_DIRECT);
 	unsigned long long *const pairs = reinterpret_cast<unsigned long long *>(smem + BT_OFF_PAIRS);
@@ -161,17 +203,17 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 	// vars: [0 .. 2]: node counters of the levels (in turn); [3]: no room; [4]: list entries; [5]: the next id; [8 ..]: scan scratch
 	uint32_t *const vars = reinterpret_cast<uint32_t *>(smem + BT_OFF_VARS);
 	uint32_t const tid = threadIdx.x, lane = lane_id();
-	uint32_t const nwords = (m + 15u) / 16u;
+	uint32_t const nwords = (m + (uint32_t) N - 1u) / (uint32_t) N;
 	uint32_t const nslots = (nwords + BT_T - 1u) / BT_T;                  // <= 32 (the host checks m)
 	uint32_t *const wsg = ws + (size_t) blockIdx.x * ws_per_group;
-	uint4 *const idw = reinterpret_cast<uint4 *>(wsg);                      // ids of the rows, two to a word: 8 words per packed word of 16 rows
-	uint32_t *const wst = wsg + 8u * (size_t) nslots * BT_T;               // the trie: node counts per level, nodes, the list
+	uint32_t *const idw = wsg;                                             // ids of the rows, two to a word: IW words per packed word of N rows
+	uint32_t *const wst = wsg + (size_t) IW * nslots * BT_T;               // the trie: node counts per level, nodes, the list
 
 	for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x)
 	{
 		uint64_t const k0 = col0 + (uint64_t) b * B;
 		uint64_t const kend = (k0 + B < n) ? k0 + B : n;
-		uint32_t const levels = ((uint32_t) (kend - k0) + 15u) / 16u;
+		uint32_t const levels = ((uint32_t) (kend - k0) + (uint32_t) N - 1u) / (uint32_t) N;
 		uint32_t *const hdr = wst;
 		uint2 *const nodes = reinterpret_cast<uint2 *>(wst + ((levels + 3u) & ~3u));
 		uint2 *const glist = nodes + (size_t) levels * BT_NK_MAX;      // the nodes with siblings of the level at hand
@@ -187,12 +229,12 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 		for (uint32_t t = 0; t < levels; ++t)
 		{
 			uint32_t const g = levels - 1u - t;
-			uint64_t const kc = k0 + 16ull * g;
+			uint64_t const kc = k0 + (uint64_t) N * g;
 			// (the first slot's words are on their way while the tables are cleared)
-			uint32_t xn[16], curn[8];
+			uint32_t xn[N], curn[IW];
 #pragma unroll
-			for (int q = 0; q < 8; ++q) curn[q] = 0u;
-			bt_fetch(msa, ld, kc, kend, tid, nwords, idw, t != 0u, xn, curn);
+			for (int q = 0; q < IW; ++q) curn[q] = 0u;
+			bt_fetch<BITS>(msa, ld, kc, kend, tid, nwords, idw, t != 0u, xn, curn);
 			{
 				uint4 *const t4 = reinterpret_cast<uint4 *>(smem);
 				uint4 const ones = make_uint4(~0u, ~0u, ~0u, ~0u);
@@ -208,28 +250,28 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 			for (uint32_t s = 0; s < nslots; ++s)
 			{
 				uint32_t const wi = s * BT_T + tid;
-				uint32_t x[16], cur[8];
+				uint32_t x[N], cur[IW];
 #pragma unroll
-				for (int c = 0; c < 16; ++c) x[c] = xn[c];
+				for (int c = 0; c < N; ++c) x[c] = xn[c];
 #pragma unroll
-				for (int q = 0; q < 8; ++q) cur[q] = curn[q];
+				for (int q = 0; q < IW; ++q) cur[q] = curn[q];
 				// the next slot's words and ids are loaded while this one is looked up
-				if (s + 1u < nslots) bt_fetch(msa, ld, kc, kend, wi + BT_T, nwords, idw, t != 0u, xn, curn);
+				if (s + 1u < nslots) bt_fetch<BITS>(msa, ld, kc, kend, wi + BT_T, nwords, idw, t != 0u, xn, curn);
 				if (wi < nwords)
 				{
-					bt_transpose16(x);
+					bt_transpose<BITS>(x);
 					BT_STAMP(6);
-					if (wi * 16u + 16u > m)
+					if (wi * (uint32_t) N + (uint32_t) N > m)
 					{
 						// the last word of a column: the positions behind row m - 1 follow its first row (same class throughout)
-						uint32_t const valid = m - wi * 16u;
+						uint32_t const valid = m - wi * (uint32_t) N;
 #pragma unroll
-						for (int r = 1; r < 16; ++r) x[r] = ((uint32_t) r < valid) ? x[r] : x[0];
+						for (int r = 1; r < N; ++r) x[r] = ((uint32_t) r < valid) ? x[r] : x[0];
 					}
 					bool changed = t == 0u;
 					uint32_t fl = 0;
 #pragma unroll
-					for (int q4 = 0; q4 < 4; ++q4)
+					for (int q4 = 0; q4 < N / 4; ++q4)
 					{
 						// four rows at a time; no branch, and no new ids, while every row carries the word registered for its class
 						uint32_t par[4], e[4];
@@ -251,7 +293,7 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 								int const r = q4 * 4 + u;
 								if (e[u] != x[r] || e[u] == BT_SENT)
 								{
-									uint32_t const id = bt_other_word(direct, pairs, vars, par[u], x[r], e[u], full);
+									uint32_t const id = bt_other_word<BT_T>(direct, pairs, vars, par[u], x[r], e[u], full);
 									changed |= id != par[u];
 									par[u] = id;
 									fl |= id & BT_FLAG;
@@ -261,11 +303,7 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 							cur[2 * q4 + 1] = par[2] | (par[3] << 16);
 						}
 					}
-					if (changed)
-					{
-						idw[2u * (size_t) wi] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
-						idw[2u * (size_t) wi + 1u] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
-					}
+					if (changed) bt_store_ids<IW>(idw, wi, cur);
 					flagged |= fl ? (1u << s) : 0u;
 					BT_STAMP(1);
 				}
@@ -279,26 +317,25 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 			{
 				uint32_t const s = (uint32_t) __ffs((int) flagged) - 1u;
 				flagged &= flagged - 1u;
-				size_t const wi = (size_t) s * BT_T + tid;
-				uint4 const a = idw[2u * wi], c4 = idw[2u * wi + 1u];
-				uint32_t cur[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
+				uint32_t const wi = s * BT_T + tid;
+				uint32_t xd[N], cur[IW];
+				bt_fetch<BITS>(msa, ld, kend, kend, wi, nwords, idw, true, xd, cur);      // (the ids only: no column in front of kend)
 #pragma unroll
-				for (int q = 0; q < 8; ++q)
+				for (int q = 0; q < IW; ++q)
 				{
 					uint32_t v = cur[q];
 					if (v & BT_FLAG) v = (v & 0xFFFF0000u) | ((reinterpret_cast<uint32_t const *>(pairs + (v & (BT_OVF - 1u)))[1] >> 14) & 0x3FFFu);
 					if (v & (BT_FLAG << 16)) v = (v & 0x0000FFFFu) | (((reinterpret_cast<uint32_t const *>(pairs + ((v >> 16) & (BT_OVF - 1u)))[1] >> 14) & 0x3FFFu) << 16);
 					cur[q] = v;
 				}
-				idw[2u * wi] = make_uint4(cur[0], cur[1], cur[2], cur[3]);
-				idw[2u * wi + 1u] = make_uint4(cur[4], cur[5], cur[6], cur[7]);
+				bt_store_ids<IW>(idw, wi, cur);
 			}
 			BT_STAMP(7);
 			// the live ids are the nodes of this level: who kept its id (direct[]), who got a new one (the pair table)
 			{
 				uint32_t mine = 0;
 #pragma unroll
-				for (int i = 0; i < BT_PER; ++i) mine += direct[tid + i * BT_T] != BT_SENT ? 1u : 0u;
+				for (int i = 0; i < BT_PER; ++i) mine += direct[tid + i * BT_T] != BT_SENT ? 1u : 0u;      // (NK = BT_PER * T)
 #pragma unroll
 				for (int i = 0; i < (int) (BT_OVF / BT_T); ++i) mine += pairs[tid + i * BT_T] != ~0ull ? 1u : 0u;
 				uint32_t const inc = wave_incl_add(mine);
@@ -436,7 +473,7 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 					uint32_t const at = (cnt[r] & 0x7FFFu) + pos;
 					Rc[me.x >> 16] = (uint16_t) at;
 					// the last column in which this word differs from the next smaller sibling (later columns in the higher bits)
-					Dc[at] = pos == 0u ? Dp[r] : (uint16_t) (16u * g + ((31u - (uint32_t) __clz((int) (w ^ pred))) >> 1) + 1u);
+					Dc[at] = pos == 0u ? Dp[r] : (uint16_t) ((uint32_t) N * g + (31u - (uint32_t) __clz((int) (w ^ pred))) / (uint32_t) BITS + 1u);
 				}
 			}
 			__syncthreads();
@@ -450,11 +487,11 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 #pragma unroll 1
 		for (uint32_t wi = tid; wi < nwords; wi += BT_T)
 		{
-			uint4 const a = idw[2u * (size_t) wi], c4 = idw[2u * (size_t) wi + 1u];
-			uint32_t const cur[8] = {a.x, a.y, a.z, a.w, c4.x, c4.y, c4.z, c4.w};
-			uint32_t const r0 = wi * 16u;
+			uint32_t xd[N], cur[IW];
+			bt_fetch<BITS>(msa, ld, kend, kend, wi, nwords, idw, true, xd, cur);
+			uint32_t const r0 = wi * (uint32_t) N;
 #pragma unroll
-			for (int r = 0; r < 16; ++r)
+			for (int r = 0; r < N; ++r)
 				if (r0 + (uint32_t) r < m) rank[ob + r0 + r] = Rp[(cur[r >> 1] >> (16 * (r & 1))) & 0x3FFFu];
 		}
 		for (uint32_t j = tid; j < nprev; j += BT_T) keyd[ob + j] = (uint32_t) (k0 + Dp[j]);

@@ -211,6 +211,35 @@ def test_streamed_phase_a_trie(pkg, monkeypatch, m, n, L, K, Brec, mu, seed, B, 
     assert np.array_equal(ctx2.traceback(), tb)
 
 
+@pytest.mark.parametrize("m,n,L,K,Brec,mu,seed,kind,B", [
+    (2504, 3000, 20, 16, 400, 5e-4, 81, 0, 245),          # 2 bits, T = 256 (BASELINE C3's rows), a last group of 5 columns
+    (2504, 1200, 20, 2504, 500, 1e-2, 91, 0, 245),        # ... every row its own founder
+    (5000, 900, 15, 30, 200, 3e-4, 82, 1, 100),           # 4 bits (sigma = 16): groups of 8 columns, T = 512
+    (10000, 700, 30, 24, 300, 2e-4, 83, 1, 200),          # BASELINE C5's rows: T = 1024, the trie by itself
+    (10000, 500, 30, 10000, 500, 1e-3, 84, 1, 200),       # ... all rows distinct: more new classes in a group than the pair table holds
+    (3000, 400, 10, 40, 100, 5e-4, 85, 2, 64),            # 8 bits per symbol: groups of 4 columns
+])
+def test_phase_a_trie_on_lds_resident_rows(pkg, monkeypatch, m, n, L, K, Brec, mu, seed, kind, B):
+    """The trie of fseq_blocktrie.hpp in front of the LDS-resident key-space tree (by itself from 6,145 rows on; here on every
+    row count): 2, 4 and 8 bits per symbol, 256 / 512 / 1024 threads; what it gives up is the tree's (and what the tree gives
+    up the sweep's).  Block boundary states against the oracle's pBWT, the run against the oracle, a second run identical."""
+    monkeypatch.setenv("FSEQ_BLOCKTRIE_ALWAYS", "1")
+    msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, min(kind, 1)), m, n)
+    if kind == 2:
+        msa = msa.copy()
+        msa[:, 1::2] += 32                                   # (up to 32 characters: 8 bits per symbol)
+    ctx, ref = compare_long(pkg, msa, L, check_dp=False, block_len=B)
+    t = ctx.timings()
+    _block_states_match(ctx, msa, every=2)
+    tb = ctx.traceback().copy()
+    try:
+        ctx.run()
+    except pkg.NoReduction:
+        pass
+    t2 = ctx.timings()
+    assert np.array_equal(ctx.traceback(), tb) and t2["phase_a_trie_given_up"] in (t["phase_a_trie_given_up"], 0), (t, t2)
+
+
 def test_streamed_phase_a_trie_gives_blocks_up(pkg):
     """What does not fit the trie's table goes to the key-space tree, block by block: columns 0..95 of 30,000 rows are a
     mosaic of few founders (the trie's), columns 96..191 random (every row its own key after eight columns: more than 12,288
@@ -592,7 +621,7 @@ def test_config_c3_shape_at_high_diversity_matches_oracle(pkg):
     ctx.generate_synthetic(c["seed"], 1024, c["B"], 1e-3, c["kind"])
     res = ctx.run()
     t = ctx.timings()
-    assert t["phase_a_given_up"] > 0 and t["list_cap_used"] > 1000, t
+    assert t["list_cap_used"] > 1000, t                  # (the key-space tree would give most blocks up; the trie ranks them: 1,024 founders are few classes)
     tb = ctx.traceback()
     red = ctx.reduced_traceback()
     assert tb["lb"][0] == 0 and tb["rb"][-1] == n and np.array_equal(tb["lb"][1:], tb["rb"][:-1]) and (tb["rb"] - tb["lb"]).min() >= L
@@ -1044,12 +1073,13 @@ def test_phase_a_in_key_space_matches_the_column_sweep(pkg, monkeypatch, mode):
     (10000, 1400, 30, 10000, 1e-3, 1, 200),               # sigma = 16, 16-bit LDS state (BASELINE C5's rows)
     (30000, 400, 10, 30000, 1e-3, 0, 80),                 # streamed rows
 ])
-def test_diverse_blocks_go_to_the_column_sweep(pkg, shape):
+def test_diverse_blocks_go_to_the_column_sweep(pkg, monkeypatch, shape):
     """A block whose merges would slice past its budget is given up by the key-space tree and ranked by the column sweep
     (profiles/r04_diversity_sweep.txt: with all rows distinct the slices made phase A 25 - 150 times slower).  First run:
     tree + filtered sweep; the second run knows that most blocks were given up and runs the sweep alone; a friendly input
     on the same shape gives nothing up and its second run launches the tree alone.  All bit-identical to the oracle."""
     m, n, L, K, mu, kind, B = shape
+    monkeypatch.setenv("FSEQ_NO_BLOCKTRIE", "1")             # (the trie in front of the tree: test_phase_a_trie_on_lds_resident_rows)
     msa = fso.synth_msa(fso.synth_spec(91, K, 500, mu, kind), m, n)
     ctx, ref = compare_long(pkg, msa, L, check_dp=False, block_len=B)
     t = ctx.timings()
