@@ -25,7 +25,7 @@ extern "C" {
 /* 2: fseq_timings grew (dp_chunks .. reserved), FSEQ_E_PEER, fseq_set_memory_budget, fseq_set_progress /
  *    fseq_step_max / fseq_current_step; the fseq_debug_* entry points moved to include/fseq_debug.h */
 /* 3: fseq_shard_abort */
-/* 4: fseq_timings.phase_a_trie_given_up (the struct keeps its size: the field lies in what was tail padding) */
+/* 4: fseq_timings grew (phase_a_trie_given_up: 120 -> 128 bytes): a host that calls fseq_get_timings must be rebuilt */
 #define FSEQ_ABI_VERSION 4
 
 enum {
