@@ -27,7 +27,7 @@ def main():
     which = [a for a in sys.argv[1:] if not a.startswith("-")] or ["C3", "C5"]
     quick = "--quick" in sys.argv
     print("# tools/diversity_sweep.py on kernel sources %s; one MI355X; step = pass 1 + DP + traceback + merge + pass 2 (bench.py's metric)" % bench.csrc_sha())
-    print("# columns: workload K mu | ms/step (x the K = bench point) | A B C D pass2 host ms | X retries dp_sweeps phase_a_fallbacks | "
+    print("# columns: workload K mu | ms/step (x the K = bench point) | A B C D pass2 host ms | X retries dp_sweeps phase_a_fallbacks, blocks the tree gave to the sweep / the trie gave to the tree | "
           "max_segment_size segments | list GB | status")
     for name in which:
         w = bench.WORKLOADS[name]
@@ -72,10 +72,10 @@ def main():
                     base_ms = ms
                 stride = (t["list_cap_used"] + 3) & ~1
                 res = ctx.result
-                print("%s K=%-6d mu=%-6g | %9.3f ms (%5.2fx) first run %9.1f ms | A %.2f B %.2f C %.2f D %.2f p2 %.2f host %.2f | X %d retries(first run) %d dp_sweeps %d fallbacks %d | max %d segments %d | lists %.2f GB | %s"
+                print("%s K=%-6d mu=%-6g | %9.3f ms (%5.2fx) first run %9.1f ms | A %.2f B %.2f C %.2f D %.2f p2 %.2f host %.2f | X %d retries(first run) %d dp_sweeps %d fallbacks %d given up tree %d trie %d | max %d segments %d | lists %.2f GB | %s"
                       % (name, K, mu, ms, ms / base_ms if base_ms else float("nan"), first_ms,
                          acc.get("ms_phase_a", 0), acc.get("ms_phase_b", 0), acc.get("ms_phase_c", 0), acc.get("ms_dp", 0), acc.get("ms_pass2", 0), acc.get("ms_host", 0),
-                         t["list_cap_used"], t_first_run["retries"], t["dp_sweeps"], t["phase_a_fallbacks"],
+                         t["list_cap_used"], t_first_run["retries"], t["dp_sweeps"], t["phase_a_fallbacks"], t["phase_a_given_up"], t["phase_a_trie_given_up"],
                          res.max_segment_size if res else -1, res.segment_count if res else -1, n * stride * 8 / 1e9, status), flush=True)
                 ctx.close()
                 del ctx
