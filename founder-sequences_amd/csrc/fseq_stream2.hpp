@@ -168,6 +168,9 @@ __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 		else pairs0[i] = make_uint2(sa[i], lo);
 	}
 	if (tid == 0) w[9u * (size_t) m + B] = D0;
+#ifdef FSEQ_S2_D0_PRINT
+	if (tid == 0 && (blk & 127u) == 0u) printf("s2 prologue block %u: D0 %u (distinct divergence values in the start state), nb %u, pack_abits %u\n", blk, D0, nb, pack_abits);
+#endif
 }
 
 // block-wide sum of four counters (T threads); every thread gets the totals.  Two barriers.
