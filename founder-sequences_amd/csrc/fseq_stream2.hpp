@@ -53,6 +53,10 @@ constexpr int s2_key_shift(int tile)
 #define FSEQ_S2_SKIP 0
 #endif
 // -DFSEQ_S2_PW=0: the thread's own rows with four running maxima per row (the form before round 4's pairwise halves)
+// -DFSEQ_S2_NARROW=0: the high bytes of the packed rows move with every block (by itself: only with blocks whose value ids need them)
+#ifndef FSEQ_S2_NARROW
+#define FSEQ_S2_NARROW 1
+#endif
 #ifndef FSEQ_S2_PW
 #define FSEQ_S2_PW 1
 #endif
@@ -494,6 +498,11 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint64_t const k0 = (uint64_t) blk * B;
 	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
 	uint32_t const nb = (uint32_t) (kend - k0);
+	// [r4] A block whose value ids all fit the word beside the row id (D0 boundary values + one id per column <= 2^hshift: every
+	// block of BASELINE C4, D0 13,000 - 20,000 at 15 bits) never sets a high byte: they are neither loaded, nor staged, nor
+	// stored, nor copied into the stride states -- 8 instead of 10 bytes per row and column through HBM.  (Uniform per block, and
+	// the same in phase C and in pass 2: both read D0 from the block's workspace.)
+	bool const narrow = PACK && FSEQ_S2_NARROW && D0 + nb <= (1u << hshift);
 	bool const zero_present = (V[0] == 0u);
 	uint32_t const colbytes = sym_bytes(m, bsh);
 	uint32_t cur = 0;
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 		j_end = (uint32_t) (SN.task_rb[t_first + t_count - 1u] - k0);
 		__syncthreads();                                          // (the group before may still be read: its last snapshot)
 		cur = 0;
-		for (uint32_t i = tid; i < m; i += T) { words[0][i] = sw[i]; highs[0][i] = sh[i]; }
+		for (uint32_t i = tid; i < m; i += T) { words[0][i] = sw[i]; if (!narrow) highs[0][i] = sh[i]; }
 		__syncthreads();
 	}
 	// a boundary at column k (the state in front of it): ids back to divergences, unpacked
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 			for (uint32_t i = tid; i < m; i += T)
 			{
 				uint32_t const pw = PW[i];
-				uint32_t const id = (pw >> abits) | ((uint32_t) PH[i] << hshift);
+				uint32_t const id = (pw >> abits) | (narrow ? 0u : ((uint32_t) PH[i] << hshift));
 				SN.snap_a[ob + i] = pw & amask;
 				SN.snap_d[ob + i] = id < D0 ? V[id] : (uint32_t) (k0 + (id - D0) + 1u);
 			}
@@ -580,15 +589,24 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 					{
 						u32x4 const v = __builtin_amdgcn_raw_buffer_load_b128(rs, toff + 16u * q, base * 4u, 0);
 						an[4 * q] = v.x; an[4 * q + 1] = v.y; an[4 * q + 2] = v.z; an[4 * q + 3] = v.w;
-						hw[q] = __builtin_amdgcn_raw_buffer_load_b32(rsh, tid * (uint32_t) E + 4u * q, base, 0);
+						hw[q] = 0u;
+						if (!narrow) hw[q] = __builtin_amdgcn_raw_buffer_load_b32(rsh, tid * (uint32_t) E + 4u * q, base, 0);
 					}
 					// (unpacked where they arrive: dn = value id, an = row id)
-#pragma unroll
-					for (int e = 0; e < E; ++e)
+					if (narrow)
 					{
-						uint32_t const hb = (hw[e / 4] >> (8 * (e % 4))) & 255u;
-						dn[e] = (an[e] >> abits) | (hb << hshift);
-						an[e] &= amask;
+#pragma unroll
+						for (int e = 0; e < E; ++e) { dn[e] = an[e] >> abits; an[e] &= amask; }
+					}
+					else
+					{
+#pragma unroll
+						for (int e = 0; e < E; ++e)
+						{
+							uint32_t const hb = (hw[e / 4] >> (8 * (e % 4))) & 255u;
+							dn[e] = (an[e] >> abits) | (hb << hshift);
+							an[e] &= amask;
+						}
 					}
 				}
 				else
@@ -628,7 +646,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 						if constexpr (PACK)
 						{
 							stage_w[lp[e]] = a[e] | (dnew[e] << abits);
-							stage_h[lp[e]] = (uint8_t) (dnew[e] >> hshift);
+							if (!narrow) stage_h[lp[e]] = (uint8_t) (dnew[e] >> hshift);
 						}
 						else if (!(FSEQ_S2_SKIP & 16)) stage[lp[e]] = make_uint2(a[e], dnew[e]);
 						if (MODE == S2_COLUMNS && !(FSEQ_S2_SKIP & 2) && d[e] != dnew[e])
@@ -661,7 +679,8 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 						// the high bytes of the same 256 slots: four per lane, one 4-byte store at whatever byte the run stands at (the
 						// memory pipeline takes unaligned dwords; one byte per lane and store instruction was 8 of a thread's 10 stores
 						// per tile, each with its own LDS read and scalar bucket selection)
-						uint32_t const hv = *reinterpret_cast<uint32_t const *>(stage_h + j0 + 4u * lane);
+						uint32_t hv = 0u;
+						if (!narrow) hv = *reinterpret_cast<uint32_t const *>(stage_h + j0 + 4u * lane);
 						if (FULL && g != sg1 && g != sg2 && g != sg3)
 						{
 							uint32_t sh = gsh[0];
@@ -670,7 +689,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 							sh = ge(g, gb3) ? gsh[3] : sh;
 							u32x4 const vv = {v.x, v.y, v.z, v.w};
 							__builtin_amdgcn_raw_buffer_store_b128(vv, rd, lane * 16u, (j0 + sh) * 4u, 0);
-							__builtin_amdgcn_raw_buffer_store_b32(hv, rdh, lane * 4u, j0 + sh, 0);
+							if (!narrow) __builtin_amdgcn_raw_buffer_store_b32(hv, rdh, lane * 4u, j0 + sh, 0);
 						}
 						else
 						{
@@ -686,7 +705,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 								if (FULL || jj < tile_n)
 								{
 									__builtin_amdgcn_raw_buffer_store_b32(vq[h], rd, (jj + sh) * 4u, 0u, 0);
-									__builtin_amdgcn_raw_buffer_store_b8((uint8_t) (hv >> (8 * h)), rdh, jj + sh, 0u, 0);
+									if (!narrow) __builtin_amdgcn_raw_buffer_store_b8((uint8_t) (hv >> (8 * h)), rdh, jj + sh, 0u, 0);
 								}
 							}
 						}
@@ -757,7 +776,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 			size_t const q = (size_t) ((k0 + j + 1) / snap_stride), ob = q * m;
 			uint8_t *sh = reinterpret_cast<uint8_t *>(ss_d) + q * ss_high_stride(m);
 			if constexpr (PACK)
-				for (uint32_t i = tid; i < m; i += T) { ss_a[ob + i] = PW[i]; sh[i] = PH[i]; }
+				for (uint32_t i = tid; i < m; i += T) { ss_a[ob + i] = PW[i]; if (!narrow) sh[i] = PH[i]; }
 		}
 		else if (MODE == S2_COLUMNS && ss_a && (k0 + j + 1) % snap_stride == 0)
 		{
@@ -766,7 +785,7 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 			for (uint32_t i = tid; i < m; i += T)
 			{
 				uint2 p;
-				if constexpr (PACK) { uint32_t const pw = PW[i]; p = make_uint2(pw & amask, (pw >> abits) | ((uint32_t) PH[i] << hshift)); }
+				if constexpr (PACK) { uint32_t const pw = PW[i]; p = make_uint2(pw & amask, (pw >> abits) | (narrow ? 0u : ((uint32_t) PH[i] << hshift))); }
 				else p = P[i];
 				uint32_t const dv = p.y < D0 ? V[p.y] : (uint32_t) (k0 + (p.y - D0) + 1u);
 				if (ss_pack) { ss_a[ob + i] = p.x | (dv << ss_pack); sh[i] = (uint8_t) (dv >> (32u - ss_pack)); }
