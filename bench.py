@@ -104,8 +104,9 @@ def dominant_kernel_bound(workload, m, n, avg_launch_ms):
     (1024 SIMDs x clock x launch time): the share of all vector issue slots of the launch that issued.  The clock is
     the effective one of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs / its duration, MI355X_MICROARCH.md "DVFS
     give-back"), not an assumed 2.4 GHz.  The LDS pipe's share is put beside it in the same normalisation.
-    Streamed kernel (k_columns_stream2: the order streams through HBM / L2): bound hbm, priced at the bytes the PMC
-    passes counted (FETCH_SIZE x 2 + WRITE_SIZE), not at the 17 B/cell of the formula."""
+    Streamed kernel (k_columns_stream2: the order streams through HBM / L2): the HBM fraction priced at the bytes the PMC
+    passes counted (FETCH_SIZE x 2 + WRITE_SIZE), not at the 17 B/cell of the formula, and the vector issue fraction as
+    above; `bound` names the one nearer its ceiling, both are in the line."""
     d = load_pmc_summary(workload)
     prefix = None
     if d is None and workload == "C4":
@@ -146,9 +147,15 @@ def dominant_kernel_bound(workload, m, n, avg_launch_ms):
     hbm_frac = out["pmc_hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_launch_ms else None
     out["hbm_frac_pmc_bytes"] = round(hbm_frac, 4) if hbm_frac is not None else None
     if "stream" in name:
-        out["bound"] = "hbm"
-        out["frac"] = out["hbm_frac_pmc_bytes"]
+        # the order streams through HBM / L2: the PMC bytes against the HBM peak, or the vector issue slots -- whichever is
+        # nearer its ceiling (with the narrow blocks of round 4, 8.9 B per cell, the issue slots are; both stay in the line)
         out["pmc_bytes_per_cell"] = round(out["pmc_hbm_bytes_per_launch"] / (m * n), 2)
+        if (out["valu_issue_frac"] or 0.0) > (out["hbm_frac_pmc_bytes"] or 0.0):
+            out["bound"] = "valu_issue"
+            out["frac"] = out["valu_issue_frac"]
+        else:
+            out["bound"] = "hbm"
+            out["frac"] = out["hbm_frac_pmc_bytes"]
     else:
         out["bound"] = "valu_issue"
         out["frac"] = out["valu_issue_frac"]
