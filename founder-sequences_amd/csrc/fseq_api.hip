@@ -1583,7 +1583,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 	// and the key-space tree for the blocks it gives up (too many distinct keys for its tables).  As with the tree and the
 	// sweep, what the last run on this input saw decides what is launched: nothing given up -> the trie alone; most blocks ->
 	// no trie.  The tests of the tree's slices (FSEQ_BLOCKKEYS_CAP, _NO_LIMIT) keep the tree.
-	uint32_t const bt_bits = 8u >> c->bsh, bt_T = c->tune.blocktrie_threads ? (uint32_t) c->tune.blocktrie_threads : blocktrie_threads(m, c->use_stream);
+	uint32_t const bt_bits = 8u >> c->bsh, bt_T = blocktrie_threads(m, c->use_stream);
 	// (LDS-resident rows: from 6,145 rows on -- BASELINE C5's 10,000: phase A 7.3 -> 5.9 ms; on C3's 2,504 rows a level of the trie is
 	// a dozen barriers for 157 busy threads and the tree is as fast, 1.31 against 1.36 ms; FSEQ_BLOCKTRIE_ALWAYS: tests)
 	bool const trie = tree && limited && (uint64_t) m <= (uint64_t) (32u / bt_bits) * bt_T * 32u && c->B < 65536u && !c->tune.no_blocktrie

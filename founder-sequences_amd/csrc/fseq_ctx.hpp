@@ -89,7 +89,6 @@ struct Tuning {
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
 	bool no_blocktrie = false;           // FSEQ_NO_BLOCKTRIE: the streamed phase A without the trie over 16-column words (fseq_blocktrie.hpp): the key-space tree on every block
-	int blocktrie_threads = 0;           // FSEQ_BLOCKTRIE_THREADS=256|512|1024: the trie's workgroup size (by itself: by the row count)
 	bool blocktrie_always = false;       // FSEQ_BLOCKTRIE_ALWAYS: the trie for LDS-resident rows of any count (by itself: from 6,145 rows on)
 	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
 	int  blockkeys_cap = 0;              // FSEQ_BLOCKKEYS_CAP: words of the key-space tree's LDS bitmap
@@ -134,7 +133,6 @@ struct Tuning {
 		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
 		else if (n == "FSEQ_NO_BLOCKTRIE") no_blocktrie = on;
 		else if (n == "FSEQ_BLOCKTRIE_ALWAYS") blocktrie_always = on;
-		else if (n == "FSEQ_BLOCKTRIE_THREADS") blocktrie_threads = (iv == 256 || iv == 512 || iv == 1024) ? iv : 0;
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
 		else if (n == "FSEQ_SS_UNPACKED") ss_unpacked = on;
@@ -159,7 +157,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_BLOCKTRIE_THREADS"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
