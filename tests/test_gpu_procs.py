@@ -63,3 +63,13 @@ def test_two_ranks_over_rccl():
         pytest.skip("needs two GPUs (the development box has one)")
     codes, outs = run_ranks(2, "streamed", backend="nccl")
     assert codes == [0, 0], "\n".join(outs)
+
+
+def test_one_rank_over_rccl():
+    """The driver's backend with the one GPU there is: the exchange primitive and bench.py's timing collectives against the
+    real RCCL (tests/rccl_transport_worker.py) -- the dtypes, ops and views the ranks of a sharded run use."""
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_transport_worker.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert p.returncode == 0 and "rccl transport ok" in p.stdout, p.stdout[-2000:]
