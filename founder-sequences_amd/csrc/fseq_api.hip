@@ -67,10 +67,14 @@ struct Launch {
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch)
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask)
 	{
-		hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-		                   snap_stride, ss_a, ss_d, block0, done_host, epoch);
+		if (colmask)
+			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, true>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
+			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, colmask);
+		else
+			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, false>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
+			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, (uint32_t const *) nullptr);
 	}
 	static uint32_t columns_resident(size_t lds)
 	{
@@ -94,7 +98,11 @@ struct Launch {
 		(void) lds_columns;
 		return hipSuccess;
 	}
-	static hipError_t prepare_columns(size_t lds_columns) { return allow_lds(k_columns<T, E, SIGMA, PK, EW>, lds_columns); }
+	static hipError_t prepare_columns(size_t lds_columns)
+	{
+		hipError_t const e = allow_lds(k_columns<T, E, SIGMA, PK, EW, false>, lds_columns);
+		return e != hipSuccess ? e : allow_lds(k_columns<T, E, SIGMA, PK, EW, true>, lds_columns);
+	}
 	static KernelSet make()
 	{
 		KernelSet k;
@@ -768,6 +776,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_ent_alloc); c->d_ent = nullptr; dev_free(c, &c->d_hdr); dev_free(c, &c->d_flags); dev_free(c, &c->d_recent);
 	dev_free(c, &c->d_chunk_r0); c->chunk_cap = 0; dev_free(c, &c->d_tau); c->tau_cap = 0;
 	dev_free(c, &c->d_bk); c->bk_blocks = 0; dev_free(c, &c->d_bkws); c->bkws_words = 0; dev_free(c, &c->d_todo); c->todo_cap = 0;
+	dev_free(c, &c->d_colmask_alloc); c->d_colmask = nullptr; c->colmask_ready = false;
 	dev_free(c, &c->d_btws); c->btws_words = 0; dev_free(c, &c->d_only); c->only_cap = 0;
 	dev_free(c, &c->d_tb); c->tb_cap = 0; c->tb_win = 0;
 	dev_free(c, &c->dp.M); dev_free(c, &c->dp.LB); dev_free(c, &c->dp.SZ); dev_free(c, &c->dp.K); dev_free(c, &c->dp.Tb); dev_free(c, &c->dp.Tbv);
@@ -855,7 +864,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
 	return FSEQ_OK;
 }
 
@@ -896,7 +905,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
 	return FSEQ_OK;
 }
 
@@ -1557,6 +1566,23 @@ bool sync_at(fseq_ctx const *c, char ph) { return c->tune.sync_phases.find(ph) !
 int long_phase_a(fseq_ctx *c, LongRun &R)
 {
 	FSEQ_LONG_LOCALS(c);
+	// 4-bit symbols, LDS-resident rows: the codes present in every column I hold, once per input (k_columns takes a column with at
+	// most four of them in one digit pass)
+	if (c->bsh == 1u && c->npass == 2u && !c->use_stream && !c->tune.no_dense_columns && !c->colmask_ready && held_hi(c) > held_lo(c)
+	    && c->d_msa_alloc && (c->ld & 3u) == 0)                  // (own columns: padded past their last byte, whole words can be read)
+	{
+		uint64_t const lo = held_lo(c), hi = held_hi(c);
+		if ((rc = dev_alloc_range(c, &c->d_colmask_alloc, &c->d_colmask, (size_t) lo, (size_t) hi, 1))) return rc;
+		HIP_TRY(c, hipMemsetAsync(c->d_flags + 67, 0, 4, st));
+		hipLaunchKernelGGL(k_column_presence, dim3((uint32_t) std::min<uint64_t>(hi - lo, 8192)), dim3(256), 0, st, c->d_msa, c->ld, sym_bytes(m, c->bsh), lo, hi, c->d_colmask,
+		                   c->d_flags + 67);
+		// (once per input: one column in twenty with at most four codes, and phase C is the kernel with the one-pass branch)
+		uint32_t n_dense = 0;
+		HIP_TRY(c, hipMemcpyAsync(&n_dense, c->d_flags + 67, 4, hipMemcpyDeviceToHost, st));
+		HIP_TRY(c, hipStreamSynchronize(st));
+		c->colmask_use = (uint64_t) n_dense * 20u >= hi - lo;
+		c->colmask_ready = true;
+	}
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
 	progress(c, FSEQ_STAGE_TRACEBACK, 0, n);
 	FSEQ_RANGE_PUSH("fseq pass 1: phases A + B (block keys, boundary states)");
@@ -1995,7 +2021,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 		else
 			ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
-			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch);
+			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->colmask_ready && c->colmask_use ? c->d_colmask : (uint32_t const *) nullptr);
 	};
 	// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
 	// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
@@ -2616,7 +2642,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2640,7 +2666,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2744,7 +2770,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
 	return FSEQ_OK;
 }
 

@@ -35,7 +35,7 @@ struct KernelSet {
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
-	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch);
+	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask);
 	uint32_t (*columns_resident)(size_t lds);                 // workgroups of k_columns one CU holds
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -88,6 +88,7 @@ struct Tuning {
 	bool chain_stream_single = false;    // FSEQ_CHAIN_STREAM_SINGLE: ... as the sorted step on one workgroup per chain (not spread over the chip)
 	bool blockkeys_wide = false;         // FSEQ_BLOCKKEYS_WIDE: 32-bit ids in the streamed key-space tree from the start
 	bool blockkeys_single = false;       // FSEQ_BLOCKKEYS_SINGLE: its leaves one by one (no pair leaves)
+	bool no_dense_columns = false;       // FSEQ_NO_DENSE_COLUMNS: every column of 4-bit symbols in two digit passes (by itself: one pass where at most four codes are present)
 	bool no_blocktrie = false;           // FSEQ_NO_BLOCKTRIE: the streamed phase A without the trie over 16-column words (fseq_blocktrie.hpp): the key-space tree on every block
 	bool blocktrie_always = false;       // FSEQ_BLOCKTRIE_ALWAYS: the trie for LDS-resident rows of any count (by itself: from 6,145 rows on)
 	bool blockkeys_no_limit = false;     // FSEQ_BLOCKKEYS_NO_LIMIT: the key-space tree slices as often as it takes (never hands a block to the column sweep)
@@ -132,6 +133,7 @@ struct Tuning {
 		else if (n == "FSEQ_BLOCKKEYS_SINGLE") blockkeys_single = on;
 		else if (n == "FSEQ_BLOCKKEYS_NO_LIMIT") blockkeys_no_limit = on;
 		else if (n == "FSEQ_NO_BLOCKTRIE") no_blocktrie = on;
+		else if (n == "FSEQ_NO_DENSE_COLUMNS") no_dense_columns = on;
 		else if (n == "FSEQ_BLOCKTRIE_ALWAYS") blocktrie_always = on;
 		else if (n == "FSEQ_BLOCKKEYS_CAP") blockkeys_cap = on ? std::max(2048, iv) : 0;
 		else if (n == "FSEQ_STREAM2") stream2 = v;
@@ -157,7 +159,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -206,6 +208,9 @@ struct fseq_ctx {
 	int bk_given_up = -1;                    // ... in the last run on this input (-1: not run yet): later runs skip the sweep's launch when
 	                                         // it was none, and the tree altogether when it was most blocks
 	size_t bk_lds = 0;
+	uint32_t *d_colmask_alloc = nullptr;     // 4-bit symbols: the codes present in every held column (k_column_presence), once per input;
+	uint32_t *d_colmask = nullptr;           // d_colmask = d_colmask_alloc - c_lo (column k at d_colmask[k])
+	bool colmask_ready = false, colmask_use = false;      // ... computed for this input; ... enough dense columns for the kernel that looks at it
 	uint32_t *d_btws = nullptr;              // phase A, streamed rows, the trie (fseq_blocktrie.hpp): per-workgroup workspace (the nodes of the levels)
 	size_t btws_words = 0;
 	uint32_t *d_only = nullptr;              // ... blocks the trie gave up on (the key-space tree does them)

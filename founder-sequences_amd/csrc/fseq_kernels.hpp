@@ -182,6 +182,44 @@ __global__ __launch_bounds__(256) void k_max_code(uint8_t const *__restrict__ ms
 	if (lane_id() == 63) atomicMax(out, mx);
 }
 
+// The codes present in every column of 4-bit symbols (bsh = 1): bit c of out[k] = some row carries code c in column k.  A
+// property of the input, computed once per input (not per run).  [r4] k_columns takes a column with at most four present
+// codes in ONE digit pass over the codes' ranks among the present ones (the remap keeps their order, so the stable sort -- and
+// every divergence -- is the one the two 2-bit passes produce): rare on the survey's generator, common in real gapped
+// alignments.  A padding nibble behind row m - 1 counts as code 0: a superset of the present codes is as good.
+__global__ __launch_bounds__(256) void k_column_presence(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t c_lo, uint64_t c_hi,
+                                                         uint32_t *__restrict__ out, uint32_t *__restrict__ n_dense /* += columns with <= 4 codes */)
+{
+	__shared__ uint32_t part[4];
+	for (uint64_t c = c_lo + blockIdx.x; c < c_hi; c += gridDim.x)
+	{
+		uint32_t pm = 0;
+		for (uint32_t b = threadIdx.x * 4u; b < col_bytes; b += 1024u)
+		{
+			uint32_t const w = *reinterpret_cast<uint32_t const *>(msa + c * ld + b);      // (columns are padded to 16 bytes)
+			uint32_t const nv = min(4u, col_bytes - b);
+#pragma unroll
+			for (uint32_t j = 0; j < 8; ++j)
+				if (j < 2u * nv) pm |= 1u << ((w >> (4u * j)) & 15u);
+		}
+		pm |= dpp_mov<DPP_ROW_SHR1, 0xF>(0u, pm);
+		pm |= dpp_mov<DPP_ROW_SHR2, 0xF>(0u, pm);
+		pm |= dpp_mov<DPP_ROW_SHR4, 0xF>(0u, pm);
+		pm |= dpp_mov<DPP_ROW_SHR8, 0xF>(0u, pm);
+		pm |= dpp_mov<DPP_ROW_BCAST15, 0xA>(0u, pm);
+		pm |= dpp_mov<DPP_ROW_BCAST31, 0xC>(0u, pm);
+		if (lane_id() == 63) part[wave_id()] = pm;
+		__syncthreads();
+		if (threadIdx.x == 0)
+		{
+			uint32_t const all = part[0] | part[1] | part[2] | part[3];
+			out[c] = all;
+			if (__popc(all) <= 4) atomicAdd(n_dense, 1u);
+		}
+		__syncthreads();
+	}
+}
+
 struct CodeTable { uint8_t code_of[256]; };
 
 // ... and the encode + transpose + pack: raw[r * n + c] -> code_of[byte] at row r of packed column c; 64 x 64
@@ -705,14 +743,18 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 // time on the per-column list alone.  Measured on BASELINE C3: with the list on a wave that also carries 1/8 of the
 // rows, the list's serial chain (~150 instructions under 8-way issue contention) stretched EVERY column's critical
 // path: 2.9 of 10.8 ms.  Needs m <= (T - 64) * E.
-template <int T, int E, int SIGMA, bool PK, bool EW = false>
+// DENSE (4-bit symbols): a column with at most four present codes takes ONE digit pass (colmask: k_column_presence).  A kernel of
+// its own -- compiled into the one every input runs, the three uniform branches cost BASELINE C5 2.6 ms and C3 0.14 ms --
+// that the host launches when at least one column in twenty is that dense.
+template <int T, int E, int SIGMA, bool PK, bool EW = false, bool DENSE = false>
 __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch)
+	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask = nullptr)
 {
+	// colmask (4-bit symbols, or nullptr): the codes present in every column (k_column_presence)
 	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
 	FSEQ_CLOCK_STAMP(blockIdx.x, 0);
 	constexpr uint32_t CAP = T * E;
@@ -839,9 +881,25 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 		bool const more = j + 1 < nb;
 		if (more && has_chunk)
 			nxt = *reinterpret_cast<uint4 const *>(msa + (k0 + j + 1) * ld + tid * 16u);
+		// [r4] at most four codes present in a column of 4-bit symbols: ONE pass over their ranks among the present codes
+		// (remap: two bits per code)
+		bool dense = false;
+		uint32_t remap = 0;
+		if (DENSE && colmask && npass == 2u && bsh == 1u)
+		{
+			uint32_t const pm = __builtin_amdgcn_readfirstlane(colmask[k0 + j]);
+			if (__popc(pm) <= 4)
+			{
+				dense = true;
+				uint32_t idx = 0;
+#pragma unroll
+				for (uint32_t cde = 0; cde < 16; ++cde) { remap |= (idx & 3u) << (2u * cde); idx += (pm >> cde) & 1u; }
+			}
+		}
 
 		for (uint32_t pass = 0; pass < npass; ++pass)
 		{
+			bool const last_pass = (DENSE && dense) || pass + 1 == npass;
 			uint32_t s[E], dst[E], dnew[E], hi[CARRY_OK ? E : 1];
 			if (rows) read_chunk<T, E>(a_l, d_l, a, d, p0);
 			// 16-bit row ids of at most 14 bits and a 4-bit alphabet (two digit passes): the first pass fetches the whole symbol
@@ -853,8 +911,18 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 				for (int e = 0; e < E; ++e)
 				{
 					uint32_t const sy = (symc[a[e] >> 1] >> ((a[e] & 1u) * 4u)) & 15u;
-					s[e] = (p0 + e < m) ? (sy & 3u) : (uint32_t) SIGMA;
-					hi[e] = sy >> 2;
+					s[e] = (p0 + e < m) ? ((DENSE && dense) ? ((remap >> (2u * sy)) & 3u) : (sy & 3u)) : (uint32_t) SIGMA;
+					hi[e] = (DENSE && dense) ? 0u : (sy >> 2);
+				}
+			}
+			else if (DENSE && dense)
+			{
+#pragma unroll
+				for (int e = 0; e < E; ++e)
+				{
+					uint32_t const sy = (symc[a[e] >> 1] >> ((a[e] & 1u) * 4u)) & 15u;
+					s[e] = (p0 + e < m) ? ((remap >> (2u * sy)) & 3u) : (uint32_t) SIGMA;
+					if (CARRY_OK) hi[e] = 0;
 				}
 			}
 			else if (carry)
@@ -895,7 +963,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 					}
 				}
 			}
-			if (pass + 1 == npass && more && has_chunk)
+			if (last_pass && more && has_chunk)
 				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
 #ifdef FSEQ_KC_STAMPS
 			{ long long const t_ = clock64(); kc_work += t_ - kc_last; kc_last = t_; }
@@ -904,6 +972,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 #else
 			__syncthreads();
 #endif
+			if (DENSE && dense) break;
 		}
 
 		// ---- every snap_stride columns: drop the exact (a, d) for pass 2 (ids back to divergence values)

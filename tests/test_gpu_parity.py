@@ -240,6 +240,41 @@ def test_phase_a_trie_on_lds_resident_rows(pkg, monkeypatch, m, n, L, K, Brec, m
     assert np.array_equal(ctx.traceback(), tb) and t2["phase_a_trie_given_up"] in (t["phase_a_trie_given_up"], 0), (t, t2)
 
 
+def _gapped_sigma16(m, n, seed, dense_share):
+    """A sigma = 16 alignment in which a share of the columns carries at most four codes (an order-preserving image of the
+    generator's column: the codes' ranks in the column, cut to 0..3, mapped into four codes spread over the alphabet)."""
+    msa = fso.synth_msa(fso.synth_spec(seed, 24, 300, 2e-4, 1), m, n).copy()
+    codes = np.unique(msa)
+    assert len(codes) > 8
+    rng = np.random.default_rng(seed)
+    for k in np.nonzero(rng.random(n) < dense_share)[0]:
+        pick = np.sort(rng.choice(len(codes), size=int(rng.integers(1, 5)), replace=False))      # 1 .. 4 codes, any digits
+        col = np.searchsorted(codes, msa[:, k])
+        msa[:, k] = codes[pick[col % len(pick)]]
+    return msa
+
+
+@pytest.mark.parametrize("m,n,L,share,B", [
+    (10000, 900, 30, 0.8, 200),          # BASELINE C5's rows (the second digit rides with the row where a column takes two passes)
+    (3000, 700, 12, 0.5, 64),            # 32-bit LDS state
+    (10000, 400, 20, 1.0, 100),          # every column dense
+])
+def test_columns_with_at_most_four_codes_take_one_pass(pkg, monkeypatch, m, n, L, share, B):
+    """4-bit symbols: a column with at most four present codes is partitioned ONCE, by the codes' ranks among the present ones
+    (k_column_presence, k_columns); the remap keeps the codes' order, so the result is the two digit passes'.  The run against the
+    oracle (DP array, traceback, segments, boundary states), block states against its pBWT, and the same with every column in two
+    passes (FSEQ_NO_DENSE_COLUMNS)."""
+    msa = _gapped_sigma16(m, n, 300 + m // 1000, share)
+    ctx, ref = compare_long(pkg, msa, L, block_len=B)
+    _block_states_match(ctx, msa, every=2)
+    tb = ctx.traceback().copy()
+    ctx.run()
+    assert np.array_equal(ctx.traceback(), tb)
+    monkeypatch.setenv("FSEQ_NO_DENSE_COLUMNS", "1")
+    ctx2 = run_gpu(pkg, msa, L, block_len=B)
+    assert np.array_equal(ctx2.traceback(), tb)
+
+
 def test_streamed_phase_a_trie_gives_blocks_up(pkg):
     """What does not fit the trie's table goes to the key-space tree, block by block: columns 0..95 of 30,000 rows are a
     mosaic of few founders (the trie's), columns 96..191 random (every row its own key after eight columns: more than 12,288
