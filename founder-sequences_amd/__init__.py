@@ -58,7 +58,8 @@ class Timings(C.Structure):
                 ("ms_colstep_kernels", C.c_double), ("colstep_launches", C.c_uint64), ("colstep_cells", C.c_uint64),
                 ("pass2_cells", C.c_uint64), ("list_cap_used", C.c_uint32), ("retries", C.c_uint32),
                 ("block_len", C.c_uint32), ("n_blocks", C.c_uint32),
-                ("dp_chunks", C.c_uint32), ("dp_sweeps", C.c_uint32), ("phase_a_fallbacks", C.c_uint32), ("phase_a_given_up", C.c_uint32), ("phase_a_trie_given_up", C.c_uint32)]
+                ("dp_chunks", C.c_uint32), ("dp_sweeps", C.c_uint32), ("phase_a_fallbacks", C.c_uint32), ("phase_a_given_up", C.c_uint32), ("phase_a_trie_given_up", C.c_uint32),
+                ("reduced_blocks", C.c_uint32), ("reduced_rows_mean", C.c_uint32), ("reduced_redone", C.c_uint32)]
 
 
 class JoinProfile(C.Structure):

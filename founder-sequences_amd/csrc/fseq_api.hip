@@ -602,7 +602,7 @@ int prepare_geometry(fseq_ctx *c)
 	return FSEQ_OK;
 }
 
-int ensure_work_buffers(fseq_ctx *c, uint32_t X)
+int ensure_work_buffers(fseq_ctx *c, uint32_t X, bool want_ss = true)
 {
 	fseq_params const &p = c->p;
 	size_t const m = p.m;
@@ -696,7 +696,7 @@ int ensure_work_buffers(fseq_ctx *c, uint32_t X)
 		if (rc) return rc;
 		c->d_ent = c->d_ent_alloc - (size_t) k_lo * c->stride;   // list of column k at d_ent + k * stride
 	}
-	if (X && !c->d_ss_a && p.n >= 2 * p.segment_length)
+	if (X && want_ss && !c->d_ss_a && p.n >= 2 * p.segment_length)
 	{
 		// stride states for pass 2: one (a, d) pair of m words each every snap_stride columns.  Sized after the lists:
 		// what is free now, minus the boundary snapshots pass 2 will need at most (one per L columns) and a margin,
@@ -786,6 +786,10 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
 	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
+	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows); dev_free(c, &c->d_red_leaf); dev_free(c, &c->d_red_a); dev_free(c, &c->d_red_d);
+	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa); c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
+	dev_free(c, &c->d_red_cls); dev_free(c, &c->d_red_headd); dev_free(c, &c->d_red_ncls); dev_free(c, &c->d_red_taskblk); dev_free(c, &c->d_red_wgtasks); c->red_task_cap = 0;
+	c->red_active = false;
 }
 
 // Device-side input path (row N2): rows go up as they are (one copy per row), the alphabet scan
@@ -864,7 +868,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
 	return FSEQ_OK;
 }
 
@@ -905,7 +909,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
 	return FSEQ_OK;
 }
 
@@ -1542,6 +1546,8 @@ struct LongRun {
 	bool tree_ran = false;                   // phase A ran the key-space tree at all (else: the column sweep did every block, as last time)
 	bool tree_alone = false;                 // phase A ran the key-space tree without the column sweep behind it (no block was given up last time)
 	bool trie_ran = false, trie_alone = false;   // ... the trie over 16-column words (streamed rows); ... without the key-space tree behind it
+	bool redo = false;                       // [r5] lists of some blocks could not be proven on their representatives: the attempt runs again, those blocks on all rows
+	uint32_t redone = 0;
 };
 
 // the aliases every phase uses
@@ -1947,13 +1953,143 @@ int long_traceback_and_merge(fseq_ctx *c, LongRun &R, double th0, bool *overflow
 	return FSEQ_OK;
 }
 
+
+// ---- [r5] phase C on representative rows (fseq_reduced.hpp): the plan of one attempt.
+// k_reduce_prep leaves, per block, the representatives and the reduced start state; the host reads the counts back and
+// sorts the blocks into the configurations that hold them (a launch per configuration in use) and the blocks that run on all
+// rows: more representatives than any configuration holds (or than pay: > 70 % of the rows), or lists an earlier run on this
+// input could not prove on the representatives.  *use: false when more than a quarter of the blocks would run on all rows
+// anyway -- the attempt then takes the run on all rows with its stride states (diverse inputs).
+bool columns_fit_reduced(fseq_ctx const *c, ReducedSet const &rs)
+{
+	// (value ids of a block -- its boundary values and one per column -- are 16-bit keys of the partition step)
+	return rs.lds(c->B) <= LDS_LIMIT && (uint64_t) rs.rows + c->B + 1u <= 65535u;
+}
+
+int red_plan(fseq_ctx *c, uint32_t X, bool *use)
+{
+	FSEQ_LONG_LOCALS(c);
+	*use = false;
+	uint32_t cap = std::min<uint32_t>(m, 11264u);
+	if (c->tune.reduced_cap) cap = std::min<uint32_t>(cap, (uint32_t) c->tune.reduced_cap);
+	uint32_t const nbk = c->nblocks;
+	if (!c->d_red_cnt || c->red_cap != cap)
+	{
+		if ((rc = dev_alloc(c, &c->d_red_cnt, nbk))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_vmin, nbk))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_invalid, nbk + 1))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_blocks, 2 * (size_t) nbk))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_rows, (size_t) nbk * cap))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_leaf, (size_t) nbk * cap))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_a, (size_t) nbk * cap))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_d, (size_t) nbk * cap))) return rc;
+		c->red_cap = cap;
+	}
+	if (c->red_pin_words < 4 * (size_t) nbk + 64)
+	{
+		if (c->h_red_pin) (void) hipHostFree(c->h_red_pin);
+		c->h_red_pin = nullptr; c->red_pin_words = 0;
+		HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_red_pin), (4 * (size_t) nbk + 64) * 4, hipHostMallocDefault));
+		c->red_pin_words = 4 * (size_t) nbk + 64;
+	}
+	RedPrepArgs A{};
+	A.bstate_a = c->d_bstate_a; A.bstate_d = c->d_bstate_d; A.rank = c->d_rank; A.blocks = nullptr;
+	A.m = m; A.B = c->B; A.L = (uint32_t) L; A.cap = cap; A.block0 = 0; A.leaf_only = 0; A.n = n;
+	A.Xp = X + (c->tune.reduced_margin >= 0 ? (uint32_t) c->tune.reduced_margin : X / 4u + 8u);
+	A.cnt = c->d_red_cnt; A.vmin = c->d_red_vmin; A.rows = c->d_red_rows; A.leaf = c->d_red_leaf; A.a = c->d_red_a; A.d = c->d_red_d;
+	HIP_TRY(c, launch_reduce_prep(st, nbk, A));
+	uint32_t *const h_cnt = c->h_red_pin;
+	HIP_TRY(c, hipMemcpyAsync(h_cnt, c->d_red_cnt, (size_t) nbk * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemsetAsync(c->d_red_invalid, 0, ((size_t) nbk + 1) * 4, st));
+	HIP_TRY(c, hipStreamSynchronize(st));
+	c->red_cnt_host.assign(h_cnt, h_cnt + nbk);
+	if (c->red_force_full.size() != nbk) c->red_force_full.assign(nbk, 0);
+	c->red_full.assign(nbk, 0);
+	c->red_config_of.assign(nbk, -1);
+	int const nconf = reduced_config_count();
+	std::vector<ReducedSet> sets((size_t) nconf);
+	for (int i = 0; i < nconf; ++i) (void) reduced_config(i, &sets[(size_t) i]);
+	std::vector<std::vector<uint32_t>> per((size_t) nconf);
+	uint32_t n_full = 0, max_rows = 0, listed = 0;
+	uint64_t sum_rows = 0;
+	uint32_t *const h_blocks = c->h_red_pin + nbk;             // [0, listed): every reduced block; then the configurations' lists
+	for (uint32_t b = 0; b < nbk; ++b)
+	{
+		uint32_t const r = c->red_cnt_host[b];
+		if (r != RED_NONE)
+		{
+			h_blocks[listed++] = b;
+			max_rows = std::max(max_rows, r);
+			int cf = -1;
+			for (int i = 0; i < nconf; ++i) if (sets[(size_t) i].rows >= r && columns_fit_reduced(c, sets[(size_t) i])) { cf = i; break; }
+			c->red_config_of[b] = cf;
+		}
+		bool const full = r == RED_NONE || c->red_config_of[b] < 0 || c->red_force_full[b] || (uint64_t) r * 10u > (uint64_t) m * 7u;
+		if (full) { c->red_full[b] = 1; ++n_full; }
+		else { per[(size_t) c->red_config_of[b]].push_back(b); sum_rows += r; }
+	}
+	c->red_listed = listed; c->red_max_rows = max_rows;
+	c->tm.reduced_blocks = nbk - n_full;
+	c->tm.reduced_rows_mean = nbk > n_full ? (uint32_t) (sum_rows / (nbk - n_full)) : 0u;
+	if (c->tune.debug)
+		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", nbk - n_full, nbk,
+		        c->tm.reduced_rows_mean, m, max_rows, n_full);
+	if ((uint64_t) n_full * 4u > nbk) return FSEQ_OK;
+	// the reduced alignment: column k at d_red_msa + k * red_ld
+	{
+		size_t const ldr = ((size_t) sym_bytes(max_rows ? max_rows : 1u, c->bsh) + 15) & ~size_t(15);
+		size_t const need = (size_t) n * ldr + 64;
+		if (c->red_msa_bytes < need || c->red_ld != ldr)
+		{
+			if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa, need))) return rc; c->red_msa_bytes = need; }
+			c->red_ld = ldr;
+		}
+	}
+	c->red_bins.clear();
+	uint32_t at = listed;
+	for (int i = 0; i < nconf; ++i)
+	{
+		auto const &v = per[(size_t) i];
+		if (v.empty()) continue;
+		std::copy(v.begin(), v.end(), h_blocks + at);
+		c->red_bins.push_back(fseq_ctx::RedBin{i, at, (uint32_t) v.size()});
+		at += (uint32_t) v.size();
+	}
+	HIP_TRY(c, hipMemcpyAsync(c->d_red_blocks, h_blocks, (size_t) at * 4, hipMemcpyHostToDevice, st));
+	launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+	*use = true;
+	return FSEQ_OK;
+}
+
+// the lists of the reduced blocks, configuration by configuration
+int red_columns(fseq_ctx *c)
+{
+	FSEQ_LONG_LOCALS(c);
+	for (auto const &bin : c->red_bins)
+	{
+		ReducedSet rs;
+		(void) reduced_config(bin.config, &rs);
+		size_t const lds = rs.lds(c->B);
+		HIP_TRY(c, rs.prepare(lds));
+		RedArgs RA;
+		RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf; RA.blocks = c->d_red_blocks + bin.first;
+		RA.invalid = c->d_red_invalid; RA.cap = c->red_cap; RA.m_true = m;
+		rs.launch(st, bin.count, lds, c->d_red_msa, c->red_ld, n, c->B, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh, RA);
+	}
+	HIP_TRY(c, hipGetLastError());
+	return FSEQ_OK;
+}
+
 int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 {
 	FSEQ_LONG_LOCALS(c);
 	uint32_t &X = R.X;
 	double &ms_c = R.ms_c, &ms_dp = R.ms_dp, &ms_host = R.ms_host;
 	bool const keyspace = R.keyspace;
-	if ((rc = ensure_work_buffers(c, X))) return rc;
+	// [r5] phase C on representative rows: the default wherever the lists are consumed by the speculative DP behind phase C
+	// (not sharded yet: a rank's halo block has no state behind it to take the classes from)
+	bool const red_candidate = !sharded && !c->use_stream && !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
+	if ((rc = ensure_work_buffers(c, X, !red_candidate))) return rc;
 	// ---- phase C + D
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
 	HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 1024, st));
@@ -2084,7 +2220,28 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			if ((rc = dp_spec_reset(c, spec, c->stream2))) return rc;
 			HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
 		}
-		if (!sharded) launch_columns(0, c->nblocks);
+		c->red_active = false;
+		if (!sharded && red_candidate && use_spec)
+		{
+			bool use = false;
+			if ((rc = red_plan(c, X, &use))) return rc;
+			if (use)
+			{
+				c->red_active = true;
+				if ((rc = red_columns(c))) return rc;
+				// the blocks that run on all rows (no stride states: pass 2 reaches their boundaries from the block's start)
+				for (uint32_t b = 0; b < c->nblocks;)
+				{
+					if (!c->red_full[b]) { ++b; continue; }
+					uint32_t e = b;
+					while (e < c->nblocks && c->red_full[e]) ++e;
+					launch_columns(b, e - b);
+					b = e;
+				}
+			}
+			else if ((rc = ensure_work_buffers(c, X, true))) return rc;      // (the stride states after all)
+		}
+		if (!sharded && !c->red_active) launch_columns(0, c->nblocks);
 		if (sync_at(c, 'C')) { fprintf(stderr, "[fseq] phase C queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase C done\n"); }
 		if (sharded && my_blocks)
 		{
@@ -2150,7 +2307,24 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	h_flags[5] = 0;
 	h_flags[6] = 0;
 	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 12, hipMemcpyDeviceToHost, st));
+	h_flags[7] = 0;
+	if (c->red_active)
+	{
+		// any block whose lists could not be proven on its representatives?  (one word; the per-block flags only then)
+		hipLaunchKernelGGL(k_any_nonzero, dim3(1), dim3(256), 0, st, c->d_red_invalid, c->nblocks, c->d_red_invalid + c->nblocks);
+		HIP_TRY(c, hipMemcpyAsync(h_flags + 7, c->d_red_invalid + c->nblocks, 4, hipMemcpyDeviceToHost, st));
+	}
 	HIP_TRY(c, hipStreamSynchronize(st));
+	R.redo = false;
+	if (c->red_active && h_flags[7])
+	{
+		std::vector<uint32_t> inv(c->nblocks);
+		HIP_TRY(c, hipMemcpy(inv.data(), c->d_red_invalid, (size_t) c->nblocks * 4, hipMemcpyDeviceToHost));
+		uint32_t cnt = 0;
+		for (uint32_t b = 0; b < c->nblocks; ++b) if (inv[b] && !c->red_full[b]) { c->red_force_full[b] = 1; ++cnt; }
+		if (c->tune.debug) fprintf(stderr, "[fseq] reduced phase C: the lists of %u blocks reach below what their representatives vouch for: those blocks again on all rows\n", cnt);
+		if (cnt) { R.redo = true; R.redone += cnt; *overflow_out = false; return FSEQ_OK; }
+	}
 	if (keyspace)
 	{
 		if (!R.tree_ran) h_flags[5] = my_blocks;               // (no tree this time: every block went to the column sweep, as last time)
@@ -2215,10 +2389,158 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	return FSEQ_OK;
 }
 
+
+// ---- [r5] pass 2 behind the reduced phase C: a boundary inside a block is ONE chain step from the block's boundary state
+// (k_chain_snap), keyed by the classes the block's representatives form at that column (k_columns_red with the class
+// tables as its output); a boundary on a block border is that border's state.  Blocks without representatives (more than a
+// configuration holds) replay their columns on all rows from the block's start (k_colblock<MODE_SNAP>).
+int long_pass2_reduced(fseq_ctx *c, LongRun &R)
+{
+	FSEQ_LONG_LOCALS(c);
+	size_t const S2 = c->segments.size();
+	if (!S2) return FSEQ_OK;
+	ChainSnapSet cs;
+	if (!select_chain_snap(ks.T, ks.E, &cs)) return fail(c, FSEQ_E_UNSUPPORTED, "pass 2: no chain step for this configuration");
+	HIP_TRY(c, cs.prepare());
+	c->snap_slot.assign(S2, -1);
+	std::vector<uint64_t> rbs(S2);
+	std::vector<uint32_t> task_blk(S2), ncls0(S2);
+	// tasks of reduced blocks by configuration: workgroups {block, first task, count}; tasks of the other blocks: old groups
+	struct Wg { uint32_t blk, first, count; };
+	std::vector<std::vector<Wg>> wgs((size_t) reduced_config_count());
+	std::vector<uint64_t> o_rbs, o_srcs;
+	std::vector<uint2> o_grp;
+	std::vector<uint32_t> o_slot;
+	uint64_t cells = 0;
+	for (size_t i = 0; i < S2; ++i)
+	{
+		uint64_t const rb = c->segments[i].rb;
+		c->snap_slot[i] = (int64_t) i;
+		rbs[i] = rb;
+		bool const border = rb % c->B == 0;
+		uint32_t const blk = border ? (uint32_t) (rb / c->B) : (uint32_t) std::min<uint64_t>(rb / c->B, c->nblocks - 1u);
+		task_blk[i] = blk;
+		ncls0[i] = 0;                                             // a border: the copy; else the sweep fills it in
+		if (border) continue;
+		int const cf = c->red_config_of[blk];
+		if (cf >= 0 && c->red_cnt_host[blk] != RED_NONE)
+		{
+			auto &v = wgs[(size_t) cf];
+			if (!v.empty() && v.back().blk == blk) ++v.back().count;
+			else v.push_back(Wg{blk, (uint32_t) i, 1u});
+		}
+		else
+		{
+			ncls0[i] = 0xFFFFFFFFu;                                // not this kernel's
+			if (!o_srcs.empty() && o_srcs.back() == blk) ++o_grp.back().y;
+			else { o_grp.push_back(make_uint2((uint32_t) o_rbs.size(), 1u)); o_srcs.push_back(blk); }
+			o_rbs.push_back(rb); o_slot.push_back((uint32_t) i);
+		}
+	}
+	if (c->snap_cap < S2)
+	{
+		if ((rc = dev_alloc(c, &c->d_snap_a, S2 * (size_t) m))) return rc;
+		if ((rc = dev_alloc(c, &c->d_snap_d, S2 * (size_t) m))) return rc;
+		c->snap_cap = S2;
+	}
+	if (c->red_task_cap < S2)
+	{
+		if ((rc = dev_alloc(c, &c->d_red_cls, S2 * (size_t) c->red_cap))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_headd, S2 * (size_t) c->red_cap))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_ncls, S2))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_taskblk, S2))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_wgtasks, 2 * S2 + 2 * (size_t) c->nblocks))) return rc;
+		c->red_task_cap = S2;
+	}
+	if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
+	// (pageable sources: the runtime stages them before the call returns)
+	HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->d_red_taskblk, task_blk.data(), S2 * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(c->d_red_ncls, ncls0.data(), S2 * 4, hipMemcpyHostToDevice, st));
+	HIP_TRY(c, hipEventRecord(c->ev[6], st));
+	progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
+	FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
+	// the class tables, configuration by configuration
+	{
+		std::vector<uint32_t> hb, hw;
+		struct Launch_ { int cf; uint32_t first, count; };
+		std::vector<Launch_> ls;
+		for (size_t cf = 0; cf < wgs.size(); ++cf)
+		{
+			if (wgs[cf].empty()) continue;
+			ls.push_back(Launch_{(int) cf, (uint32_t) hb.size(), (uint32_t) wgs[cf].size()});
+			for (auto const &w : wgs[cf])
+			{
+				hb.push_back(w.blk); hw.push_back(w.first); hw.push_back(w.count);
+				cells += (rbs[w.first + w.count - 1u] - (uint64_t) w.blk * c->B) * c->red_cnt_host[w.blk];
+			}
+		}
+		if (!hb.empty())
+		{
+			uint32_t *const d_wb = c->d_red_wgtasks + 2 * S2;       // [workgroup] block, behind the {first, count} pairs
+			HIP_TRY(c, hipMemcpyAsync(d_wb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, st));
+			for (auto const &l : ls)
+			{
+				ReducedSet rs;
+				(void) reduced_config(l.cf, &rs);
+				size_t const lds = rs.lds(c->B);
+				HIP_TRY(c, rs.prepare(lds));
+				RedArgs RA;
+				RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf; RA.blocks = d_wb + l.first;
+				RA.invalid = c->d_red_invalid; RA.cap = c->red_cap; RA.m_true = m;
+				RA.wg_tasks = c->d_red_wgtasks + 2 * (size_t) l.first; RA.task_rb = reinterpret_cast<unsigned long long const *>(c->d_cols);
+				RA.cls = c->d_red_cls; RA.headd = c->d_red_headd; RA.ncls = c->d_red_ncls;
+				rs.launch(st, l.count, lds, c->d_red_msa, c->red_ld, n, c->B, (uint32_t) L, 0u, 0u, (uint2 *) nullptr, (uint4 *) nullptr, c->npass, c->bsh, RA);
+			}
+		}
+	}
+	// one chain step per boundary (a copy for the borders)
+	cs.launch(st, (uint32_t) S2, cs.lds, c->d_bstate_a, c->d_bstate_d, c->d_rank, m, c->d_red_taskblk, c->d_red_cls, c->d_red_headd, c->d_red_ncls, c->red_cap,
+	          c->d_snap_a, c->d_snap_d, scan_keyed(c));
+	for (size_t i = 0; i < S2; ++i)
+		if (ncls0[i] == 0u && rbs[i] % c->B != 0) cells += (uint64_t) m * 4u;      // (a step is ~4 digit passes over the rows)
+	// the boundaries of blocks without representatives: their columns on all rows from the block's start
+	if (!o_grp.empty())
+	{
+		size_t const So = o_rbs.size();
+		uint32_t *tmp_a = nullptr, *tmp_d = nullptr;
+		uint64_t *d_orb = nullptr, *d_osrc = nullptr;
+		uint2 *d_ogrp = nullptr;
+		if ((rc = dev_alloc(c, &tmp_a, So * (size_t) m))) return rc;
+		if ((rc = dev_alloc(c, &tmp_d, So * (size_t) m))) { dev_free(c, &tmp_a); return rc; }
+		if ((rc = dev_alloc(c, &d_orb, So)) || (rc = dev_alloc(c, &d_osrc, o_srcs.size())) || (rc = dev_alloc(c, &d_ogrp, o_grp.size())))
+		{ dev_free(c, &tmp_a); dev_free(c, &tmp_d); dev_free(c, &d_orb); dev_free(c, &d_osrc); dev_free(c, &d_ogrp); return rc; }
+		HIP_TRY(c, hipMemcpyAsync(d_orb, o_rbs.data(), So * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(d_osrc, o_srcs.data(), o_srcs.size() * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(d_ogrp, o_grp.data(), o_grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+		ks.snap(st, (uint32_t) o_grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, d_orb, d_ogrp,
+		        tmp_a, tmp_d, d_osrc, c->snap_stride, (uint32_t const *) nullptr, (uint32_t const *) nullptr, scan_keyed(c));
+		for (size_t j = 0; j < So; ++j)
+		{
+			HIP_TRY(c, hipMemcpyAsync(c->d_snap_a + (size_t) o_slot[j] * m, tmp_a + j * (size_t) m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_snap_d + (size_t) o_slot[j] * m, tmp_d + j * (size_t) m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
+		}
+		for (size_t g = 0; g < o_grp.size(); ++g) cells += (o_rbs[o_grp[g].x + o_grp[g].y - 1] - o_srcs[g] * c->B) * m;
+		HIP_TRY(c, hipStreamSynchronize(st));
+		dev_free(c, &tmp_a); dev_free(c, &tmp_d); dev_free(c, &d_orb); dev_free(c, &d_osrc); dev_free(c, &d_ogrp);
+	}
+	HIP_TRY(c, hipEventRecord(c->ev[7], st));
+	HIP_TRY(c, hipGetLastError());
+	HIP_TRY(c, hipStreamSynchronize(st));
+	FSEQ_RANGE_POP();
+	progress(c, FSEQ_STAGE_SAMPLES, S2, S2);
+	float f = 0;
+	HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); R.ms_p2 = f;
+	R.pass2_cells = cells;
+	return FSEQ_OK;
+}
+
 // ---- pass 2: (a, d) at the merged boundaries
 int long_pass2(fseq_ctx *c, LongRun &R)
 {
 	FSEQ_LONG_LOCALS(c);
+	if (c->red_active && !c->use_stream) return long_pass2_reduced(c, R);
 	uint64_t &pass2_cells = R.pass2_cells;
 	double &ms_p2 = R.ms_p2;
 	size_t const S2 = c->segments.size();
@@ -2380,6 +2702,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	{
 		bool overflow = false;
 		if ((rc = long_attempt(c, R, &overflow))) return rc;
+		if (R.redo) continue;                  // (the same capacity; the blocks that were flagged run on all rows now)
 		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
 		if (!overflow) break;
 		if (R.X >= m) return fail(c, FSEQ_E_HIP, "internal: divergence lists complete but DP flagged overflow");
@@ -2409,6 +2732,8 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	c->tm.pass2_cells = pass2_cells;
 	c->tm.list_cap_used = X;
 	c->tm.retries = retries;
+	c->tm.reduced_redone = R.redone;
+	if (!c->red_active) { c->tm.reduced_blocks = 0; c->tm.reduced_rows_mean = 0; }
 	c->tm.ms_total = now_ms() - t_begin;
 	c->have_result = true;
 	*res = c->res;
@@ -2563,6 +2888,7 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev_part) if (e) (void) hipEventDestroy(e);
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
 	if (c->h_pin) (void) hipHostFree(c->h_pin);
+	if (c->h_red_pin) (void) hipHostFree(c->h_red_pin);
 	if (c->h_done) (void) hipHostFree(c->h_done);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -2642,7 +2968,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2666,7 +2992,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2770,7 +3096,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
 	return FSEQ_OK;
 }
 
@@ -2827,6 +3153,8 @@ int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
 	free_work(c);
 	c->have_result = false;
 	c->kernels_ready = false;
+	// (what the last run saw belongs to the old geometry: a block the tree or the trie ranked then may be given up now)
+	c->bk_given_up = -1; c->bt_given_up = -1; c->red_force_full.clear();
 	return FSEQ_OK;
 }
 

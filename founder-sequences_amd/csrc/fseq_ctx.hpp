@@ -59,6 +59,31 @@ struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t co
 	// pass 2 on the same tile step (packed rows only; nullptr otherwise): k_columns_stream2<.., S2_SNAP>
 	void (*launch_snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
 	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, S2SnapArgs const &); };
+// [r5] phase C on representative rows (fseq_reduced.hpp; the kernels live in csrc/fseq_reduced.hip)
+struct ReducedSet {
+	uint32_t T, E, rows;                     // rows: representatives a workgroup holds
+	bool pk, ew;
+	size_t (*lds)(uint32_t B);
+	hipError_t (*prepare)(size_t lds);
+	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *red_msa, size_t red_ld, uint64_t n, uint32_t B, uint32_t L, uint32_t X, uint32_t stride,
+	               uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh, RedArgs const &);
+	uint32_t (*resident)(size_t lds);
+};
+// the smallest configuration that holds `rows` representatives (index into the list; -1: none)
+int reduced_config_count();
+bool reduced_config(int index, ReducedSet *out);
+// pass 2's chain step for the base configuration <T, E> of a KernelSet
+struct ChainSnapSet {
+	size_t lds;
+	hipError_t (*prepare)();
+	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *bstate_a, uint32_t const *bstate_d, uint32_t const *rank, uint32_t m,
+	               uint32_t const *task_blk, uint32_t const *cls, uint32_t const *headd, uint32_t const *ncls, uint32_t cap, uint32_t *snap_a, uint32_t *snap_d, uint32_t keyed);
+};
+bool select_chain_snap(uint32_t T, uint32_t E, ChainSnapSet *out);
+hipError_t launch_reduce_prep(hipStream_t, uint32_t grid, RedPrepArgs const &);
+void launch_reduce_msa(hipStream_t, uint32_t nblocks_listed, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,
+                       uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks);
+
 inline double now_ms()
 {
 	using namespace std::chrono;
@@ -105,6 +130,9 @@ struct Tuning {
 	int  inject_failure_rank = -1;       // FSEQ_INJECT_FAILURE_RANK: this rank of a sharded run fails after phase A
 	std::string sync_phases;             // FSEQ_SYNC_PHASES: "ABC": synchronise after these phases (a fault shows where it happened)
 	bool check_phase_a = false;          // FSEQ_CHECK_PHASE_A: validate the key blocks on the host before phase B
+	bool no_reduced = false;             // FSEQ_NO_REDUCED: phase C and pass 2 on all rows of every block (the form before round 5)
+	int  reduced_margin = -1;            // FSEQ_REDUCED_MARGIN: counts beyond the list capacity the choice of vmin allows for (tests: 0 makes lists dig below it)
+	int  reduced_cap = 0;                // FSEQ_REDUCED_CAP: most representatives a block may have (tests: small values send blocks to the run on all rows)
 
 	// returns false for a name it does not know
 	bool set(char const *name, char const *value)
@@ -148,6 +176,9 @@ struct Tuning {
 		else if (n == "FSEQ_INJECT_FAILURE_RANK") inject_failure_rank = on ? iv : -1;
 		else if (n == "FSEQ_SYNC_PHASES") sync_phases = v;
 		else if (n == "FSEQ_CHECK_PHASE_A") check_phase_a = on;
+		else if (n == "FSEQ_NO_REDUCED") no_reduced = on;
+		else if (n == "FSEQ_REDUCED_MARGIN") reduced_margin = on ? std::max(0, iv) : -1;
+		else if (n == "FSEQ_REDUCED_CAP") reduced_cap = on ? std::max(1, iv) : 0;
 		else return false;
 		return true;
 	}
@@ -159,7 +190,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -303,6 +334,26 @@ struct fseq_ctx {
 	size_t gather_cap = 0, gather_stride = 0;
 	uint32_t *d_snap_a = nullptr, *d_snap_d = nullptr;
 	size_t snap_cap = 0;
+
+	// [r5] phase C / pass 2 on representative rows (fseq_reduced.hpp): per block [red_cap] representatives (ascending row id),
+	// their block keys, the reduced start state; the reduced alignment (column k at d_red_msa + k * red_ld)
+	uint32_t *d_red_cnt = nullptr, *d_red_vmin = nullptr, *d_red_rows = nullptr, *d_red_leaf = nullptr, *d_red_a = nullptr, *d_red_d = nullptr;
+	uint32_t *d_red_invalid = nullptr, *d_red_blocks = nullptr;
+	uint32_t red_cap = 0, red_blocks_cap = 0;
+	uint8_t *d_red_msa = nullptr;
+	size_t red_ld = 0, red_msa_bytes = 0;
+	std::vector<uint32_t> red_cnt_host;      // representatives per block of the last prep (RED_NONE: not reduced)
+	std::vector<uint8_t> red_full;           // blocks this run sends to the kernel on all rows
+	std::vector<uint8_t> red_force_full;     // ... because an earlier run on this input could not prove their lists on the representatives
+	bool red_active = false;                 // this run's phase C went through the representatives (pass 2 follows it)
+	uint32_t *d_red_cls = nullptr, *d_red_headd = nullptr, *d_red_ncls = nullptr, *d_red_taskblk = nullptr, *d_red_wgtasks = nullptr;
+	size_t red_task_cap = 0;
+	uint32_t *h_red_pin = nullptr;           // pinned host staging of the plan (counts back, block lists out): its own buffer, live across the run
+	size_t red_pin_words = 0;
+	struct RedBin { int config; uint32_t first, count; };     // blocks [first, first + count) of d_red_blocks run on configuration `config`
+	std::vector<RedBin> red_bins;
+	std::vector<int> red_config_of;          // [block] configuration of a reduced block (-1: not reduced)
+	uint32_t red_listed = 0, red_max_rows = 0;   // d_red_blocks[0 .. red_listed): every reduced block; the most representatives among them
 
 	// results
 	bool have_result = false;

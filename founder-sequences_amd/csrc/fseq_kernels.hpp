@@ -87,7 +87,7 @@ __device__ __forceinline__ uint32_t sym_digit(uint8_t const *col, uint32_t a, ui
 // one thread per 32-bit word of one column = 4 << bsh consecutive rows (coalesced stores down the column);
 // blockIdx.y strides over the columns (a launch holds fewer than 2^32 threads per dimension)
 // columns [c_begin, c_end) (a rank of a sharded run generates its own share), column c at msa + c * ld
-__global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t c_begin, uint64_t c_end, uint32_t bsh)
+static __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__restrict__ msa, size_t ld, uint32_t m, uint64_t c_begin, uint64_t c_end, uint32_t bsh)
 {
 	uint32_t const words_per_col = (uint32_t) (ld / 4);
 	uint32_t const w = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_synth(SynthArgs const A, uint8_t *__res
 // Input side: raw sequence bytes -> dense codes, row-major -> column-major.
 // consecutive_alphabet_as_builder (generate_context.cc:135-147): which byte values occur ...
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ raw, size_t total, uint32_t *__restrict__ present /* 8 words */)
+static __global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ raw, size_t total, uint32_t *__restrict__ present /* 8 words */)
 {
 	__shared__ uint32_t bm[8];
 	if (threadIdx.x < 8) bm[threadIdx.x] = 0;
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void k_presence(uint8_t const *__restrict__ ra
 
 // Largest symbol code in borrowed device columns (fseq_set_device_columns*: the caller promises codes < sigma; a
 // larger code would silently lose its high digits in the 2-bit digit passes).  bits per code = 8 >> bsh.
-__global__ __launch_bounds__(256) void k_max_code(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t ncols, uint32_t bsh,
+static __global__ __launch_bounds__(256) void k_max_code(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t ncols, uint32_t bsh,
                                                   uint32_t tail_rows, uint32_t *__restrict__ out)
 {
 	uint32_t const bits = 8u >> bsh, smask = (1u << bits) - 1u;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_max_code(uint8_t const *__restrict__ ms
 // codes in ONE digit pass over the codes' ranks among the present ones (the remap keeps their order, so the stable sort -- and
 // every divergence -- is the one the two 2-bit passes produce): rare on the survey's generator, common in real gapped
 // alignments.  A padding nibble behind row m - 1 counts as code 0: a superset of the present codes is as good.
-__global__ __launch_bounds__(256) void k_column_presence(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t c_lo, uint64_t c_hi,
+static __global__ __launch_bounds__(256) void k_column_presence(uint8_t const *__restrict__ msa, size_t ld, uint32_t col_bytes, uint64_t c_lo, uint64_t c_hi,
                                                          uint32_t *__restrict__ out, uint32_t *__restrict__ n_dense /* += columns with <= 4 codes */)
 {
 	__shared__ uint32_t part[4];
@@ -224,7 +224,7 @@ struct CodeTable { uint8_t code_of[256]; };
 
 // ... and the encode + transpose + pack: raw[r * n + c] -> code_of[byte] at row r of packed column c; 64 x 64
 // tiles through LDS, reads coalesced along a row, writes down a column (64 >> bsh bytes per tile column).
-__global__ __launch_bounds__(256) void k_encode_transpose(
+static __global__ __launch_bounds__(256) void k_encode_transpose(
 	uint8_t const *__restrict__ raw, CodeTable const tab, uint32_t m, uint64_t n, uint8_t *__restrict__ msa, size_t ld, uint32_t bsh)
 {
 	__shared__ uint8_t tile[64][65];
@@ -746,19 +746,40 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 // DENSE (4-bit symbols): a column with at most four present codes takes ONE digit pass (colmask: k_column_presence).  A kernel of
 // its own -- compiled into the one every input runs, the three uniform branches cost BASELINE C5 2.6 ms and C3 0.14 ms --
 // that the host launches when at least one column in twenty is that dense.
-template <int T, int E, int SIGMA, bool PK, bool EW = false, bool DENSE = false>
-__global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
+// RED [r5] (fseq_reduced.hpp): the block's REPRESENTATIVE rows only -- one row of every class of rows that agree from column
+// vmin - 1 to the end of the block, the start state restricted to them (k_reduce_prep), the packed columns of those rows
+// (k_reduce_msa: msa / ld are the reduced alignment's).  Every count of values >= v is then the full run's for every
+// v >= vmin, so the lists are the full run's as long as no entry below vmin is taken; a list that takes one flags the block
+// (red.invalid) and the block is run again on all rows.  vmin == 1: the rows left out are duplicates over all of [0, k1) --
+// their divergences are zeros, added where the zeros are counted -- and every list is exact.  With red.cls set (pass 2) the
+// workgroup emits, instead of lists, the class tables at its task columns: the class of every block key (rank among the
+// distinct key prefixes up to that column) and the divergence in front of every class -- what one chain step from the
+// block's boundary state needs (k_chain_snap).
+template <int T, int E, int SIGMA, bool PK, bool EW, bool DENSE, bool RED>
+__device__ __forceinline__ void columns_body(char *smem,
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask = nullptr)
+	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask, RedArgs const &red)
 {
 	// colmask (4-bit symbols, or nullptr): the codes present in every column (k_column_presence)
 	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
 	FSEQ_CLOCK_STAMP(blockIdx.x, 0);
 	constexpr uint32_t CAP = T * E;
-	extern __shared__ __attribute__((aligned(16))) char smem[];
+	uint32_t const blk = RED ? red.blocks[blockIdx.x] : blockIdx.x + block0;
+	uint32_t red_vmin = 0, red_deficit = 0, t_first = 0, t_count = 0, t_next = 0;
+	bool const red_snap = RED && red.cls != nullptr;
+	if constexpr (RED)
+	{
+		m = red.cnt[blk];
+		if (m == RED_NONE || m > (EW ? (uint32_t) (T - 64) * E : CAP)) return;      // (never listed: a block the host runs on all rows)
+		red_vmin = red.vmin[blk];
+		red_deficit = red.m_true - m;
+		N2 = 2; while (N2 < m + 1u) N2 <<= 1;
+		if (red_snap) { t_first = red.wg_tasks[2u * blockIdx.x]; t_count = red.wg_tasks[2u * blockIdx.x + 1u]; }
+	}
+	bool const red_exact = RED && red_vmin <= 1u;
 	// [a_l][d_l][sym0][sym1][cnt_l] are contiguous: the prologue's sort buffer (N2 < 2m words) overlays them
 	using AT = std::conditional_t<PK, uint16_t, uint32_t>;     // row ids < m, value ids < m + B
 	Carver cv{smem};
@@ -777,21 +798,22 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = EW ? (tid >= 64u ? (tid - 64u) * E : 0x7FFF0000u) : tid * E;     // 0x7FFF0000: owns nothing (every p0 + e >= m)
 	bool const rows = !EW || tid >= 64u;
-	uint64_t const k0 = (uint64_t) (blockIdx.x + block0) * B;
-	uint64_t const kend = (k0 + B < n) ? k0 + B : n;
+	uint64_t const k0 = (uint64_t) blk * B;
+	uint64_t const kend = red_snap ? (uint64_t) red.task_rb[t_first + t_count - 1u] : ((k0 + B < n) ? k0 + B : n);
 	uint32_t const nb = (uint32_t) (kend - k0);
 
 	// ---- prologue
 	// boundary state straight into registers (chunk ownership: positions tid*E .. tid*E+E-1)
 	uint32_t a[E], d[E];
 	{
-		size_t const ob = (size_t) (blockIdx.x + block0) * m;
+		size_t const ob = RED ? (size_t) blk * red.cap : (size_t) blk * m;
+		uint32_t const *const sa = RED ? red.a : bstate_a, *const sd = RED ? red.d : bstate_d;
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
 			uint32_t const pos = p0 + e;
-			a[e] = pos < m ? bstate_a[ob + pos] : 0u;
-			d[e] = pos < m ? bstate_d[ob + pos] : 0u;
+			a[e] = pos < m ? sa[ob + pos] : 0u;
+			d[e] = pos < m ? sd[ob + pos] : 0u;
 		}
 	}
 
@@ -802,6 +824,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 #pragma unroll
 	for (int e = 0; e < E; ++e)
 		if (p0 + e < m) sb[p0 + e] = d[e];
+	if (RED && red_exact && tid == 0) sb[m] = 0u;               // the value of the rows left out always has an id: 0
 	__syncthreads();
 	bitonic_sort_lds<T>(sb, N2);
 	uint32_t D0;
@@ -995,6 +1018,45 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 			}
 		}
 
+		// ---- [r5] pass 2 on the representatives: the class tables at a task column.  A position starts a class iff its
+		// divergence lies inside the block (an id of one of the block's columns); the class of a block key is the class of any
+		// representative that carries it.
+		if (RED && red_snap)
+		{
+			if (t_next < t_count && red.task_rb[t_first + t_next] == k0 + j + 1u)
+			{
+				uint32_t const task = t_first + t_next;
+				uint32_t nf = 0;
+				if (rows)
+				{
+#pragma unroll
+					for (int e = 0; e < E; ++e) nf += (p0 + e < m && (uint32_t) d_l[p0 + e] >= D0) ? 1u : 0u;
+				}
+				uint32_t total;
+				uint32_t r = block_excl_add<T>(nf, sscr, &total);
+				size_t const ot = (size_t) task * red.cap, ol = (size_t) blk * red.cap;
+				if (rows)
+				{
+#pragma unroll
+					for (int e = 0; e < E; ++e)
+					{
+						uint32_t const pos = p0 + e;
+						if (pos < m)
+						{
+							uint32_t const vid = d_l[pos];
+							bool const first = vid >= D0;
+							r += first ? 1u : 0u;
+							red.cls[ot + red.leaf[ol + a_l[pos]]] = r - 1u;
+							if (first) red.headd[ot + r - 1u] = (uint32_t) (k0 + (vid - D0) + 1u);
+						}
+					}
+				}
+				if (tid == 0) red.ncls[task] = total;
+				++t_next;
+			}
+			continue;
+		}
+
 		// ---- emit the top of the histogram for column k0+j (wave 0; the others run ahead into
 		// the next column and meet it again at the partition step's barrier).
 		// Entry 0 lumps every value >= thr = end+1-L (end = k+1): the DP clips all of them to the same
@@ -1017,7 +1079,11 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 			uint2 *out = ent + k * (size_t) stride;
 			int32_t const top = (int32_t) (D0 + j);
 			uint32_t cumN = 0, nent = 1, R = 0;       // cumN: count of the values below thr taken so far
-			for (int32_t base = top; base >= 0; base -= 256)
+			// RED: exact -- id 0 (value 0, with the rows left out) follows behind the loop; else the ids below red_idmin are values
+			// below vmin, which the representatives cannot vouch for
+			int32_t const id_lo = (RED && red_exact) ? 1 : 0;
+			bool red_stopped = false, red_bad = false;
+			for (int32_t base = top; base >= id_lo; base -= 256)
 			{
 				// lane l holds the ids base - 4l - q, q = 0..3: descending ids = descending values, lane-major
 				uint32_t c[4], v[4];
@@ -1030,7 +1096,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 				for (int q = 0; q < 4; ++q)
 				{
 					int32_t const i = base - 4 * (int32_t) lane - q;
-					c[q] = (i >= 0) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
+					c[q] = (i >= id_lo) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
 					v[q] = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
 					bool const nz = c[q] > 0;
 					bool const rec = nz && v[q] >= thr;       // the values >= thr are a prefix of the non-zero entries
@@ -1054,6 +1120,7 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 					uint32_t const excN = cumN + run_c - r_tot;
 					tk[q] = cand[q] && excN <= X;
 					if (tk[q]) { out[nent + run_o] = make_uint2(v[q], c[q]); lastP = excN + c[q]; }
+					if (RED && !red_exact) red_bad = red_bad || (tk[q] && v[q] < red_vmin);
 					run_o += cand[q] ? 1u : 0u;
 					run_c += c[q];
 				}
@@ -1069,13 +1136,33 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 				nent += taken;
 				if (taken) cumN = readlane_u32(mx, 63);
 				R += r_tot;
-				if (taken != tot_o || cumN > X) break;
+				if (taken != tot_o || cumN > X) { red_stopped = true; break; }
+			}
+			uint32_t cnt0 = zero_present ? cnt_get<PK>(cnt_l, 0u) : 0u;
+			if constexpr (RED)
+			{
+				if (red_exact)
+				{
+					// the zeros: those of the representatives and the rows left out (duplicates of a representative over [0, k1))
+					cnt0 += red_deficit;
+					if (!red_stopped && cnt0)
+					{
+						if (thr == 0u) R += cnt0;
+						else { if (lane == 0) out[nent] = make_uint2(0u, cnt0); ++nent; cumN += cnt0; }
+					}
+				}
+				else
+				{
+					cnt0 = 0;                                            // (unknown -- and unused: the list is not complete)
+					// a taken entry below vmin, or every value taken while rows are left out: the run on all rows would go on
+					if (__ballot(red_bad) != 0ull || (!red_stopped && red_deficit != 0u)) { if (lane == 0) red.invalid[blk] = 1u; }
+				}
 			}
 			uint32_t const cum = R + cumN;
 			if (lane == 0)
 			{
 				out[0] = make_uint2((uint32_t) (k + 1), R);
-				hdr[k] = make_uint4(nent, zero_present ? cnt_get<PK>(cnt_l, 0u) : 0u, cum == m ? 1u : 0u, cum);
+				hdr[k] = make_uint4(nent, cnt0, cum == (RED ? red.m_true : m) ? 1u : 0u, cum);
 			}
 #ifdef FSEQ_KC_STAMPS
 			kcs.acc[5] += clock64() - kc_l0;
@@ -1093,13 +1180,37 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 #endif
 	FSEQ_CLOCK_STAMP(blockIdx.x, 1);
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)
-	publish_block_done(done_host, blockIdx.x + block0, epoch);
+	if constexpr (!RED) publish_block_done(done_host, blk, epoch);
+}
+
+template <int T, int E, int SIGMA, bool PK, bool EW = false, bool DENSE = false>
+__global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t N2,
+	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
+	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
+	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask = nullptr)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	columns_body<T, E, SIGMA, PK, EW, DENSE, false>(smem, msa, ld, m, n, B, N2, bstate_a, bstate_d, L, X, stride, ent, hdr, npass, bsh, snap_stride, ss_a, ss_d, block0,
+	                                                 done_host, epoch, colmask, RedArgs{});
+}
+
+// [r5] the same on a block's representative rows (msa / ld: the reduced alignment; red: fseq_types.hpp)
+template <int T, int E, int SIGMA, bool PK, bool EW = false>
+__global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns_red(
+	uint8_t const *__restrict__ msa, size_t ld, uint64_t n, uint32_t B,
+	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh, RedArgs const red)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	columns_body<T, E, SIGMA, PK, EW, false, true>(smem, msa, ld, 0u, n, B, 0u, nullptr, nullptr, L, X, stride, ent, hdr, npass, bsh, 0u, nullptr, nullptr, 0u,
+	                                                nullptr, 0u, nullptr, red);
 }
 
 // List-capacity estimate: the length-L segment ending at block boundary k has #{i : d_k[i] > k - L} distinct
 // rows; the median over the boundaries sizes the per-column lists before phase C runs (a wrong guess only
 // costs a retry, never the result).
-__global__ __launch_bounds__(256) void k_boundary_recent(
+static __global__ __launch_bounds__(256) void k_boundary_recent(
 	uint32_t const *__restrict__ bstate_d, uint32_t m, uint64_t n, uint32_t B, uint32_t L, uint32_t *__restrict__ out, uint32_t block0)
 {
 	// boundary block0 + blockIdx.x (a rank of a sharded run looks at its own boundaries)
@@ -1117,8 +1228,20 @@ __global__ __launch_bounds__(256) void k_boundary_recent(
 	if (threadIdx.x == 0) out[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
+// out[0] = 1 iff some word of v[0 .. count) is not zero
+static __global__ __launch_bounds__(256) void k_any_nonzero(uint32_t const *__restrict__ v, uint32_t count, uint32_t *__restrict__ out)
+{
+	uint32_t any = 0;
+	for (uint32_t i = threadIdx.x; i < count; i += 256u) any |= v[i];
+	__shared__ uint32_t red[4];
+	bool const some = __ballot(any != 0u) != 0ull;
+	if (lane_id() == 0) red[wave_id()] = some ? 1u : 0u;
+	__syncthreads();
+	if (threadIdx.x == 0) out[0] = red[0] | red[1] | red[2] | red[3];
+}
+
 // copy the lists of selected columns into a compact buffer (for the host-side merge)
-__global__ __launch_bounds__(64) void k_gather_lists(
+static __global__ __launch_bounds__(64) void k_gather_lists(
 	uint64_t const *__restrict__ cols, uint32_t stride, uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr,
 	uint2 *__restrict__ out_ent, uint4 *__restrict__ out_hdr)
 {
@@ -1149,7 +1272,7 @@ __device__ __forceinline__ uint32_t tb_next(uint32_t lb, uint32_t t, uint32_t L)
 
 // (a rank of a sharded run holds valid lb's for the entries [vlo, vhi) it computed: the chain leaves its part at the
 // first entry below vlo, windows outside the part have nothing to do; vlo = 0, vhi = dp_size: the whole array)
-__global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__ LB, uint32_t dp_size, uint32_t L,
+static __global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__ LB, uint32_t dp_size, uint32_t L,
                                                     uint32_t *__restrict__ exit_next, uint32_t *__restrict__ exit_cnt,
                                                     uint32_t vlo = 0, uint32_t vhi = 0xFFFFFFFFu)
 {
@@ -1186,7 +1309,7 @@ __global__ __launch_bounds__(256) void k_tb_windows(uint32_t const *__restrict__
 }
 
 // head[w] = {entry point, output offset} of the w-th visited window; count[0] = segments, count[1] = ok, count[2] = windows
-__global__ __launch_bounds__(64) void k_tb_chain(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t dp_size,
+static __global__ __launch_bounds__(64) void k_tb_chain(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t dp_size,
                                                  uint2 *__restrict__ head, uint32_t max_windows, uint32_t *__restrict__ count)
 {
 	if (threadIdx.x != 0) return;
@@ -1206,7 +1329,7 @@ __global__ __launch_bounds__(64) void k_tb_chain(uint32_t const *__restrict__ ex
 // chain ends or leaves the part; the rank's output begins at offset off0 of the whole traceback.
 // count[0] = entries of this rank, count[2] = its windows; word[0] = 1 + the entry the chain continues at (0: it ended
 // here), word[1] = entries of this rank -- what the other ranks need to carry on (fseq_api.hip, follow_traceback_sharded)
-__global__ __launch_bounds__(64) void k_tb_chain_part(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t start, uint32_t off0,
+static __global__ __launch_bounds__(64) void k_tb_chain_part(uint32_t const *__restrict__ exit_next, uint32_t const *__restrict__ exit_cnt, uint32_t start, uint32_t off0,
                                                       uint32_t vlo, uint2 *__restrict__ head, uint32_t max_windows, uint32_t *__restrict__ count, uint32_t *__restrict__ word)
 {
 	if (threadIdx.x != 0) return;
@@ -1224,7 +1347,7 @@ __global__ __launch_bounds__(64) void k_tb_chain_part(uint32_t const *__restrict
 	word[0] = next; word[1] = off - off0;
 }
 
-__global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB, uint32_t const *__restrict__ M, uint32_t const *__restrict__ SZ,
+static __global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB, uint32_t const *__restrict__ M, uint32_t const *__restrict__ SZ,
                                                  uint32_t dp_size, uint32_t L, uint2 const *__restrict__ head, uint32_t *__restrict__ count,
                                                  uint4 *__restrict__ out, uint32_t cap, uint32_t vlo = 0)
 {
@@ -1262,7 +1385,7 @@ __global__ __launch_bounds__(256) void k_tb_emit(uint32_t const *__restrict__ LB
 
 // out[j] = {a[idx[j]], b[idx[j]]}: the DP entries on the traceback path (the host walks the lb chain, the keys and
 // sizes of the visited entries follow in one small copy)
-__global__ __launch_bounds__(256) void k_gather_pairs(uint32_t const *__restrict__ idx, uint32_t count, uint32_t const *__restrict__ a,
+static __global__ __launch_bounds__(256) void k_gather_pairs(uint32_t const *__restrict__ idx, uint32_t count, uint32_t const *__restrict__ a,
                                                       uint32_t const *__restrict__ b, uint2 *__restrict__ out)
 {
 	uint32_t const j = blockIdx.x * 256u + threadIdx.x;
@@ -1278,7 +1401,7 @@ __global__ __launch_bounds__(256) void k_gather_pairs(uint32_t const *__restrict
 //   (incomplete) before the count was exceeded: current_lb < tau is undecided (lists too short);  2: never (the
 //   values within L of the boundary alone exceed it).
 enum { SEG_TAU_EXACT = 0, SEG_TAU_OPEN = 1, SEG_TAU_NEVER = 2 };
-__global__ __launch_bounds__(64) void k_seg_tau(
+static __global__ __launch_bounds__(64) void k_seg_tau(
 	uint64_t const *__restrict__ cols, uint64_t col_lo, uint64_t col_hi, uint32_t max_seg, uint32_t stride,
 	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint2 *__restrict__ out)
 {
@@ -1310,7 +1433,7 @@ __global__ __launch_bounds__(64) void k_seg_tau(
 // The same straight off the device traceback (k_tb_emit's output: entry i = {end - L, lb, max, size}, the last segment
 // first; count[0] = S entries), so that the thresholds travel to the host together with the traceback: workgroup i
 // answers for the boundary of entry i and writes out[S - 1 - i] (the host's order); max_seg = entry 0's maximum.
-__global__ __launch_bounds__(64) void k_seg_tau_tb(
+static __global__ __launch_bounds__(64) void k_seg_tau_tb(
 	uint4 const *__restrict__ tb, uint32_t const *__restrict__ count, uint32_t L, uint32_t stride,
 	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint2 *__restrict__ out)
 {
@@ -1343,7 +1466,7 @@ __global__ __launch_bounds__(64) void k_seg_tau_tb(
 }
 
 // ... and the size of a merged segment: #{d_col+1 > lb} for (col, lb) pairs (lp.cc:363,366), same ownership rule
-__global__ __launch_bounds__(64) void k_seg_count(
+static __global__ __launch_bounds__(64) void k_seg_count(
 	uint64_t const *__restrict__ cols, uint64_t const *__restrict__ lbs, uint64_t col_lo, uint64_t col_hi, uint32_t stride,
 	uint2 const *__restrict__ ent, uint4 const *__restrict__ hdr, uint32_t *__restrict__ out)
 {

@@ -16,4 +16,35 @@ struct DpArrays {
 
 struct S2SnapArgs;                   // fseq_stream2.hpp: the boundaries of a pass-2 launch on the streamed tile step
 
+// [r5] Phase C on a block's REPRESENTATIVE rows (fseq_reduced.hpp): what k_reduce_prep left for every block and where a
+// workgroup of the reduced column kernel finds it.  Plain pointers into device memory.
+constexpr uint32_t RED_NONE = 0xFFFFFFFFu;      // cnt[b]: block b is not reduced (more representatives than the kernel holds)
+struct RedArgs {
+	uint32_t const *cnt = nullptr;      // [block] representatives of the block
+	uint32_t const *vmin = nullptr;     // [block] the values >= vmin are those of the run on all rows (1: every value is)
+	uint32_t const *a = nullptr;        // [block][cap] start state: representative index (place among the block's representatives by row id) ...
+	uint32_t const *d = nullptr;        // [block][cap] ... and the maximum of d0 over the positions skipped since the last kept row
+	uint32_t const *leaf = nullptr;     // [block][cap] block-key rank of representative i (pass 2)
+	uint32_t const *blocks = nullptr;   // [workgroup] block of workgroup i of the launch
+	uint32_t *invalid = nullptr;        // [block] set when a list of the block took an entry the representatives cannot vouch for
+	uint32_t cap = 0;                   // row stride of a / d / leaf (and of cls / headd)
+	uint32_t m_true = 0;                // rows of the alignment
+	// pass 2: instead of lists, the class tables at the task columns of the block
+	uint32_t const *wg_tasks = nullptr; // [workgroup][2] {first task, tasks}
+	unsigned long long const *task_rb = nullptr;   // [task] column (ascending inside a workgroup)
+	uint32_t *cls = nullptr;            // [task][cap] class (rank among the distinct key prefixes) of every block key
+	uint32_t *headd = nullptr;          // [task][cap] divergence in front of every class
+	uint32_t *ncls = nullptr;           // [task]
+};
+
+// what k_reduce_prep reads and leaves (fseq_reduced.hpp)
+struct RedPrepArgs {
+	uint32_t const *bstate_a, *bstate_d;     // [blocks + 1][m]: the exact states in front of the blocks and behind the last
+	uint32_t const *rank;                    // [blocks][m]: block-key rank of every row (phase A)
+	uint32_t const *blocks;                  // [workgroup] block of workgroup i, or nullptr: block0 + i
+	uint32_t m, B, L, Xp, cap, block0, leaf_only;
+	uint64_t n;
+	uint32_t *cnt, *vmin, *rows, *leaf, *a, *d;
+};
+
 } // namespace fseq

@@ -26,7 +26,8 @@ extern "C" {
  *    fseq_step_max / fseq_current_step; the fseq_debug_* entry points moved to include/fseq_debug.h */
 /* 3: fseq_shard_abort */
 /* 4: fseq_timings grew (phase_a_trie_given_up: 120 -> 128 bytes): a host that calls fseq_get_timings must be rebuilt */
-#define FSEQ_ABI_VERSION 4
+/* 5: fseq_timings grew (reduced_blocks, reduced_rows_mean, reduced_redone: 128 -> 136 bytes) */
+#define FSEQ_ABI_VERSION 5
 
 enum {
 	FSEQ_OK             = 0,
@@ -103,6 +104,9 @@ typedef struct fseq_timings {
 	uint32_t phase_a_fallbacks;     /* blocks in which a merge of the key-space tree exceeded the LDS bitmap and ran in slices */
 	uint32_t phase_a_given_up;      /* blocks the key-space tree handed to the column sweep (their merges would have sliced past the budget) */
 	uint32_t phase_a_trie_given_up; /* streamed rows: blocks the trie over 16-column words handed to the key-space tree (too many distinct keys) */
+	uint32_t reduced_blocks;        /* [ABI 5] blocks whose column updates ran on their representative rows (0: every block on all rows) */
+	uint32_t reduced_rows_mean;     /* ... representatives per such block, mean                                  */
+	uint32_t reduced_redone;        /* ... blocks run again on all rows because a list could not be proven on the representatives */
 } fseq_timings;
 
 uint32_t    fseq_abi_version(void);
