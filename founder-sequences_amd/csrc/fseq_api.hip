@@ -67,14 +67,14 @@ struct Launch {
 	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
 	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
 	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask)
+	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask, uint32_t const *blocklist)
 	{
 		if (colmask)
 			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, true>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, colmask);
+			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, colmask, blocklist);
 		else
 			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, false>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, (uint32_t const *) nullptr);
+			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, (uint32_t const *) nullptr, blocklist);
 	}
 	static uint32_t columns_resident(size_t lds)
 	{
@@ -245,7 +245,11 @@ bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_
 }
 
 constexpr size_t LDS_LIMIT = 160 * 1024;
-constexpr uint64_t STREAM_BLOCK_TARGET = 1600;   // columns per block the streamed regime aims for (prepare_geometry / block_geometry)
+constexpr uint64_t STREAM_BLOCK_TARGET_ALL_ROWS = 1600;   // columns per block the streamed regime aims for (prepare_geometry / block_geometry) ...
+// [r5] ... and when phase C runs on the blocks' representatives: a block of ~800 columns of BASELINE C4 has ~6,600 of them, and
+// the ~10,700 of a block in which the founders recombine still fit the largest configuration (11,264)
+constexpr uint64_t STREAM_BLOCK_TARGET_REDUCED = 800;
+#define STREAM_BLOCK_TARGET ((c->tune.no_reduced || c->sh.on) ? STREAM_BLOCK_TARGET_ALL_ROWS : (c->tune.stream_block ? (uint64_t) c->tune.stream_block : STREAM_BLOCK_TARGET_REDUCED))
 #ifndef FSEQ_X_FLOOR_VALUE
 #define FSEQ_X_FLOOR_VALUE 63u
 #endif
@@ -271,9 +275,12 @@ struct LaunchS2 {
 			                   snap_stride, ss_a, ss_d, 0u, (uint32_t *) nullptr, 0u, 0u, SN);
 	}
 	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
-	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch, uint32_t ss_pack)
+	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch, uint32_t ss_pack,
+	                   uint32_t const *blocklist)
 	{
-		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack, S2SnapArgs{});
+		S2SnapArgs SN{};
+		SN.wg_block = blocklist;
+		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack, SN);
 	}
 	static uint32_t resident(size_t bytes)
 	{
@@ -488,6 +495,7 @@ int prepare_geometry(fseq_ctx *c)
 		HIP_TRY(c, allow_lds(k_chain_stream<false>, stream_lds_bytes(0, true)));
 		HIP_TRY(c, allow_lds(k_chain_stream<true>, stream_lds_bytes(0, true)));
 		HIP_TRY(c, allow_lds(k_chain_stream_sort, chainsort_lds_bytes()));
+		HIP_TRY(c, allow_lds(k_chain_snap_stream, chainsort_lds_bytes()));
 		HIP_TRY(c, allow_lds(k_cm_emit, stream_lds_bytes(0, false)));
 		// phase C in its second form (fseq_stream2.hpp) while every value id (< m + B) fits the key shift of its tile
 		// (FSEQ_STREAM2=T,E[,0] picks another configuration [8-byte rows], FSEQ_STREAM2=0 and FSEQ_STREAM_PLAIN_SCAN keep the first form)
@@ -786,7 +794,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
 	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
-	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows); dev_free(c, &c->d_red_leaf); dev_free(c, &c->d_red_a); dev_free(c, &c->d_red_d);
+	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows); dev_free(c, &c->d_red_leaf); dev_free(c, &c->d_red_a); dev_free(c, &c->d_red_d);
 	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa); c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
 	dev_free(c, &c->d_red_cls); dev_free(c, &c->d_red_headd); dev_free(c, &c->d_red_ncls); dev_free(c, &c->d_red_taskblk); dev_free(c, &c->d_red_wgtasks); c->red_task_cap = 0;
 	c->red_active = false;
@@ -868,7 +876,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
 	return FSEQ_OK;
 }
 
@@ -909,7 +917,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
 	return FSEQ_OK;
 }
 
@@ -1960,12 +1968,36 @@ int long_traceback_and_merge(fseq_ctx *c, LongRun &R, double th0, bool *overflow
 // rows: more representatives than any configuration holds (or than pay: > 70 % of the rows), or lists an earlier run on this
 // input could not prove on the representatives.  *use: false when more than a quarter of the blocks would run on all rows
 // anyway -- the attempt then takes the run on all rows with its stride states (diverse inputs).
-bool columns_fit_reduced(fseq_ctx const *c, ReducedSet const &rs)
+// bytes of each staged-column buffer of a reduced configuration
+uint32_t red_symcap(fseq_ctx const *c, ReducedSet const &rs, bool direct)
 {
-	// (value ids of a block -- its boundary values and one per column -- are 16-bit keys of the partition step)
-	return rs.lds(c->B) <= LDS_LIMIT && (uint64_t) rs.rows + c->B + 1u <= 65535u;
+	uint32_t const bytes = direct ? sym_bytes(c->p.m, c->bsh) : sym_bytes(rs.rows, c->bsh);
+	(void) rs;
+	return (bytes + 1023u) & ~1023u;                           // whole kilobytes: a wave stages sixteen bytes per lane
 }
 
+bool columns_fit_reduced(fseq_ctx const *c, ReducedSet const &rs, bool direct)
+{
+	// (value ids of a block -- its boundary values and one per column -- are 16-bit keys of the partition step)
+	return rs.lds(c->B, red_symcap(c, rs, direct)) <= LDS_LIMIT && (uint64_t) rs.rows + c->B + 1u <= 65535u;
+}
+
+void red_fill_args(fseq_ctx *c, RedArgs &RA)
+{
+	RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf;
+	RA.invalid = c->d_red_invalid; RA.any_invalid = c->d_red_invalid + c->nblocks; RA.cap = c->red_cap; RA.m_true = c->p.m;
+	RA.direct = c->red_direct ? 1u : 0u; RA.colbytes = sym_bytes(c->p.m, c->bsh); RA.rank = c->d_rank;
+}
+
+// ---- [r5] phase C on representative rows (fseq_reduced.hpp): the plan of one attempt.
+// k_reduce_prep leaves, per block, the representatives and the reduced start state.  The blocks are sorted into the
+// configurations that hold them (a launch per configuration in use, side by side on their own streams) and the blocks
+// that run on all rows: more representatives than any configuration holds (or than pay: > 70 % of the rows), or lists an
+// earlier run on this input could not prove on the representatives.  The first run on an input (or at a new capacity) reads
+// the counts back and plans; later runs launch by the same plan without waiting and have the device check that the counts
+// are the ones the plan was made from (flags word 1; the attempt is repeated with a fresh plan if not).
+// *use: false when more than a quarter of the blocks would run on all rows anyway -- the attempt then takes the run on
+// all rows with its stride states (diverse inputs).
 int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 {
 	FSEQ_LONG_LOCALS(c);
@@ -1976,14 +2008,16 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (!c->d_red_cnt || c->red_cap != cap)
 	{
 		if ((rc = dev_alloc(c, &c->d_red_cnt, nbk))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_cnt_plan, nbk))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_vmin, nbk))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_invalid, nbk + 1))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_blocks, 2 * (size_t) nbk))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_invalid, nbk + 2))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_blocks, 3 * (size_t) nbk))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_rows, (size_t) nbk * cap))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_leaf, (size_t) nbk * cap))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_a, (size_t) nbk * cap))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_d, (size_t) nbk * cap))) return rc;
 		c->red_cap = cap;
+		c->red_plan_valid = false;
 	}
 	if (c->red_pin_words < 4 * (size_t) nbk + 64)
 	{
@@ -1992,15 +2026,31 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_red_pin), (4 * (size_t) nbk + 64) * 4, hipHostMallocDefault));
 		c->red_pin_words = 4 * (size_t) nbk + 64;
 	}
+	if (!c->red_st[0])
+	{
+		for (auto &strm : c->red_st) HIP_TRY(c, hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));
+		for (auto &evt : c->red_ev) HIP_TRY(c, hipEventCreateWithFlags(&evt, hipEventDisableTiming));
+	}
+	// LDS-resident row counts: the representatives' symbols come from the alignment's own columns (a block stages whole columns)
+	c->red_direct = !c->use_stream;
 	RedPrepArgs A{};
 	A.bstate_a = c->d_bstate_a; A.bstate_d = c->d_bstate_d; A.rank = c->d_rank; A.blocks = nullptr;
-	A.m = m; A.B = c->B; A.L = (uint32_t) L; A.cap = cap; A.block0 = 0; A.leaf_only = 0; A.n = n;
+	A.m = m; A.B = c->B; A.L = (uint32_t) L; A.cap = cap; A.block0 = 0; A.leaf_only = 0; A.n = n; A.direct = c->red_direct ? 1u : 0u;
 	A.Xp = X + (c->tune.reduced_margin >= 0 ? (uint32_t) c->tune.reduced_margin : X / 4u + 8u);
 	A.cnt = c->d_red_cnt; A.vmin = c->d_red_vmin; A.rows = c->d_red_rows; A.leaf = c->d_red_leaf; A.a = c->d_red_a; A.d = c->d_red_d;
+	A.invalid = c->d_red_invalid; A.flags = c->d_red_invalid + nbk;
 	HIP_TRY(c, launch_reduce_prep(st, nbk, A));
+	if (c->red_plan_valid && c->red_plan_X == X && c->red_force_full.size() == nbk)
+	{
+		launch_reduce_check(st, c->d_red_cnt, c->d_red_cnt_plan, nbk, c->d_red_invalid + nbk);
+		if (!c->red_direct)
+			launch_reduce_msa(st, c->red_listed, c->red_max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+		*use = true;
+		return FSEQ_OK;
+	}
 	uint32_t *const h_cnt = c->h_red_pin;
 	HIP_TRY(c, hipMemcpyAsync(h_cnt, c->d_red_cnt, (size_t) nbk * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipMemsetAsync(c->d_red_invalid, 0, ((size_t) nbk + 1) * 4, st));
+	HIP_TRY(c, hipMemcpyAsync(c->d_red_cnt_plan, c->d_red_cnt, (size_t) nbk * 4, hipMemcpyDeviceToDevice, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	c->red_cnt_host.assign(h_cnt, h_cnt + nbk);
 	if (c->red_force_full.size() != nbk) c->red_force_full.assign(nbk, 0);
@@ -2008,7 +2058,14 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	c->red_config_of.assign(nbk, -1);
 	int const nconf = reduced_config_count();
 	std::vector<ReducedSet> sets((size_t) nconf);
-	for (int i = 0; i < nconf; ++i) (void) reduced_config(i, &sets[(size_t) i]);
+	std::vector<uint8_t> usable((size_t) nconf);
+	for (int i = 0; i < nconf; ++i)
+	{
+		(void) reduced_config(i, &sets[(size_t) i]);
+		ReducedSet const &rs = sets[(size_t) i];
+		// (one-wave workgroups, or two with the list on a wave of its own: FSEQ_REDUCED_EW picks the latter)
+		usable[(size_t) i] = columns_fit_reduced(c, rs, c->red_direct) && (rs.T > 128u || rs.ew == c->tune.reduced_ew);
+	}
 	std::vector<std::vector<uint32_t>> per((size_t) nconf);
 	uint32_t n_full = 0, max_rows = 0, listed = 0;
 	uint64_t sum_rows = 0;
@@ -2021,7 +2078,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 			h_blocks[listed++] = b;
 			max_rows = std::max(max_rows, r);
 			int cf = -1;
-			for (int i = 0; i < nconf; ++i) if (sets[(size_t) i].rows >= r && columns_fit_reduced(c, sets[(size_t) i])) { cf = i; break; }
+			for (int i = 0; i < nconf; ++i) if (usable[(size_t) i] && sets[(size_t) i].rows >= r) { cf = i; break; }
 			c->red_config_of[b] = cf;
 		}
 		bool const full = r == RED_NONE || c->red_config_of[b] < 0 || c->red_force_full[b] || (uint64_t) r * 10u > (uint64_t) m * 7u;
@@ -2035,15 +2092,14 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", nbk - n_full, nbk,
 		        c->tm.reduced_rows_mean, m, max_rows, n_full);
 	if ((uint64_t) n_full * 4u > nbk) return FSEQ_OK;
-	// the reduced alignment: column k at d_red_msa + k * red_ld
+	if (n_full && c->use_stream && !c->s2.T) return FSEQ_OK;     // (the first form of the streamed kernel takes no block list)
+	if (!c->red_direct)
 	{
+		// the reduced alignment: column k at d_red_msa + k * red_ld
 		size_t const ldr = ((size_t) sym_bytes(max_rows ? max_rows : 1u, c->bsh) + 15) & ~size_t(15);
 		size_t const need = (size_t) n * ldr + 64;
-		if (c->red_msa_bytes < need || c->red_ld != ldr)
-		{
-			if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa, need))) return rc; c->red_msa_bytes = need; }
-			c->red_ld = ldr;
-		}
+		if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa, need))) return rc; c->red_msa_bytes = need; }
+		c->red_ld = ldr;
 	}
 	c->red_bins.clear();
 	uint32_t at = listed;
@@ -2055,29 +2111,57 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		c->red_bins.push_back(fseq_ctx::RedBin{i, at, (uint32_t) v.size()});
 		at += (uint32_t) v.size();
 	}
+	c->red_full_at = at; c->red_nfull = 0;
+	for (uint32_t b = 0; b < nbk; ++b) if (c->red_full[b]) h_blocks[at + c->red_nfull++] = b;
+	at += c->red_nfull;
 	HIP_TRY(c, hipMemcpyAsync(c->d_red_blocks, h_blocks, (size_t) at * 4, hipMemcpyHostToDevice, st));
-	launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+	if (!c->red_direct)
+		launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+	c->red_plan_valid = true; c->red_plan_X = X;
 	*use = true;
 	return FSEQ_OK;
 }
 
-// the lists of the reduced blocks, configuration by configuration
-int red_columns(fseq_ctx *c)
+// launches of the reduced column kernel over lists of workgroups, one per configuration, side by side: the first on the
+// context's stream, the others on streams of their own that wait for it and that it waits for
+struct RedLaunch { int config; uint32_t first, count; };
+int red_launch_all(fseq_ctx *c, std::vector<RedLaunch> const &ls, RedArgs const &base, uint32_t const *blocks, uint32_t const *wg_tasks, uint2 *ent, uint4 *hdr, uint32_t X, uint32_t stride)
 {
 	FSEQ_LONG_LOCALS(c);
-	for (auto const &bin : c->red_bins)
+	if (ls.empty()) return FSEQ_OK;
+	size_t const nside = std::min<size_t>(ls.size() - 1, 3);
+	if (nside) HIP_TRY(c, hipEventRecord(c->red_ev[3], st));
+	for (size_t i = 0; i < ls.size(); ++i)
 	{
 		ReducedSet rs;
-		(void) reduced_config(bin.config, &rs);
-		size_t const lds = rs.lds(c->B);
+		(void) reduced_config(ls[i].config, &rs);
+		RedArgs RA = base;
+		RA.symcap = red_symcap(c, rs, c->red_direct);
+		size_t const lds = rs.lds(c->B, RA.symcap);
 		HIP_TRY(c, rs.prepare(lds));
-		RedArgs RA;
-		RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf; RA.blocks = c->d_red_blocks + bin.first;
-		RA.invalid = c->d_red_invalid; RA.cap = c->red_cap; RA.m_true = m;
-		rs.launch(st, bin.count, lds, c->d_red_msa, c->red_ld, n, c->B, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh, RA);
+		RA.blocks = blocks + ls[i].first;
+		if (wg_tasks) RA.wg_tasks = wg_tasks + 2 * (size_t) ls[i].first;
+		// the largest launches on the side streams, the rest in turn on the context's
+		hipStream_t const s_ = (i >= 1 && i <= nside) ? c->red_st[i - 1] : st;
+		if (s_ != st) HIP_TRY(c, hipStreamWaitEvent(s_, c->red_ev[3], 0));
+		rs.launch(s_, ls[i].count, lds, c->red_direct ? c->d_msa : c->d_red_msa, c->red_direct ? c->ld : c->red_ld, n, c->B, (uint32_t) L, X, stride, ent, hdr, c->npass, c->bsh, RA);
+		if (s_ != st) HIP_TRY(c, hipEventRecord(c->red_ev[i - 1], s_));
 	}
+	for (size_t i = 0; i < nside; ++i) HIP_TRY(c, hipStreamWaitEvent(st, c->red_ev[i], 0));
 	HIP_TRY(c, hipGetLastError());
 	return FSEQ_OK;
+}
+
+// the lists of the reduced blocks
+int red_columns(fseq_ctx *c)
+{
+	RedArgs RA;
+	red_fill_args(c, RA);
+	std::vector<RedLaunch> ls;
+	for (auto const &bin : c->red_bins) ls.push_back(RedLaunch{bin.config, bin.first, bin.count});
+	// (the configuration with the most blocks first: it stays on the context's stream)
+	std::stable_sort(ls.begin(), ls.end(), [](RedLaunch const &x, RedLaunch const &y) { return x.count > y.count; });
+	return red_launch_all(c, ls, RA, c->d_red_blocks, nullptr, c->d_ent, c->d_hdr, c->X, c->stride);
 }
 
 int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
@@ -2088,7 +2172,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	bool const keyspace = R.keyspace;
 	// [r5] phase C on representative rows: the default wherever the lists are consumed by the speculative DP behind phase C
 	// (not sharded yet: a rank's halo block has no state behind it to take the classes from)
-	bool const red_candidate = !sharded && !c->use_stream && !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
+	bool const red_candidate = !sharded && !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
 	if ((rc = ensure_work_buffers(c, X, !red_candidate))) return rc;
 	// ---- phase C + D
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
@@ -2139,15 +2223,16 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[3], st));
 	FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
-	auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0) {
+	// (list [r5]: workgroup i owns block list[i] instead of b0 + i -- the blocks the reduced phase C hands to the run on all rows)
+	auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0, uint32_t const *list = nullptr) {
 		if (c->use_stream && c->s2.T)
 		{
 			uint32_t pack_abits = 0;
 			if (c->s2.pack) { pack_abits = 1; while ((1u << pack_abits) < m) ++pack_abits; }
 			hipLaunchKernelGGL(k_columns_stream2_prologue, dim3(nb), dim3(ST), stream_lds_bytes(0, true), st, m, n_c, c->B, c->d_ws_c, c->d_bstate_a, c->d_bstate_d, b0, pack_abits,
-			                   c->ss_ids ? c->d_bs_w : (uint32_t *) nullptr, c->ss_ids ? c->d_bs_h : (uint8_t *) nullptr);
+			                   c->ss_ids ? c->d_bs_w : (uint32_t *) nullptr, c->ss_ids ? c->d_bs_h : (uint8_t *) nullptr, list);
 			c->s2.launch(st, nb, c->s2_lds, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr,
-			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack | (c->ss_ids ? S2_SS_IDS : 0u));
+			             c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack | (c->ss_ids ? S2_SS_IDS : 0u), list);
 		}
 		else if (c->use_stream && (uint64_t) m + c->B < (1u << 19) && !c->tune.stream_plain_scan)
 			hipLaunchKernelGGL(k_columns_stream<19>, dim3(nb), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n_c, c->B, c->npass, c->bsh, c->d_ws_c, (uint32_t) c->stream_staged,
@@ -2157,7 +2242,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			                   c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->ss_pack);
 		else
 			ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
-			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->colmask_ready && c->colmask_use ? c->d_colmask : (uint32_t const *) nullptr);
+			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->colmask_ready && c->colmask_use ? c->d_colmask : (uint32_t const *) nullptr, list);
 	};
 	// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
 	// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
@@ -2229,15 +2314,8 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			{
 				c->red_active = true;
 				if ((rc = red_columns(c))) return rc;
-				// the blocks that run on all rows (no stride states: pass 2 reaches their boundaries from the block's start)
-				for (uint32_t b = 0; b < c->nblocks;)
-				{
-					if (!c->red_full[b]) { ++b; continue; }
-					uint32_t e = b;
-					while (e < c->nblocks && c->red_full[e]) ++e;
-					launch_columns(b, e - b);
-					b = e;
-				}
+				// the blocks that run on all rows, in one launch (no stride states: pass 2 reaches their boundaries from the block's start)
+				if (c->red_nfull) launch_columns(0, c->red_nfull, nullptr, 0, c->d_red_blocks + c->red_full_at);
 			}
 			else if ((rc = ensure_work_buffers(c, X, true))) return rc;      // (the stride states after all)
 		}
@@ -2301,29 +2379,32 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	HIP_TRY(c, hipGetLastError());
 
 	if ((rc = pin_reserve(c, 64))) return rc;
-	uint32_t *const h_flags = pin_take<uint32_t>(c, 8);
+	uint32_t *const h_flags = pin_take<uint32_t>(c, 12);
 	h_flags[4] = 0;
 	HIP_TRY(c, hipMemcpyAsync(h_flags, c->d_flags, 16, hipMemcpyDeviceToHost, st));
 	h_flags[5] = 0;
 	h_flags[6] = 0;
 	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 12, hipMemcpyDeviceToHost, st));
-	h_flags[7] = 0;
-	if (c->red_active)
-	{
-		// any block whose lists could not be proven on its representatives?  (one word; the per-block flags only then)
-		hipLaunchKernelGGL(k_any_nonzero, dim3(1), dim3(256), 0, st, c->d_red_invalid, c->nblocks, c->d_red_invalid + c->nblocks);
-		HIP_TRY(c, hipMemcpyAsync(h_flags + 7, c->d_red_invalid + c->nblocks, 4, hipMemcpyDeviceToHost, st));
-	}
+	h_flags[6 + 1] = 0; h_flags[6 + 2] = 0;
+	uint32_t *const h_red = h_flags + 7;                         // {a block's lists not proven, the plan's counts have changed}
+	if (c->red_active) HIP_TRY(c, hipMemcpyAsync(h_red, c->d_red_invalid + c->nblocks, 8, hipMemcpyDeviceToHost, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
 	R.redo = false;
-	if (c->red_active && h_flags[7])
+	if (c->red_active && h_red[1])
+	{
+		// (the counts are not what the plan was made from: plan afresh)
+		c->red_plan_valid = false;
+		R.redo = true; *overflow_out = false;
+		return FSEQ_OK;
+	}
+	if (c->red_active && h_red[0])
 	{
 		std::vector<uint32_t> inv(c->nblocks);
 		HIP_TRY(c, hipMemcpy(inv.data(), c->d_red_invalid, (size_t) c->nblocks * 4, hipMemcpyDeviceToHost));
 		uint32_t cnt = 0;
 		for (uint32_t b = 0; b < c->nblocks; ++b) if (inv[b] && !c->red_full[b]) { c->red_force_full[b] = 1; ++cnt; }
 		if (c->tune.debug) fprintf(stderr, "[fseq] reduced phase C: the lists of %u blocks reach below what their representatives vouch for: those blocks again on all rows\n", cnt);
-		if (cnt) { R.redo = true; R.redone += cnt; *overflow_out = false; return FSEQ_OK; }
+		if (cnt) { c->red_plan_valid = false; R.redo = true; R.redone += cnt; *overflow_out = false; return FSEQ_OK; }
 	}
 	if (keyspace)
 	{
@@ -2399,9 +2480,12 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 	FSEQ_LONG_LOCALS(c);
 	size_t const S2 = c->segments.size();
 	if (!S2) return FSEQ_OK;
-	ChainSnapSet cs;
-	if (!select_chain_snap(ks.T, ks.E, &cs)) return fail(c, FSEQ_E_UNSUPPORTED, "pass 2: no chain step for this configuration");
-	HIP_TRY(c, cs.prepare());
+	ChainSnapSet cs{};
+	if (!c->use_stream)
+	{
+		if (!select_chain_snap(ks.T, ks.E, &cs)) return fail(c, FSEQ_E_UNSUPPORTED, "pass 2: no chain step for this configuration");
+		HIP_TRY(c, cs.prepare());
+	}
 	c->snap_slot.assign(S2, -1);
 	std::vector<uint64_t> rbs(S2);
 	std::vector<uint32_t> task_blk(S2), ncls0(S2);
@@ -2453,51 +2537,68 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		c->red_task_cap = S2;
 	}
 	if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
-	// (pageable sources: the runtime stages them before the call returns)
-	HIP_TRY(c, hipMemcpyAsync(c->d_cols, rbs.data(), S2 * 8, hipMemcpyHostToDevice, st));
-	HIP_TRY(c, hipMemcpyAsync(c->d_red_taskblk, task_blk.data(), S2 * 4, hipMemcpyHostToDevice, st));
-	HIP_TRY(c, hipMemcpyAsync(c->d_red_ncls, ncls0.data(), S2 * 4, hipMemcpyHostToDevice, st));
+	// the task lists through pinned memory of their own (live until the synchronisation behind the kernels)
+	std::vector<uint32_t> hb, hw;
+	std::vector<RedLaunch> ls;
+	for (size_t cf = 0; cf < wgs.size(); ++cf)
+	{
+		if (wgs[cf].empty()) continue;
+		ls.push_back(RedLaunch{(int) cf, (uint32_t) hb.size(), (uint32_t) wgs[cf].size()});
+		for (auto const &w : wgs[cf])
+		{
+			hb.push_back(w.blk); hw.push_back(w.first); hw.push_back(w.count);
+			cells += (rbs[w.first + w.count - 1u] - (uint64_t) w.blk * c->B) * c->red_cnt_host[w.blk];
+		}
+	}
+	{
+		size_t const need = S2 * 16 + hb.size() * 12 + 256;
+		if (c->red_pin2_bytes < need)
+		{
+			if (c->h_red_pin2) (void) hipHostFree(c->h_red_pin2);
+			c->h_red_pin2 = nullptr; c->red_pin2_bytes = 0;
+			HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_red_pin2), need * 2, hipHostMallocDefault));
+			c->red_pin2_bytes = need * 2;
+		}
+		uint8_t *pp = c->h_red_pin2;
+		auto put = [&](void const *src, size_t bytes) { void *at = pp; memcpy(pp, src, bytes); pp += (bytes + 15) & ~size_t(15); return at; };
+		HIP_TRY(c, hipMemcpyAsync(c->d_cols, put(rbs.data(), S2 * 8), S2 * 8, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(c->d_red_taskblk, put(task_blk.data(), S2 * 4), S2 * 4, hipMemcpyHostToDevice, st));
+		HIP_TRY(c, hipMemcpyAsync(c->d_red_ncls, put(ncls0.data(), S2 * 4), S2 * 4, hipMemcpyHostToDevice, st));
+		if (!hb.empty())
+		{
+			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks + 2 * S2, put(hb.data(), hb.size() * 4), hb.size() * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks, put(hw.data(), hw.size() * 4), hw.size() * 4, hipMemcpyHostToDevice, st));
+		}
+	}
 	HIP_TRY(c, hipEventRecord(c->ev[6], st));
 	progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
 	FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
-	// the class tables, configuration by configuration
+	// the class tables at the task columns, configuration by configuration
+	if (!ls.empty())
 	{
-		std::vector<uint32_t> hb, hw;
-		struct Launch_ { int cf; uint32_t first, count; };
-		std::vector<Launch_> ls;
-		for (size_t cf = 0; cf < wgs.size(); ++cf)
-		{
-			if (wgs[cf].empty()) continue;
-			ls.push_back(Launch_{(int) cf, (uint32_t) hb.size(), (uint32_t) wgs[cf].size()});
-			for (auto const &w : wgs[cf])
-			{
-				hb.push_back(w.blk); hw.push_back(w.first); hw.push_back(w.count);
-				cells += (rbs[w.first + w.count - 1u] - (uint64_t) w.blk * c->B) * c->red_cnt_host[w.blk];
-			}
-		}
-		if (!hb.empty())
-		{
-			uint32_t *const d_wb = c->d_red_wgtasks + 2 * S2;       // [workgroup] block, behind the {first, count} pairs
-			HIP_TRY(c, hipMemcpyAsync(d_wb, hb.data(), hb.size() * 4, hipMemcpyHostToDevice, st));
-			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, st));
-			for (auto const &l : ls)
-			{
-				ReducedSet rs;
-				(void) reduced_config(l.cf, &rs);
-				size_t const lds = rs.lds(c->B);
-				HIP_TRY(c, rs.prepare(lds));
-				RedArgs RA;
-				RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf; RA.blocks = d_wb + l.first;
-				RA.invalid = c->d_red_invalid; RA.cap = c->red_cap; RA.m_true = m;
-				RA.wg_tasks = c->d_red_wgtasks + 2 * (size_t) l.first; RA.task_rb = reinterpret_cast<unsigned long long const *>(c->d_cols);
-				RA.cls = c->d_red_cls; RA.headd = c->d_red_headd; RA.ncls = c->d_red_ncls;
-				rs.launch(st, l.count, lds, c->d_red_msa, c->red_ld, n, c->B, (uint32_t) L, 0u, 0u, (uint2 *) nullptr, (uint4 *) nullptr, c->npass, c->bsh, RA);
-			}
-		}
+		RedArgs RA;
+		red_fill_args(c, RA);
+		RA.task_rb = reinterpret_cast<unsigned long long const *>(c->d_cols);
+		RA.cls = c->d_red_cls; RA.headd = c->d_red_headd; RA.ncls = c->d_red_ncls;
+		std::stable_sort(ls.begin(), ls.end(), [](RedLaunch const &x, RedLaunch const &y) { return x.count > y.count; });
+		if ((rc = red_launch_all(c, ls, RA, c->d_red_wgtasks + 2 * S2, c->d_red_wgtasks, (uint2 *) nullptr, (uint4 *) nullptr, 0u, 0u))) return rc;
 	}
 	// one chain step per boundary (a copy for the borders)
-	cs.launch(st, (uint32_t) S2, cs.lds, c->d_bstate_a, c->d_bstate_d, c->d_rank, m, c->d_red_taskblk, c->d_red_cls, c->d_red_headd, c->d_red_ncls, c->red_cap,
-	          c->d_snap_a, c->d_snap_d, scan_keyed(c));
+	if (!c->use_stream)
+		cs.launch(st, (uint32_t) S2, cs.lds, c->d_bstate_a, c->d_bstate_d, c->d_rank, m, c->d_red_taskblk, c->d_red_cls, c->d_red_headd, c->d_red_ncls, c->red_cap,
+		          c->d_snap_a, c->d_snap_d, scan_keyed(c));
+	else
+	{
+		// streamed rows: the step as a radix sort + range maxima in a workspace per workgroup (fseq_chainsort.hpp), the workgroups
+		// take the tasks in turn
+		int ncu = 0;
+		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
+		size_t const fit = c->ws_words / chainsort_ws_words(m);
+		uint32_t const grid = (uint32_t) std::min<size_t>(std::min<size_t>(S2, fit), (size_t) std::max(ncu, 1) * 2u);
+		if (!grid) return fail(c, FSEQ_E_OOM, "pass 2: the workspace holds no chain step");
+		hipLaunchKernelGGL(k_chain_snap_stream, dim3(grid), dim3(ST), chainsort_lds_bytes(), st, c->d_bstate_a, c->d_bstate_d, c->d_rank, m, c->d_red_taskblk, c->d_red_cls,
+		                   c->d_red_headd, c->d_red_ncls, c->red_cap, (uint32_t) S2, c->d_snap_a, c->d_snap_d, c->d_ws);
+	}
 	for (size_t i = 0; i < S2; ++i)
 		if (ncls0[i] == 0u && rbs[i] % c->B != 0) cells += (uint64_t) m * 4u;      // (a step is ~4 digit passes over the rows)
 	// the boundaries of blocks without representatives: their columns on all rows from the block's start
@@ -2514,8 +2615,21 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		HIP_TRY(c, hipMemcpyAsync(d_orb, o_rbs.data(), So * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(d_osrc, o_srcs.data(), o_srcs.size() * 8, hipMemcpyHostToDevice, st));
 		HIP_TRY(c, hipMemcpyAsync(d_ogrp, o_grp.data(), o_grp.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
-		ks.snap(st, (uint32_t) o_grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, d_orb, d_ogrp,
-		        tmp_a, tmp_d, d_osrc, c->snap_stride, (uint32_t const *) nullptr, (uint32_t const *) nullptr, scan_keyed(c));
+		if (!c->use_stream)
+			ks.snap(st, (uint32_t) o_grp.size(), ks.lds_snap, c->d_msa, c->ld, m, n, c->B, c->nblocks, c->npass, c->bsh, c->d_bstate_a, c->d_bstate_d, d_orb, d_ogrp,
+			        tmp_a, tmp_d, d_osrc, c->snap_stride, (uint32_t const *) nullptr, (uint32_t const *) nullptr, scan_keyed(c));
+		else
+		{
+			// (the streamed sweep needs 4m workspace words per workgroup: as many groups per launch as d_ws holds)
+			size_t const capg = std::max<size_t>(1, c->ws_words / (4 * (size_t) m));
+			for (size_t g0 = 0; g0 < o_grp.size(); g0 += capg)
+			{
+				size_t const cntg = std::min(capg, o_grp.size() - g0);
+				hipLaunchKernelGGL((stream_keyed(c) ? k_colblock_stream<MODE_SNAP, true> : k_colblock_stream<MODE_SNAP, false>), dim3((uint32_t) cntg), dim3(ST), stream_lds_bytes(sym_bytes(m, c->bsh), c->stream_staged), st, c->d_msa, c->ld, m, n, c->B,
+				                   c->nblocks, c->npass, c->bsh, c->d_ws, (uint32_t) c->stream_staged, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, c->d_bstate_a, c->d_bstate_d,
+				                   d_orb, d_ogrp + g0, tmp_a, tmp_d, d_osrc + g0, c->snap_stride, (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t) 0, 0u);
+			}
+		}
 		for (size_t j = 0; j < So; ++j)
 		{
 			HIP_TRY(c, hipMemcpyAsync(c->d_snap_a + (size_t) o_slot[j] * m, tmp_a + j * (size_t) m, (size_t) m * 4, hipMemcpyDeviceToDevice, st));
@@ -2540,7 +2654,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 int long_pass2(fseq_ctx *c, LongRun &R)
 {
 	FSEQ_LONG_LOCALS(c);
-	if (c->red_active && !c->use_stream) return long_pass2_reduced(c, R);
+	if (c->red_active) return long_pass2_reduced(c, R);
 	uint64_t &pass2_cells = R.pass2_cells;
 	double &ms_p2 = R.ms_p2;
 	size_t const S2 = c->segments.size();
@@ -2889,6 +3003,9 @@ void fseq_destroy(fseq_ctx *c)
 	for (auto &e : c->ev_dp) if (e) (void) hipEventDestroy(e);
 	if (c->h_pin) (void) hipHostFree(c->h_pin);
 	if (c->h_red_pin) (void) hipHostFree(c->h_red_pin);
+	if (c->h_red_pin2) (void) hipHostFree(c->h_red_pin2);
+	for (auto &s_ : c->red_st) if (s_) (void) hipStreamDestroy(s_);
+	for (auto &e_ : c->red_ev) if (e_) (void) hipEventDestroy(e_);
 	if (c->h_done) (void) hipHostFree(c->h_done);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -2968,7 +3085,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -2992,7 +3109,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -3096,7 +3213,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
 	return FSEQ_OK;
 }
 
@@ -3154,7 +3271,7 @@ int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
 	c->have_result = false;
 	c->kernels_ready = false;
 	// (what the last run saw belongs to the old geometry: a block the tree or the trie ranked then may be given up now)
-	c->bk_given_up = -1; c->bt_given_up = -1; c->red_force_full.clear();
+	c->bk_given_up = -1; c->bt_given_up = -1; c->red_force_full.clear(); c->red_plan_valid = false;
 	return FSEQ_OK;
 }
 

@@ -64,9 +64,11 @@ __device__ __forceinline__ uint32_t cs_below(uint64_t mask)
 
 // One step: (a0, d0) -> (a1, d1) through the key block (rk, kd, nkeys).  w: the workgroup's workspace with a0 d0 at
 // w + off0 .. and a1 d1 at w + off1 .. (each 2m words, off in {0, 2m}); ends with a barrier.
+// cls (pass 2 behind the reduced phase C, k_chain_snap_stream): the key of a row is cls[rk[row]] -- the class of its block
+// key at the boundary's column -- instead of rk[row]
 __device__ __forceinline__ void chain_step_sorted(
 	uint32_t m, uint32_t const *__restrict__ rk, uint32_t const *__restrict__ kd, uint32_t nkeys,
-	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L)
+	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L, uint32_t const *__restrict__ cls = nullptr)
 {
 	uint32_t const tid = threadIdx.x, lane = lane_id();
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -94,7 +96,7 @@ __device__ __forceinline__ void chain_step_sorted(
 		uint2 *dst = ((npass - p) & 1u) ? pairB : pairA;
 		auto load = [&](uint32_t i) -> uint2 {
 			// first pass: the pairs are made on the way (rank of the row at position i, i)
-			return first ? make_uint2(rk[a0[i]], i) : src[i];
+			return first ? make_uint2(cls ? cls[rk[a0[i]]] : rk[a0[i]], i) : src[i];
 		};
 		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] = 0;
 		// (a wave's histogram row is its own: no barrier between clearing and counting; LDS operations of a wave stay in order)
@@ -260,6 +262,41 @@ __global__ __launch_bounds__(ST) void k_chain_stream_sort(
 		for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) nb_total * m + i] = a[i]; out_state_d[(size_t) nb_total * m + i] = d[i]; }
 	if (out_rank)
 		stream_emit_ranks(m, a, d, kstart, out_rank + (size_t) grp * m, out_keyd + (size_t) grp * m, out_nkeys + grp, L);
+}
+
+// ------------------------------------------------------------------------------------------------
+// [r5] Pass 2 behind the reduced phase C, streamed rows (fseq_reduced.hpp): a boundary inside a block is ONE such step from
+// the block's boundary state, keyed by the classes the block's representatives form at the boundary's column (the tables of
+// k_columns_red).  Workgroups take the tasks in turn, each in its own workspace.  ncls[t] == 0: the boundary is the block's
+// border (a copy); 0xFFFFFFFF: not this kernel's.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(ST) void k_chain_snap_stream(
+	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t const *__restrict__ rank, uint32_t m,
+	uint32_t const *__restrict__ task_blk, uint32_t const *__restrict__ cls, uint32_t const *__restrict__ headd, uint32_t const *__restrict__ ncls,
+	uint32_t cap, uint32_t ntasks, uint32_t *__restrict__ snap_a, uint32_t *__restrict__ snap_d, uint32_t *ws)
+{
+	extern __shared__ __attribute__((aligned(16))) char smem[];
+	Carver cv{smem};
+	StreamLds &L = *cv.take<StreamLds>(1);
+	ChainSortLds &S = *cv.take<ChainSortLds>(1);
+	uint32_t const tid = threadIdx.x;
+	uint32_t *const w = ws + (size_t) blockIdx.x * chainsort_ws_words(m);
+	for (uint32_t task = blockIdx.x; task < ntasks; task += gridDim.x)
+	{
+		uint32_t const D = ncls[task];
+		if (D == 0xFFFFFFFFu) continue;
+		size_t const sb = (size_t) task_blk[task] * m, ob = (size_t) task * m;
+		if (D == 0u)
+		{
+			for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = bstate_a[sb + i]; snap_d[ob + i] = bstate_d[sb + i]; }
+			continue;
+		}
+		for (uint32_t i = tid; i < m; i += ST) { w[i] = bstate_a[sb + i]; w[(size_t) m + i] = bstate_d[sb + i]; }
+		__syncthreads();
+		chain_step_sorted(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap);
+		for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = w[2u * (size_t) m + i]; snap_d[ob + i] = w[3u * (size_t) m + i]; }
+		__syncthreads();
+	}
 }
 
 // ================================================================================================

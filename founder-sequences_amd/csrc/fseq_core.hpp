@@ -207,6 +207,15 @@ __device__ __forceinline__ void stream_touch(void const *g, uint32_t lds_addr)
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// Sixteen bytes per lane from `g` into LDS at lds_addr + 16 * lane (LDS-DMA; lds_addr wave-uniform).  The compiler does not
+// see the load: the caller waits for it (s_waitcnt vmcnt(0)) before the barrier in front of the first read of those bytes.
+__device__ __forceinline__ void lds_dma16(void const *g, uint32_t lds_addr)
+{
+	uint32_t keep;
+	asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
+}
+
 // -DFSEQ_KC_STAMPS: cycle stamps of a column step per wave (k_columns prints them)
 #ifdef FSEQ_KC_STAMPS
 struct KcStamps { long long acc[8]; long long last; };

@@ -35,7 +35,7 @@ struct KernelSet {
 	size_t (*columns_lds)(uint32_t B);
 	void (*columns)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t,
 	                uint32_t const *, uint32_t const *, uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t npass, uint32_t bsh,
-	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask);
+	                uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask, uint32_t const *blocklist);
 	uint32_t (*columns_resident)(size_t lds);                 // workgroups of k_columns one CU holds
 	size_t lds_chain;
 	void (*chain)(hipStream_t, uint32_t grid, size_t lds, uint32_t const *rank, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
@@ -54,7 +54,7 @@ inline hipError_t allow_lds(K kernel, size_t bytes)
 
 struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t colbytes); hipError_t (*prepare)(size_t lds);
 	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
-	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t);
+	               uint32_t, uint32_t, uint32_t, uint2 *, uint4 *, uint32_t, uint32_t *, uint32_t *, uint32_t, uint32_t *, uint32_t, uint32_t, uint32_t const *blocklist);
 	uint32_t (*resident)(size_t lds);
 	// pass 2 on the same tile step (packed rows only; nullptr otherwise): k_columns_stream2<.., S2_SNAP>
 	void (*launch_snap)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *, size_t, uint32_t, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t *,
@@ -63,7 +63,7 @@ struct Stream2Config { uint32_t T, E, key_shift, pack; size_t (*lds)(uint32_t co
 struct ReducedSet {
 	uint32_t T, E, rows;                     // rows: representatives a workgroup holds
 	bool pk, ew;
-	size_t (*lds)(uint32_t B);
+	size_t (*lds)(uint32_t B, uint32_t symcap);   // symcap: bytes of each staged-column buffer (RedArgs)
 	hipError_t (*prepare)(size_t lds);
 	void (*launch)(hipStream_t, uint32_t grid, size_t lds, uint8_t const *red_msa, size_t red_ld, uint64_t n, uint32_t B, uint32_t L, uint32_t X, uint32_t stride,
 	               uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh, RedArgs const &);
@@ -81,6 +81,7 @@ struct ChainSnapSet {
 };
 bool select_chain_snap(uint32_t T, uint32_t E, ChainSnapSet *out);
 hipError_t launch_reduce_prep(hipStream_t, uint32_t grid, RedPrepArgs const &);
+void launch_reduce_check(hipStream_t, uint32_t const *cnt, uint32_t const *planned, uint32_t count, uint32_t *flags);
 void launch_reduce_msa(hipStream_t, uint32_t nblocks_listed, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,
                        uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks);
 
@@ -132,6 +133,8 @@ struct Tuning {
 	bool check_phase_a = false;          // FSEQ_CHECK_PHASE_A: validate the key blocks on the host before phase B
 	bool no_reduced = false;             // FSEQ_NO_REDUCED: phase C and pass 2 on all rows of every block (the form before round 5)
 	int  reduced_margin = -1;            // FSEQ_REDUCED_MARGIN: counts beyond the list capacity the choice of vmin allows for (tests: 0 makes lists dig below it)
+	bool reduced_ew = false;             // FSEQ_REDUCED_EW: small blocks on two-wave workgroups (the list on a wave of its own) instead of one wave
+	int  stream_block = 0;               // FSEQ_STREAM_BLOCK: columns per block the streamed regime aims for when phase C runs on representatives
 	int  reduced_cap = 0;                // FSEQ_REDUCED_CAP: most representatives a block may have (tests: small values send blocks to the run on all rows)
 
 	// returns false for a name it does not know
@@ -179,6 +182,8 @@ struct Tuning {
 		else if (n == "FSEQ_NO_REDUCED") no_reduced = on;
 		else if (n == "FSEQ_REDUCED_MARGIN") reduced_margin = on ? std::max(0, iv) : -1;
 		else if (n == "FSEQ_REDUCED_CAP") reduced_cap = on ? std::max(1, iv) : 0;
+		else if (n == "FSEQ_REDUCED_EW") reduced_ew = on;
+		else if (n == "FSEQ_STREAM_BLOCK") stream_block = on ? std::max(64, iv) : 0;
 		else return false;
 		return true;
 	}
@@ -190,7 +195,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -353,7 +358,18 @@ struct fseq_ctx {
 	struct RedBin { int config; uint32_t first, count; };     // blocks [first, first + count) of d_red_blocks run on configuration `config`
 	std::vector<RedBin> red_bins;
 	std::vector<int> red_config_of;          // [block] configuration of a reduced block (-1: not reduced)
+	uint32_t red_full_at = 0, red_nfull = 0;     // d_red_blocks[red_full_at .. + red_nfull): the blocks that run on all rows
 	uint32_t red_listed = 0, red_max_rows = 0;   // d_red_blocks[0 .. red_listed): every reduced block; the most representatives among them
+	bool red_direct = false;                 // the representatives' symbols are read from the alignment's own columns (LDS-resident row counts): no reduced alignment
+	// the plan (which block on which configuration) of the last run on this input at capacity red_plan_X: the next run launches
+	// by it without waiting for the counts, and checks on the device that they are what the plan was made from
+	bool red_plan_valid = false;
+	uint32_t red_plan_X = 0;
+	uint32_t *d_red_cnt_plan = nullptr;
+	hipStream_t red_st[3]{};                 // the configurations' launches side by side
+	hipEvent_t red_ev[4]{};
+	uint8_t *h_red_pin2 = nullptr;           // pass 2's task lists (pinned)
+	size_t red_pin2_bytes = 0;
 
 	// results
 	bool have_result = false;

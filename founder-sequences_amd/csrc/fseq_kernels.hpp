@@ -761,13 +761,14 @@ __device__ __forceinline__ void columns_body(char *smem,
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask, RedArgs const &red)
+	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask, RedArgs const &red, uint32_t const *__restrict__ blocklist = nullptr)
 {
+	// blocklist (not RED) [r5]: workgroup i owns block blocklist[i] -- the blocks the reduced phase C hands to the run on all rows
 	// colmask (4-bit symbols, or nullptr): the codes present in every column (k_column_presence)
 	// workgroup i of the launch owns column block block0 + i (phase C may be launched in several parts)
 	FSEQ_CLOCK_STAMP(blockIdx.x, 0);
 	constexpr uint32_t CAP = T * E;
-	uint32_t const blk = RED ? red.blocks[blockIdx.x] : blockIdx.x + block0;
+	uint32_t const blk = RED ? red.blocks[blockIdx.x] : (blocklist ? blocklist[blockIdx.x] : blockIdx.x + block0);
 	uint32_t red_vmin = 0, red_deficit = 0, t_first = 0, t_count = 0, t_next = 0;
 	bool const red_snap = RED && red.cls != nullptr;
 	if constexpr (RED)
@@ -785,8 +786,8 @@ __device__ __forceinline__ void columns_body(char *smem,
 	Carver cv{smem};
 	AT *a_l = cv.take<AT>(CAP);
 	AT *d_l = cv.take<AT>(CAP);
-	uint8_t *sym0 = cv.take<uint8_t>(CAP);
-	uint8_t *sym1 = cv.take<uint8_t>(CAP);
+	uint8_t *sym0 = cv.take<uint8_t>(RED ? red.symcap : CAP);
+	uint8_t *sym1 = cv.take<uint8_t>(RED ? red.symcap : CAP);
 	uint32_t *cnt_l = cv.take<uint32_t>(PK ? (CAP + B + 1) / 2 : CAP + B);
 	uint32_t *V_l = cv.take<uint32_t>(CAP);
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
@@ -879,19 +880,33 @@ __device__ __forceinline__ void columns_body(char *smem,
 	for (int e = 0; e < E; ++e)
 		if (rows) { a_l[p0 + e] = (AT) a[e]; d_l[p0 + e] = (AT) id[e]; }
 
-	bool const has_chunk = tid * 16u < sym_bytes(m, bsh);
+	bool const has_chunk = !RED && tid * 16u < sym_bytes(m, bsh);
 	uint4 nxt = make_uint4(0, 0, 0, 0);
 	if (nb && has_chunk)
 	{
 		nxt = *reinterpret_cast<uint4 const *>(msa + k0 * ld + tid * 16u);
 		*reinterpret_cast<uint4 *>(sym0 + tid * 16u) = nxt;
 	}
+	// RED: the packed column straight into LDS (LDS-DMA, no registers: a column of the alignment itself may be several
+	// 16-byte pieces per thread); every lane loads -- a lane past the column's bytes re-reads its first piece into the
+	// buffer's padding
+	uint32_t const red_colbytes = RED ? (red.direct ? red.colbytes : sym_bytes(m, bsh)) : 0u;
+	auto red_stage = [&](uint64_t k, uint8_t *dstb) {
+		uint8_t const *const col = msa + k * ld;
+		for (uint32_t cb = 0; cb < red_colbytes; cb += (uint32_t) T * 16u)
+		{
+			uint32_t const off = cb + tid * 16u;
+			if (cb + wave_id() * 1024u < red_colbytes)               // (wave-uniform: the buffers end with the last wave's kilobyte that holds bytes)
+				lds_dma16(col + (off < red_colbytes ? off : 0u), __builtin_amdgcn_readfirstlane((uint32_t) (uintptr_t) (dstb + cb + wave_id() * 1024u)));
+		}
+	};
+	if (RED && nb) { red_stage(k0, sym0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 	__syncthreads();
 
 	bool const zero_present = (V_l[0] == 0u);
 	// (see the pass loop; compiled into the nine-to-eleven-row kernels only -- the 512-thread 16-bit kernels have no register to spare)
 	constexpr bool CARRY_OK = PK && E >= 9;
-	bool const carry = CARRY_OK && npass == 2u && bsh == 1u && m <= 16384u;
+	bool const carry = CARRY_OK && npass == 2u && bsh == 1u && ((RED && red.direct) ? red.m_true : m) <= 16384u;
 #ifdef FSEQ_KC_STAMPS
 	long long kc_work = 0, kc_wait = 0, kc_last = clock64();
 	KcStamps kcs{{0, 0, 0, 0, 0, 0, 0, 0}, clock64()};
@@ -904,6 +919,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 		bool const more = j + 1 < nb;
 		if (more && has_chunk)
 			nxt = *reinterpret_cast<uint4 const *>(msa + (k0 + j + 1) * ld + tid * 16u);
+		if (RED && more) red_stage(k0 + j + 1, symn);
 		// [r4] at most four codes present in a column of 4-bit symbols: ONE pass over their ranks among the present codes
 		// (remap: two bits per code)
 		bool dense = false;
@@ -988,6 +1004,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 			}
 			if (last_pass && more && has_chunk)
 				*reinterpret_cast<uint4 *>(symn + tid * 16u) = nxt;
+			if (RED && last_pass && more) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the next column has landed
 #ifdef FSEQ_KC_STAMPS
 			{ long long const t_ = clock64(); kc_work += t_ - kc_last; kc_last = t_; }
 			__syncthreads();
@@ -1046,7 +1063,8 @@ __device__ __forceinline__ void columns_body(char *smem,
 							uint32_t const vid = d_l[pos];
 							bool const first = vid >= D0;
 							r += first ? 1u : 0u;
-							red.cls[ot + red.leaf[ol + a_l[pos]]] = r - 1u;
+							uint32_t const lf = red.direct ? red.rank[(size_t) blk * red.m_true + a_l[pos]] : red.leaf[ol + a_l[pos]];
+							red.cls[ot + lf] = r - 1u;
 							if (first) red.headd[ot + r - 1u] = (uint32_t) (k0 + (vid - D0) + 1u);
 						}
 					}
@@ -1155,7 +1173,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 				{
 					cnt0 = 0;                                            // (unknown -- and unused: the list is not complete)
 					// a taken entry below vmin, or every value taken while rows are left out: the run on all rows would go on
-					if (__ballot(red_bad) != 0ull || (!red_stopped && red_deficit != 0u)) { if (lane == 0) red.invalid[blk] = 1u; }
+					if (__ballot(red_bad) != 0ull || (!red_stopped && red_deficit != 0u)) { if (lane == 0) { red.invalid[blk] = 1u; red.any_invalid[0] = 1u; } }
 				}
 			}
 			uint32_t const cum = R + cumN;
@@ -1189,11 +1207,11 @@ __global__ __launch_bounds__(T, (PK && T == 512) ? 6 : 4) void k_columns(
 	uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d,
 	uint32_t L, uint32_t X, uint32_t stride, uint2 *__restrict__ ent, uint4 *__restrict__ hdr, uint32_t npass, uint32_t bsh,
 	uint32_t snap_stride, uint32_t *__restrict__ ss_a, uint32_t *__restrict__ ss_d, uint32_t block0,
-	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask = nullptr)
+	uint32_t *done_host, uint32_t epoch, uint32_t const *__restrict__ colmask = nullptr, uint32_t const *__restrict__ blocklist = nullptr)
 {
 	extern __shared__ __attribute__((aligned(16))) char smem[];
 	columns_body<T, E, SIGMA, PK, EW, DENSE, false>(smem, msa, ld, m, n, B, N2, bstate_a, bstate_d, L, X, stride, ent, hdr, npass, bsh, snap_stride, ss_a, ss_d, block0,
-	                                                 done_host, epoch, colmask, RedArgs{});
+	                                                 done_host, epoch, colmask, RedArgs{}, blocklist);
 }
 
 // [r5] the same on a block's representative rows (msa / ld: the reduced alignment; red: fseq_types.hpp)

@@ -9,7 +9,10 @@ namespace {
 
 template <int T, int E, bool PK, bool EW>
 struct LaunchRed {
-	static size_t lds(uint32_t B) { return columns_lds_bytes<T, E, 4, PK>(B); }
+	static size_t lds(uint32_t B, uint32_t symcap)
+	{
+		return columns_lds_bytes<T, E, 4, PK>(B) - 2 * carve_bytes((size_t) T * E, 1) + 2 * carve_bytes(symcap, 1);
+	}
 	static hipError_t prepare(size_t bytes) { return allow_lds(k_columns_red<T, E, 4, PK, EW>, bytes); }
 	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint64_t n, uint32_t B, uint32_t L, uint32_t X, uint32_t stride,
 	                   uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh, RedArgs const &red)
@@ -27,7 +30,8 @@ struct LaunchRed {
 
 // ascending by the rows they hold
 #define FSEQ_RED_CONFIGS(X) \
-	X(64, 3, false, false) X(64, 5, false, false) X(64, 7, false, false) X(256, 3, false, false) X(256, 5, false, false) X(512, 5, false, false) \
+	X(64, 3, false, false) X(128, 3, false, true) X(64, 5, false, false) X(128, 5, false, true) X(64, 7, false, false) X(128, 7, false, true) \
+	X(256, 3, false, false) X(256, 5, false, false) X(512, 5, false, false) \
 	X(512, 7, false, false) X(1024, 5, false, false) X(1024, 7, false, false) X(1024, 9, true, false) X(1024, 10, true, false) X(1024, 11, true, false)
 
 template <int T, int E, bool PK>
@@ -81,6 +85,11 @@ hipError_t launch_reduce_prep(hipStream_t st, uint32_t grid, RedPrepArgs const &
 	if (e != hipSuccess) return e;
 	hipLaunchKernelGGL(k_reduce_prep, dim3(grid), dim3(RED_PREP_T), bytes, st, A);
 	return hipSuccess;
+}
+
+void launch_reduce_check(hipStream_t st, uint32_t const *cnt, uint32_t const *planned, uint32_t count, uint32_t *flags)
+{
+	if (count) hipLaunchKernelGGL(k_reduce_check, dim3((count + 255u) / 256u), dim3(256), 0, st, cnt, planned, count, flags);
 }
 
 void launch_reduce_msa(hipStream_t st, uint32_t nlisted, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,

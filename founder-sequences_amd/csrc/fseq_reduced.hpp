@@ -29,7 +29,7 @@
 
 namespace fseq {
 
-constexpr uint32_t RED_W = 8192;        // values below the first column's threshold the search for vmin looks at
+constexpr uint32_t RED_W = 2048;        // values below the first column's threshold the search for vmin looks at
 constexpr int RED_PREP_T = 256;
 
 
@@ -42,7 +42,7 @@ __host__ __device__ inline size_t reduce_prep_lds_bytes(uint32_t m)
 }
 
 // one workgroup per block: vmin, the representatives (ascending row id), their block keys, the reduced start state
-__global__ __launch_bounds__(RED_PREP_T) void k_reduce_prep(RedPrepArgs const A)
+static __global__ __launch_bounds__(RED_PREP_T) void k_reduce_prep(RedPrepArgs const A)
 {
 	constexpr int T = RED_PREP_T;
 	constexpr uint32_t NWV = T / WAVE;
@@ -59,6 +59,11 @@ __global__ __launch_bounds__(RED_PREP_T) void k_reduce_prep(RedPrepArgs const A)
 
 	uint32_t const tid = threadIdx.x, lane = lane_id(), wv = wave_id();
 	uint32_t const blk = A.blocks ? A.blocks[blockIdx.x] : A.block0 + blockIdx.x;
+	if (tid == 0)
+	{
+		if (A.invalid) A.invalid[blk] = 0u;
+		if (A.flags && blockIdx.x == 0) { A.flags[0] = 0u; A.flags[1] = 0u; }
+	}
 	uint64_t const k0 = (uint64_t) blk * A.B;
 	uint32_t const *const a0 = A.bstate_a + (size_t) blk * m, *const d0 = A.bstate_d + (size_t) blk * m;
 	uint32_t const *const a1 = a0 + m, *const d1 = d0 + m;
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(RED_PREP_T) void k_reduce_prep(RedPrepArgs const A)
 			if (k)
 			{
 				uint32_t const idx = base_idx + (uint32_t) __popcll(below);
-				A.a[ob + idx] = wpre[row >> 5] + (uint32_t) __popc(word & ((1u << (row & 31u)) - 1u));
+				A.a[ob + idx] = A.direct ? row : wpre[row >> 5] + (uint32_t) __popc(word & ((1u << (row & 31u)) - 1u));
 				A.d[ob + idx] = v;
 			}
 			if (mask)
@@ -204,11 +209,19 @@ __global__ __launch_bounds__(RED_PREP_T) void k_reduce_prep(RedPrepArgs const A)
 	}
 }
 
+// The plan of a run is the plan of the run before it on the same input (the counts have not changed: same input, same
+// capacity): flags[1] = 1 if they have after all (the host then plans afresh and runs the attempt again).
+static __global__ __launch_bounds__(256) void k_reduce_check(uint32_t const *__restrict__ cnt, uint32_t const *__restrict__ planned, uint32_t count, uint32_t *__restrict__ flags)
+{
+	uint32_t const i = blockIdx.x * 256u + threadIdx.x;
+	if (i < count && cnt[i] != planned[i]) flags[1] = 1u;
+}
+
 // The packed columns of the representatives: column k of the reduced alignment at red + k * ldr, representative i at byte
 // i >> bsh (same packing as the alignment).  Workgroup (x, y): block blocks[x], output bytes [64 y, 64 y + 64) -- a wave is 64
 // consecutive output bytes of one column (the representatives ascend by row: the gathered bytes ascend too), the four
 // waves take the block's columns in turn.
-__global__ __launch_bounds__(256) void k_reduce_msa(
+static __global__ __launch_bounds__(256) void k_reduce_msa(
 	uint8_t const *__restrict__ msa, size_t ld, uint8_t *__restrict__ red, size_t ldr, uint32_t const *__restrict__ cnt,
 	uint32_t const *__restrict__ rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *__restrict__ blocks)
 {

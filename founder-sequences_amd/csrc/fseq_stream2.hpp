@@ -94,8 +94,9 @@ __host__ __device__ inline size_t stream2_lds_bytes(uint32_t colbytes)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0,
-	uint32_t pack_abits, uint32_t *__restrict__ bs_w = nullptr, uint8_t *__restrict__ bs_h = nullptr)
+	uint32_t pack_abits, uint32_t *__restrict__ bs_w = nullptr, uint8_t *__restrict__ bs_h = nullptr, uint32_t const *__restrict__ blocklist = nullptr)
 {
+	// blocklist [r5]: workgroup i owns block blocklist[i] (the blocks the reduced phase C hands to the run on all rows)
 	// bs_w / bs_h (packed rows only): a copy of the block's start state in id form -- what pass 2 replays from when no stride
 	// state of the block lies in front of a boundary (k_columns_stream2<.., S2_SNAP>); block b at bs_w + b * m, bs_h + b * ss_high_stride(m)
 	extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 	StreamLds &L = *cv.take<StreamLds>(1);
 	uint32_t *const stage = cv.take<uint32_t>(2 * (size_t) SCAP);
 	uint32_t const tid = threadIdx.x;
-	uint32_t const blk = blockIdx.x + block0;
+	uint32_t const blk = blocklist ? blocklist[blockIdx.x] : blockIdx.x + block0;
 	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
 	uint2 *pairs0 = reinterpret_cast<uint2 *>(w);
 	uint32_t *keys[2] = {w + 4u * (size_t) m, w + 5u * (size_t) m};
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(T, 4) void k_columns_stream2(
 	uint32_t const tid = threadIdx.x;
 	uint32_t const lane = lane_id();
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-	uint32_t const blk = MODE == S2_SNAP ? SN.wg_block[blockIdx.x] : blockIdx.x + block0;
+	// (S2_COLUMNS with SN.wg_block set [r5]: the listed blocks -- what the reduced phase C hands to the run on all rows)
+	uint32_t const blk = (MODE == S2_SNAP || SN.wg_block) ? SN.wg_block[blockIdx.x] : blockIdx.x + block0;
 	uint32_t *w = ws + (size_t) blk * columns_stream_ws_words(m, B);
 	uint2 *pairs[2] = {reinterpret_cast<uint2 *>(w), reinterpret_cast<uint2 *>(w + 2u * (size_t) m)};
 	uint32_t *words[2] = {w, w + (size_t) m};                                 // PACK

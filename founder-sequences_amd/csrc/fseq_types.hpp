@@ -29,6 +29,12 @@ struct RedArgs {
 	uint32_t *invalid = nullptr;        // [block] set when a list of the block took an entry the representatives cannot vouch for
 	uint32_t cap = 0;                   // row stride of a / d / leaf (and of cls / headd)
 	uint32_t m_true = 0;                // rows of the alignment
+	uint32_t direct = 0;                // 1: a[] holds ROW IDS and msa / ld are the alignment itself (its whole column is staged: colbytes);
+	                                    // 0: a[] holds representative indices and msa / ld are the reduced alignment (k_reduce_msa)
+	uint32_t colbytes = 0;              // direct: bytes of a packed column of the alignment
+	uint32_t symcap = 0;                // bytes of each of the two staged-column buffers in LDS (whole kilobytes)
+	uint32_t const *rank = nullptr;     // direct, pass 2: [block][m_true] block-key rank of every row (leaf[] is not used)
+	uint32_t *any_invalid = nullptr;    // one word: set with invalid[b]
 	// pass 2: instead of lists, the class tables at the task columns of the block
 	uint32_t const *wg_tasks = nullptr; // [workgroup][2] {first task, tasks}
 	unsigned long long const *task_rb = nullptr;   // [task] column (ascending inside a workgroup)
@@ -42,7 +48,8 @@ struct RedPrepArgs {
 	uint32_t const *bstate_a, *bstate_d;     // [blocks + 1][m]: the exact states in front of the blocks and behind the last
 	uint32_t const *rank;                    // [blocks][m]: block-key rank of every row (phase A)
 	uint32_t const *blocks;                  // [workgroup] block of workgroup i, or nullptr: block0 + i
-	uint32_t m, B, L, Xp, cap, block0, leaf_only;
+	uint32_t m, B, L, Xp, cap, block0, leaf_only, direct;      // direct: a[] = row ids (else: indices among the block's representatives)
+	uint32_t *invalid, *flags;               // invalid[b] = 0; flags[0 .. 1] = 0 (workgroup 0): what the column kernels and the plan check set
 	uint64_t n;
 	uint32_t *cnt, *vmin, *rows, *leaf, *a, *d;
 };
