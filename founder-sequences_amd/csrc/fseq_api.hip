@@ -796,6 +796,7 @@ void free_work(fseq_ctx *c)
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
 	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows); dev_free(c, &c->d_red_leaf); dev_free(c, &c->d_red_a); dev_free(c, &c->d_red_d);
 	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa); c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
+	dev_free(c, &c->d_red_ss_a); dev_free(c, &c->d_red_ss_d); c->red_ss_words = 0;
 	dev_free(c, &c->d_red_cls); dev_free(c, &c->d_red_headd); dev_free(c, &c->d_red_ncls); dev_free(c, &c->d_red_taskblk); dev_free(c, &c->d_red_wgtasks); c->red_task_cap = 0;
 	c->red_active = false;
 }
@@ -1987,6 +1988,7 @@ void red_fill_args(fseq_ctx *c, RedArgs &RA)
 	RA.cnt = c->d_red_cnt; RA.vmin = c->d_red_vmin; RA.a = c->d_red_a; RA.d = c->d_red_d; RA.leaf = c->d_red_leaf;
 	RA.invalid = c->d_red_invalid; RA.any_invalid = c->d_red_invalid + c->nblocks; RA.cap = c->red_cap; RA.m_true = c->p.m;
 	RA.direct = c->red_direct ? 1u : 0u; RA.colbytes = sym_bytes(c->p.m, c->bsh); RA.rank = c->d_rank;
+	RA.ss_a = c->d_red_ss_a; RA.ss_d = c->d_red_ss_d; RA.ss_stride = c->red_ss_stride; RA.ss_cap = c->red_ss_cap;
 }
 
 // ---- [r5] phase C on representative rows (fseq_reduced.hpp): the plan of one attempt.
@@ -2101,6 +2103,19 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa, need))) return rc; c->red_msa_bytes = need; }
 		c->red_ld = ldr;
 	}
+	{
+		// the reduced states for pass 2: every 16 columns (32: streamed rows), rows for the most representatives of a block
+		uint32_t const stride_ = c->use_stream ? 32u : 16u;
+		uint32_t const scap = (std::max(max_rows, 1u) + 63u) & ~63u;
+		size_t const words = ((size_t) (n / stride_) + 2) * scap;
+		if (c->red_ss_words < words)
+		{
+			if ((rc = dev_alloc(c, &c->d_red_ss_a, words))) return rc;
+			if ((rc = dev_alloc(c, &c->d_red_ss_d, words))) return rc;
+			c->red_ss_words = words;
+		}
+		c->red_ss_stride = stride_; c->red_ss_cap = scap;
+	}
 	c->red_bins.clear();
 	uint32_t at = listed;
 	for (int i = 0; i < nconf; ++i)
@@ -2140,7 +2155,7 @@ int red_launch_all(fseq_ctx *c, std::vector<RedLaunch> const &ls, RedArgs const 
 		size_t const lds = rs.lds(c->B, RA.symcap);
 		HIP_TRY(c, rs.prepare(lds));
 		RA.blocks = blocks + ls[i].first;
-		if (wg_tasks) RA.wg_tasks = wg_tasks + 2 * (size_t) ls[i].first;
+		if (wg_tasks) RA.wg_tasks = wg_tasks + 3 * (size_t) ls[i].first;
 		// the largest launches on the side streams, the rest in turn on the context's
 		hipStream_t const s_ = (i >= 1 && i <= nside) ? c->red_st[i - 1] : st;
 		if (s_ != st) HIP_TRY(c, hipStreamWaitEvent(s_, c->red_ev[3], 0));
@@ -2490,7 +2505,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 	std::vector<uint64_t> rbs(S2);
 	std::vector<uint32_t> task_blk(S2), ncls0(S2);
 	// tasks of reduced blocks by configuration: workgroups {block, first task, count}; tasks of the other blocks: old groups
-	struct Wg { uint32_t blk, first, count; };
+	struct Wg { uint32_t blk, first, count, start; };
 	std::vector<std::vector<Wg>> wgs((size_t) reduced_config_count());
 	std::vector<uint64_t> o_rbs, o_srcs;
 	std::vector<uint2> o_grp;
@@ -2509,9 +2524,13 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		int const cf = c->red_config_of[blk];
 		if (cf >= 0 && c->red_cnt_host[blk] != RED_NONE)
 		{
+			// the sweep starts at the last state phase C dropped in front of the boundary (or at the block's first column)
+			uint64_t start = c->red_ss_stride ? (rb - 1u) / c->red_ss_stride * c->red_ss_stride : 0u;
+			// (a block that ran on all rows dropped none)
+			if (start <= (uint64_t) blk * c->B || c->red_full[blk]) start = (uint64_t) blk * c->B;
 			auto &v = wgs[(size_t) cf];
-			if (!v.empty() && v.back().blk == blk) ++v.back().count;
-			else v.push_back(Wg{blk, (uint32_t) i, 1u});
+			if (!v.empty() && v.back().blk == blk && v.back().start == (uint32_t) start) ++v.back().count;
+			else v.push_back(Wg{blk, (uint32_t) i, 1u, (uint32_t) start});
 		}
 		else
 		{
@@ -2533,7 +2552,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		if ((rc = dev_alloc(c, &c->d_red_headd, S2 * (size_t) c->red_cap))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_ncls, S2))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_taskblk, S2))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_wgtasks, 2 * S2 + 2 * (size_t) c->nblocks))) return rc;
+		if ((rc = dev_alloc(c, &c->d_red_wgtasks, 4 * S2 + 64))) return rc;
 		c->red_task_cap = S2;
 	}
 	if (c->cols_cap < S2) { if ((rc = dev_alloc(c, &c->d_cols, S2))) return rc; c->cols_cap = S2; }
@@ -2546,12 +2565,12 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		ls.push_back(RedLaunch{(int) cf, (uint32_t) hb.size(), (uint32_t) wgs[cf].size()});
 		for (auto const &w : wgs[cf])
 		{
-			hb.push_back(w.blk); hw.push_back(w.first); hw.push_back(w.count);
-			cells += (rbs[w.first + w.count - 1u] - (uint64_t) w.blk * c->B) * c->red_cnt_host[w.blk];
+			hb.push_back(w.blk); hw.push_back(w.first); hw.push_back(w.count); hw.push_back(w.start);
+			cells += (rbs[w.first + w.count - 1u] - (uint64_t) w.start) * c->red_cnt_host[w.blk];
 		}
 	}
 	{
-		size_t const need = S2 * 16 + hb.size() * 12 + 256;
+		size_t const need = S2 * 16 + hb.size() * 16 + 256;
 		if (c->red_pin2_bytes < need)
 		{
 			if (c->h_red_pin2) (void) hipHostFree(c->h_red_pin2);
@@ -2566,7 +2585,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		HIP_TRY(c, hipMemcpyAsync(c->d_red_ncls, put(ncls0.data(), S2 * 4), S2 * 4, hipMemcpyHostToDevice, st));
 		if (!hb.empty())
 		{
-			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks + 2 * S2, put(hb.data(), hb.size() * 4), hb.size() * 4, hipMemcpyHostToDevice, st));
+			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks + 3 * S2, put(hb.data(), hb.size() * 4), hb.size() * 4, hipMemcpyHostToDevice, st));
 			HIP_TRY(c, hipMemcpyAsync(c->d_red_wgtasks, put(hw.data(), hw.size() * 4), hw.size() * 4, hipMemcpyHostToDevice, st));
 		}
 	}
@@ -2581,7 +2600,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		RA.task_rb = reinterpret_cast<unsigned long long const *>(c->d_cols);
 		RA.cls = c->d_red_cls; RA.headd = c->d_red_headd; RA.ncls = c->d_red_ncls;
 		std::stable_sort(ls.begin(), ls.end(), [](RedLaunch const &x, RedLaunch const &y) { return x.count > y.count; });
-		if ((rc = red_launch_all(c, ls, RA, c->d_red_wgtasks + 2 * S2, c->d_red_wgtasks, (uint2 *) nullptr, (uint4 *) nullptr, 0u, 0u))) return rc;
+		if ((rc = red_launch_all(c, ls, RA, c->d_red_wgtasks + 3 * S2, c->d_red_wgtasks, (uint2 *) nullptr, (uint4 *) nullptr, 0u, 0u))) return rc;
 	}
 	// one chain step per boundary (a copy for the borders)
 	if (!c->use_stream)

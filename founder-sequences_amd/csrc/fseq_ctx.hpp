@@ -353,6 +353,9 @@ struct fseq_ctx {
 	bool red_active = false;                 // this run's phase C went through the representatives (pass 2 follows it)
 	uint32_t *d_red_cls = nullptr, *d_red_headd = nullptr, *d_red_ncls = nullptr, *d_red_taskblk = nullptr, *d_red_wgtasks = nullptr;
 	size_t red_task_cap = 0;
+	uint32_t *d_red_ss_a = nullptr, *d_red_ss_d = nullptr;      // the reduced states phase C drops every red_ss_stride columns ([q][red_ss_cap])
+	uint32_t red_ss_stride = 0, red_ss_cap = 0;
+	size_t red_ss_words = 0;
 	uint32_t *h_red_pin = nullptr;           // pinned host staging of the plan (counts back, block lists out): its own buffer, live across the run
 	size_t red_pin_words = 0;
 	struct RedBin { int config; uint32_t first, count; };     // blocks [first, first + count) of d_red_blocks run on configuration `config`

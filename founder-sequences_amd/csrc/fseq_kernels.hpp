@@ -778,7 +778,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 		red_vmin = red.vmin[blk];
 		red_deficit = red.m_true - m;
 		N2 = 2; while (N2 < m + 1u) N2 <<= 1;
-		if (red_snap) { t_first = red.wg_tasks[2u * blockIdx.x]; t_count = red.wg_tasks[2u * blockIdx.x + 1u]; }
+		if (red_snap) { t_first = red.wg_tasks[3u * blockIdx.x]; t_count = red.wg_tasks[3u * blockIdx.x + 1u]; }
 	}
 	bool const red_exact = RED && red_vmin <= 1u;
 	// [a_l][d_l][sym0][sym1][cnt_l] are contiguous: the prologue's sort buffer (N2 < 2m words) overlays them
@@ -799,7 +799,9 @@ __device__ __forceinline__ void columns_body(char *smem,
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = EW ? (tid >= 64u ? (tid - 64u) * E : 0x7FFF0000u) : tid * E;     // 0x7FFF0000: owns nothing (every p0 + e >= m)
 	bool const rows = !EW || tid >= 64u;
-	uint64_t const k0 = (uint64_t) blk * B;
+	// (pass 2 on the representatives: the sweep starts at the block's first column or at one of the states phase C dropped)
+	uint64_t const kblk = (uint64_t) blk * B;
+	uint64_t const k0 = red_snap ? (uint64_t) red.wg_tasks[3u * blockIdx.x + 2u] : kblk;
 	uint64_t const kend = red_snap ? (uint64_t) red.task_rb[t_first + t_count - 1u] : ((k0 + B < n) ? k0 + B : n);
 	uint32_t const nb = (uint32_t) (kend - k0);
 
@@ -807,8 +809,9 @@ __device__ __forceinline__ void columns_body(char *smem,
 	// boundary state straight into registers (chunk ownership: positions tid*E .. tid*E+E-1)
 	uint32_t a[E], d[E];
 	{
-		size_t const ob = RED ? (size_t) blk * red.cap : (size_t) blk * m;
-		uint32_t const *const sa = RED ? red.a : bstate_a, *const sd = RED ? red.d : bstate_d;
+		bool const from_ss = RED && k0 != kblk;
+		size_t const ob = from_ss ? (size_t) (k0 / red.ss_stride) * red.ss_cap : RED ? (size_t) blk * red.cap : (size_t) blk * m;
+		uint32_t const *const sa = from_ss ? red.ss_a : RED ? red.a : bstate_a, *const sd = from_ss ? red.ss_d : RED ? red.d : bstate_d;
 #pragma unroll
 		for (int e = 0; e < E; ++e)
 		{
@@ -1035,19 +1038,38 @@ __device__ __forceinline__ void columns_body(char *smem,
 			}
 		}
 
+		// ---- [r5] the reduced state every ss_stride columns (the columns strictly inside the block): pass 2's sweeps start there
+		if (RED && !red_snap && red.ss_a && (k0 + j + 1u) % red.ss_stride == 0u && j + 1u < nb)
+		{
+			size_t const ob = (size_t) ((k0 + j + 1u) / red.ss_stride) * red.ss_cap;
+			for (uint32_t idx = tid; idx < m; idx += T)
+			{
+				uint32_t const vid = d_l[idx];
+				red.ss_a[ob + idx] = a_l[idx];
+				red.ss_d[ob + idx] = vid < D0 ? V_l[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
+			}
+		}
 		// ---- [r5] pass 2 on the representatives: the class tables at a task column.  A position starts a class iff its
-		// divergence lies inside the block (an id of one of the block's columns); the class of a block key is the class of any
+		// divergence lies inside the block (> the block's first column); the class of a block key is the class of any
 		// representative that carries it.
 		if (RED && red_snap)
 		{
 			if (t_next < t_count && red.task_rb[t_first + t_next] == k0 + j + 1u)
 			{
 				uint32_t const task = t_first + t_next;
+				// (ids of this sweep's own columns are inside the block; of its start values those that are -- V_l ascends -- from id_in on)
+				uint32_t id_in = D0;
+				if (k0 != kblk)
+				{
+					uint32_t lo = 0, hi = D0;
+					while (lo < hi) { uint32_t const mid = (lo + hi) >> 1; if (V_l[mid] <= (uint32_t) kblk) lo = mid + 1; else hi = mid; }
+					id_in = lo;
+				}
 				uint32_t nf = 0;
 				if (rows)
 				{
 #pragma unroll
-					for (int e = 0; e < E; ++e) nf += (p0 + e < m && (uint32_t) d_l[p0 + e] >= D0) ? 1u : 0u;
+					for (int e = 0; e < E; ++e) nf += (p0 + e < m && (uint32_t) d_l[p0 + e] >= id_in) ? 1u : 0u;
 				}
 				uint32_t total;
 				uint32_t r = block_excl_add<T>(nf, sscr, &total);
@@ -1061,11 +1083,11 @@ __device__ __forceinline__ void columns_body(char *smem,
 						if (pos < m)
 						{
 							uint32_t const vid = d_l[pos];
-							bool const first = vid >= D0;
+							bool const first = vid >= id_in;
 							r += first ? 1u : 0u;
 							uint32_t const lf = red.direct ? red.rank[(size_t) blk * red.m_true + a_l[pos]] : red.leaf[ol + a_l[pos]];
 							red.cls[ot + lf] = r - 1u;
-							if (first) red.headd[ot + r - 1u] = (uint32_t) (k0 + (vid - D0) + 1u);
+							if (first) red.headd[ot + r - 1u] = vid < D0 ? V_l[vid] : (uint32_t) (k0 + (vid - D0) + 1u);
 						}
 					}
 				}

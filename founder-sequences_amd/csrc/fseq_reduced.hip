@@ -32,7 +32,7 @@ struct LaunchRed {
 #define FSEQ_RED_CONFIGS(X) \
 	X(64, 3, false, false) X(128, 3, false, true) X(64, 5, false, false) X(128, 5, false, true) X(64, 7, false, false) X(128, 7, false, true) \
 	X(256, 3, false, false) X(256, 5, false, false) X(512, 5, false, false) \
-	X(512, 7, false, false) X(1024, 5, false, false) X(1024, 7, false, false) X(1024, 9, true, false) X(1024, 10, true, false) X(1024, 11, true, false)
+	X(512, 7, false, false) X(1024, 5, false, false) X(1024, 7, true, false) X(1024, 9, true, false) X(1024, 10, true, false) X(1024, 11, true, false)
 
 template <int T, int E, bool PK>
 struct LaunchChainSnap {

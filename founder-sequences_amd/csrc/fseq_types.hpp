@@ -36,7 +36,11 @@ struct RedArgs {
 	uint32_t const *rank = nullptr;     // direct, pass 2: [block][m_true] block-key rank of every row (leaf[] is not used)
 	uint32_t *any_invalid = nullptr;    // one word: set with invalid[b]
 	// pass 2: instead of lists, the class tables at the task columns of the block
-	uint32_t const *wg_tasks = nullptr; // [workgroup][2] {first task, tasks}
+	uint32_t const *wg_tasks = nullptr; // [workgroup][3] {first task, tasks, column of the start state (the block's first column, or a stride state's)}
+	// the reduced states phase C drops every ss_stride columns (the state at column q * ss_stride at [q][ss_cap], where that
+	// column lies strictly inside a block): where pass 2's sweeps start from
+	uint32_t *ss_a = nullptr, *ss_d = nullptr;
+	uint32_t ss_stride = 0, ss_cap = 0;
 	unsigned long long const *task_rb = nullptr;   // [task] column (ascending inside a workgroup)
 	uint32_t *cls = nullptr;            // [task][cap] class (rank among the distinct key prefixes) of every block key
 	uint32_t *headd = nullptr;          // [task][cap] divergence in front of every class
