@@ -2058,15 +2058,19 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (c->red_force_full.size() != nbk) c->red_force_full.assign(nbk, 0);
 	c->red_full.assign(nbk, 0);
 	c->red_config_of.assign(nbk, -1);
+	c->red_config_snap_of.assign(nbk, -1);
 	int const nconf = reduced_config_count();
 	std::vector<ReducedSet> sets((size_t) nconf);
-	std::vector<uint8_t> usable((size_t) nconf);
+	std::vector<uint8_t> usable((size_t) nconf), usable_snap((size_t) nconf);
 	for (int i = 0; i < nconf; ++i)
 	{
 		(void) reduced_config(i, &sets[(size_t) i]);
 		ReducedSet const &rs = sets[(size_t) i];
-		// (one-wave workgroups, or two with the list on a wave of its own: FSEQ_REDUCED_EW picks the latter)
-		usable[(size_t) i] = columns_fit_reduced(c, rs, c->red_direct) && (rs.T > 128u || rs.ew == c->tune.reduced_ew);
+		// (small blocks: one-wave workgroups, or two with the list on a wave of its own: FSEQ_REDUCED_EW picks the latter; from 256
+		// threads on phase C takes the configurations with a list wave, pass 2's sweeps the others)
+		bool const fit = columns_fit_reduced(c, rs, c->red_direct);
+		usable[(size_t) i] = fit && (rs.T > 128u ? rs.ew : rs.ew == c->tune.reduced_ew);
+		usable_snap[(size_t) i] = fit && (rs.T > 128u ? !rs.ew : rs.ew == c->tune.reduced_ew);
 	}
 	std::vector<std::vector<uint32_t>> per((size_t) nconf);
 	uint32_t n_full = 0, max_rows = 0, listed = 0;
@@ -2079,9 +2083,11 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		{
 			h_blocks[listed++] = b;
 			max_rows = std::max(max_rows, r);
-			int cf = -1;
+			int cf = -1, cs = -1;
 			for (int i = 0; i < nconf; ++i) if (usable[(size_t) i] && sets[(size_t) i].rows >= r) { cf = i; break; }
+			for (int i = 0; i < nconf; ++i) if (usable_snap[(size_t) i] && sets[(size_t) i].rows >= r) { cs = i; break; }
 			c->red_config_of[b] = cf;
+			c->red_config_snap_of[b] = cs;
 		}
 		bool const full = r == RED_NONE || c->red_config_of[b] < 0 || c->red_force_full[b] || (uint64_t) r * 10u > (uint64_t) m * 7u;
 		if (full) { c->red_full[b] = 1; ++n_full; }
@@ -2521,7 +2527,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 		task_blk[i] = blk;
 		ncls0[i] = 0;                                             // a border: the copy; else the sweep fills it in
 		if (border) continue;
-		int const cf = c->red_config_of[blk];
+		int const cf = c->red_config_snap_of[blk];
 		if (cf >= 0 && c->red_cnt_host[blk] != RED_NONE)
 		{
 			// the sweep starts at the last state phase C dropped in front of the boundary (or at the block's first column)

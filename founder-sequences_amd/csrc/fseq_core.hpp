@@ -216,6 +216,10 @@ __device__ __forceinline__ void lds_dma16(void const *g, uint32_t lds_addr)
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// a barrier that waits for this wave's LDS operations only (__syncthreads() also drains its global stores: microseconds
+// when a list has just been written)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // -DFSEQ_KC_STAMPS: cycle stamps of a column step per wave (k_columns prints them)
 #ifdef FSEQ_KC_STAMPS
 struct KcStamps { long long acc[8]; long long last; };

@@ -360,7 +360,8 @@ struct fseq_ctx {
 	size_t red_pin_words = 0;
 	struct RedBin { int config; uint32_t first, count; };     // blocks [first, first + count) of d_red_blocks run on configuration `config`
 	std::vector<RedBin> red_bins;
-	std::vector<int> red_config_of;          // [block] configuration of a reduced block (-1: not reduced)
+	std::vector<int> red_config_of;          // [block] configuration of a reduced block's phase C (-1: not reduced)
+	std::vector<int> red_config_snap_of;     // ... and of its sweeps in pass 2 (no lists: no list wave)
 	uint32_t red_full_at = 0, red_nfull = 0;     // d_red_blocks[red_full_at .. + red_nfull): the blocks that run on all rows
 	uint32_t red_listed = 0, red_max_rows = 0;   // d_red_blocks[0 .. red_listed): every reduced block; the most representatives among them
 	bool red_direct = false;                 // the representatives' symbols are read from the alignment's own columns (LDS-resident row counts): no reduced alignment

@@ -795,7 +795,6 @@ __device__ __forceinline__ void columns_body(char *smem,
 	constexpr bool PW = columns_pairwise(T, E, SIGMA, PK);
 	constexpr bool LU = columns_lookup(T, E, SIGMA, PK);
 	uint32_t *runs = LU ? cv.take<uint32_t>(columns_run_words(T, E, SIGMA, PK)) : nullptr;
-
 	uint32_t const tid = threadIdx.x;
 	uint32_t const p0 = EW ? (tid >= 64u ? (tid - 64u) * E : 0x7FFF0000u) : tid * E;     // 0x7FFF0000: owns nothing (every p0 + e >= m)
 	bool const rows = !EW || tid >= 64u;

@@ -28,11 +28,15 @@ struct LaunchRed {
 	static ReducedSet make() { return ReducedSet{(uint32_t) T, (uint32_t) E, EW ? (uint32_t) (T - 64) * E : (uint32_t) T * E, PK, EW, &lds, &prepare, &launch, &resident}; }
 };
 
-// ascending by the rows they hold
+// ascending by the rows they hold.  EW: wave 0 holds no rows and emits the lists while the row waves are in the next column (from 256
+// threads on: what phase C runs -- the lists of a block with thousands of representatives are a thousand entries long, and
+// on a wave that also holds rows they were 40 % of a column of BASELINE C4 --; pass 2's sweeps, which emit none, take the others)
 #define FSEQ_RED_CONFIGS(X) \
 	X(64, 3, false, false) X(128, 3, false, true) X(64, 5, false, false) X(128, 5, false, true) X(64, 7, false, false) X(128, 7, false, true) \
-	X(256, 3, false, false) X(256, 5, false, false) X(512, 5, false, false) \
-	X(512, 7, false, false) X(1024, 5, false, false) X(1024, 7, true, false) X(1024, 9, true, false) X(1024, 10, true, false) X(1024, 11, true, false)
+	X(256, 3, false, true) X(256, 3, false, false) X(256, 5, false, true) X(256, 5, false, false) X(512, 5, false, true) X(512, 5, false, false) \
+	X(512, 7, false, true) X(512, 7, false, false) X(1024, 5, false, true) X(1024, 5, false, false) X(1024, 7, true, true) X(1024, 7, true, false) \
+	X(1024, 8, true, true) X(1024, 9, true, true) X(1024, 9, true, false) X(1024, 10, true, true) X(1024, 10, true, false) X(1024, 11, true, true) \
+	X(1024, 11, true, false) X(1024, 12, true, true)
 
 template <int T, int E, bool PK>
 struct LaunchChainSnap {
