@@ -249,7 +249,7 @@ constexpr uint64_t STREAM_BLOCK_TARGET_ALL_ROWS = 1600;   // columns per block t
 // [r5] ... and when phase C runs on the blocks' representatives: a block of ~800 columns of BASELINE C4 has ~6,600 of them, and
 // the ~10,700 of a block in which the founders recombine still fit the largest configuration (11,264)
 constexpr uint64_t STREAM_BLOCK_TARGET_REDUCED = 800;
-#define STREAM_BLOCK_TARGET ((c->tune.no_reduced || c->sh.on) ? STREAM_BLOCK_TARGET_ALL_ROWS : (c->tune.stream_block ? (uint64_t) c->tune.stream_block : STREAM_BLOCK_TARGET_REDUCED))
+#define STREAM_BLOCK_TARGET (c->tune.no_reduced ? STREAM_BLOCK_TARGET_ALL_ROWS : (c->tune.stream_block ? (uint64_t) c->tune.stream_block : STREAM_BLOCK_TARGET_REDUCED))
 #ifndef FSEQ_X_FLOOR_VALUE
 #define FSEQ_X_FLOOR_VALUE 63u
 #endif
@@ -794,9 +794,9 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
 	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
-	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows); dev_free(c, &c->d_red_leaf); dev_free(c, &c->d_red_a); dev_free(c, &c->d_red_d);
-	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa); c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
-	dev_free(c, &c->d_red_ss_a); dev_free(c, &c->d_red_ss_d); c->red_ss_words = 0;
+	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows_alloc); dev_free(c, &c->d_red_leaf_alloc); dev_free(c, &c->d_red_a_alloc); dev_free(c, &c->d_red_d_alloc); c->d_red_rows = c->d_red_leaf = c->d_red_a = c->d_red_d = nullptr;
+	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa_alloc); c->d_red_msa = nullptr; c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
+	dev_free(c, &c->d_red_ss_a_alloc); dev_free(c, &c->d_red_ss_d_alloc); c->d_red_ss_a = c->d_red_ss_d = nullptr; c->red_ss_words = 0;
 	dev_free(c, &c->d_red_cls); dev_free(c, &c->d_red_headd); dev_free(c, &c->d_red_ncls); dev_free(c, &c->d_red_taskblk); dev_free(c, &c->d_red_wgtasks); c->red_task_cap = 0;
 	c->red_active = false;
 }
@@ -2009,18 +2009,21 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	uint32_t const nbk = c->nblocks;
 	if (!c->d_red_cnt || c->red_cap != cap)
 	{
+		// (the small per-block words for every block of the alignment; the per-block rows for my blocks only -- a rank of a
+		// sharded run --, addressed by the block's place in the whole alignment like the key blocks and boundary states)
 		if ((rc = dev_alloc(c, &c->d_red_cnt, nbk))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_cnt_plan, nbk))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_vmin, nbk))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_invalid, nbk + 2))) return rc;
 		if ((rc = dev_alloc(c, &c->d_red_blocks, 3 * (size_t) nbk))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_rows, (size_t) nbk * cap))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_leaf, (size_t) nbk * cap))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_a, (size_t) nbk * cap))) return rc;
-		if ((rc = dev_alloc(c, &c->d_red_d, (size_t) nbk * cap))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_red_rows_alloc, &c->d_red_rows, b_lo, b_hi, cap))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_red_leaf_alloc, &c->d_red_leaf, b_lo, b_hi, cap))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_red_a_alloc, &c->d_red_a, b_lo, b_hi, cap))) return rc;
+		if ((rc = dev_alloc_range(c, &c->d_red_d_alloc, &c->d_red_d, b_lo, b_hi, cap))) return rc;
 		c->red_cap = cap;
 		c->red_plan_valid = false;
 	}
+	if (!my_blocks) return FSEQ_OK;                            // (a rank without blocks)
 	if (c->red_pin_words < 4 * (size_t) nbk + 64)
 	{
 		if (c->h_red_pin) (void) hipHostFree(c->h_red_pin);
@@ -2037,24 +2040,25 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	c->red_direct = !c->use_stream;
 	RedPrepArgs A{};
 	A.bstate_a = c->d_bstate_a; A.bstate_d = c->d_bstate_d; A.rank = c->d_rank; A.blocks = nullptr;
-	A.m = m; A.B = c->B; A.L = (uint32_t) L; A.cap = cap; A.block0 = 0; A.leaf_only = 0; A.n = n; A.direct = c->red_direct ? 1u : 0u;
+	A.m = m; A.B = c->B; A.L = (uint32_t) L; A.cap = cap; A.block0 = b_lo; A.leaf_only = 0; A.n = n; A.direct = c->red_direct ? 1u : 0u;
 	A.Xp = X + (c->tune.reduced_margin >= 0 ? (uint32_t) c->tune.reduced_margin : X / 4u + 8u);
 	A.cnt = c->d_red_cnt; A.vmin = c->d_red_vmin; A.rows = c->d_red_rows; A.leaf = c->d_red_leaf; A.a = c->d_red_a; A.d = c->d_red_d;
 	A.invalid = c->d_red_invalid; A.flags = c->d_red_invalid + nbk;
-	HIP_TRY(c, launch_reduce_prep(st, nbk, A));
+	HIP_TRY(c, launch_reduce_prep(st, my_blocks, A));
 	if (c->red_plan_valid && c->red_plan_X == X && c->red_force_full.size() == nbk)
 	{
-		launch_reduce_check(st, c->d_red_cnt, c->d_red_cnt_plan, nbk, c->d_red_invalid + nbk);
+		launch_reduce_check(st, c->d_red_cnt + b_lo, c->d_red_cnt_plan + b_lo, my_blocks, c->d_red_invalid + nbk);
 		if (!c->red_direct)
 			launch_reduce_msa(st, c->red_listed, c->red_max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
 		*use = true;
 		return FSEQ_OK;
 	}
 	uint32_t *const h_cnt = c->h_red_pin;
-	HIP_TRY(c, hipMemcpyAsync(h_cnt, c->d_red_cnt, (size_t) nbk * 4, hipMemcpyDeviceToHost, st));
-	HIP_TRY(c, hipMemcpyAsync(c->d_red_cnt_plan, c->d_red_cnt, (size_t) nbk * 4, hipMemcpyDeviceToDevice, st));
+	HIP_TRY(c, hipMemcpyAsync(h_cnt + b_lo, c->d_red_cnt + b_lo, (size_t) my_blocks * 4, hipMemcpyDeviceToHost, st));
+	HIP_TRY(c, hipMemcpyAsync(c->d_red_cnt_plan + b_lo, c->d_red_cnt + b_lo, (size_t) my_blocks * 4, hipMemcpyDeviceToDevice, st));
 	HIP_TRY(c, hipStreamSynchronize(st));
-	c->red_cnt_host.assign(h_cnt, h_cnt + nbk);
+	c->red_cnt_host.assign(nbk, RED_NONE);
+	std::copy(h_cnt + b_lo, h_cnt + b_hi, c->red_cnt_host.begin() + b_lo);
 	if (c->red_force_full.size() != nbk) c->red_force_full.assign(nbk, 0);
 	c->red_full.assign(nbk, 0);
 	c->red_config_of.assign(nbk, -1);
@@ -2076,7 +2080,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	uint32_t n_full = 0, max_rows = 0, listed = 0;
 	uint64_t sum_rows = 0;
 	uint32_t *const h_blocks = c->h_red_pin + nbk;             // [0, listed): every reduced block; then the configurations' lists
-	for (uint32_t b = 0; b < nbk; ++b)
+	for (uint32_t b = b_lo; b < b_hi; ++b)
 	{
 		uint32_t const r = c->red_cnt_host[b];
 		if (r != RED_NONE)
@@ -2094,33 +2098,39 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		else { per[(size_t) c->red_config_of[b]].push_back(b); sum_rows += r; }
 	}
 	c->red_listed = listed; c->red_max_rows = max_rows;
-	c->tm.reduced_blocks = nbk - n_full;
-	c->tm.reduced_rows_mean = nbk > n_full ? (uint32_t) (sum_rows / (nbk - n_full)) : 0u;
+	c->tm.reduced_blocks = my_blocks - n_full;
+	c->tm.reduced_rows_mean = my_blocks > n_full ? (uint32_t) (sum_rows / (my_blocks - n_full)) : 0u;
 	if (c->tune.debug)
-		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", nbk - n_full, nbk,
+		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", my_blocks - n_full, my_blocks,
 		        c->tm.reduced_rows_mean, m, max_rows, n_full);
-	if ((uint64_t) n_full * 4u > nbk) return FSEQ_OK;
+	if ((uint64_t) n_full * 4u > my_blocks) return FSEQ_OK;
 	if (n_full && c->use_stream && !c->s2.T) return FSEQ_OK;     // (the first form of the streamed kernel takes no block list)
 	if (!c->red_direct)
 	{
 		// the reduced alignment: column k at d_red_msa + k * red_ld
+		// (my columns only: column k at d_red_msa + k * red_ld)
 		size_t const ldr = ((size_t) sym_bytes(max_rows ? max_rows : 1u, c->bsh) + 15) & ~size_t(15);
-		size_t const need = (size_t) n * ldr + 64;
-		if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa, need))) return rc; c->red_msa_bytes = need; }
+		uint64_t const k_lo = (uint64_t) b_lo * c->B, k_hi = std::min<uint64_t>(n, (uint64_t) b_hi * c->B);
+		size_t const need = (size_t) (k_hi - k_lo) * ldr + 64;
+		if (c->red_msa_bytes < need) { if ((rc = dev_alloc(c, &c->d_red_msa_alloc, need))) return rc; c->red_msa_bytes = need; }
 		c->red_ld = ldr;
+		c->d_red_msa = c->d_red_msa_alloc - (size_t) k_lo * ldr;
 	}
 	{
 		// the reduced states for pass 2: every 16 columns (32: streamed rows), rows for the most representatives of a block
 		uint32_t const stride_ = c->use_stream ? 32u : 16u;
 		uint32_t const scap = (std::max(max_rows, 1u) + 63u) & ~63u;
-		size_t const words = ((size_t) (n / stride_) + 2) * scap;
+		uint64_t const q_lo = (uint64_t) b_lo * c->B / stride_, q_hi = std::min<uint64_t>(n, (uint64_t) b_hi * c->B) / stride_;
+		size_t const words = ((size_t) (q_hi - q_lo) + 2) * scap;
 		if (c->red_ss_words < words)
 		{
-			if ((rc = dev_alloc(c, &c->d_red_ss_a, words))) return rc;
-			if ((rc = dev_alloc(c, &c->d_red_ss_d, words))) return rc;
+			if ((rc = dev_alloc(c, &c->d_red_ss_a_alloc, words))) return rc;
+			if ((rc = dev_alloc(c, &c->d_red_ss_d_alloc, words))) return rc;
 			c->red_ss_words = words;
 		}
 		c->red_ss_stride = stride_; c->red_ss_cap = scap;
+		c->d_red_ss_a = c->d_red_ss_a_alloc - (size_t) q_lo * scap;       // (the state at column q * stride at [q][scap])
+		c->d_red_ss_d = c->d_red_ss_d_alloc - (size_t) q_lo * scap;
 	}
 	c->red_bins.clear();
 	uint32_t at = listed;
@@ -2133,7 +2143,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		at += (uint32_t) v.size();
 	}
 	c->red_full_at = at; c->red_nfull = 0;
-	for (uint32_t b = 0; b < nbk; ++b) if (c->red_full[b]) h_blocks[at + c->red_nfull++] = b;
+	for (uint32_t b = b_lo; b < b_hi; ++b) if (c->red_full[b]) h_blocks[at + c->red_nfull++] = b;
 	at += c->red_nfull;
 	HIP_TRY(c, hipMemcpyAsync(c->d_red_blocks, h_blocks, (size_t) at * 4, hipMemcpyHostToDevice, st));
 	if (!c->red_direct)
@@ -2192,8 +2202,8 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	double &ms_c = R.ms_c, &ms_dp = R.ms_dp, &ms_host = R.ms_host;
 	bool const keyspace = R.keyspace;
 	// [r5] phase C on representative rows: the default wherever the lists are consumed by the speculative DP behind phase C
-	// (not sharded yet: a rank's halo block has no state behind it to take the classes from)
-	bool const red_candidate = !sharded && !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
+	// (sharded: a rank's own blocks; its halo block has no state behind it to take the classes from and runs on all rows)
+	bool const red_candidate = !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
 	if ((rc = ensure_work_buffers(c, X, !red_candidate))) return rc;
 	// ---- phase C + D
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
@@ -2327,7 +2337,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
 		}
 		c->red_active = false;
-		if (!sharded && red_candidate && use_spec)
+		if (red_candidate && use_spec)
 		{
 			bool use = false;
 			if ((rc = red_plan(c, X, &use))) return rc;
@@ -2337,16 +2347,54 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 				if ((rc = red_columns(c))) return rc;
 				// the blocks that run on all rows, in one launch (no stride states: pass 2 reaches their boundaries from the block's start)
 				if (c->red_nfull) launch_columns(0, c->red_nfull, nullptr, 0, c->d_red_blocks + c->red_full_at);
+				// sharded: the block behind mine for as far as the halo reaches, on all rows (k_columns stops at n_c)
+				if (sharded && sh.c_end > sh.c_hi) launch_columns(b_hi, 1u);
 			}
 			else if ((rc = ensure_work_buffers(c, X, true))) return rc;      // (the stride states after all)
 		}
 		if (!sharded && !c->red_active) launch_columns(0, c->nblocks);
 		if (sync_at(c, 'C')) { fprintf(stderr, "[fseq] phase C queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase C done\n"); }
-		if (sharded && my_blocks)
+		if (sharded && my_blocks && !c->red_active)
 		{
 			// my blocks, and the block behind them for as far as the halo reaches (k_columns stops at n_c)
 			uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
 			launch_columns(b_lo, nb);
+		}
+		if (sharded && red_candidate && use_spec)
+		{
+			// the ranks agree on whether the attempt stands BEFORE the DP's exchanges: a rank whose lists could not be proven
+			// on the representatives (or whose plan's counts have changed) makes every rank run the attempt again
+			uint32_t mine[2] = {0u, 0u};
+			if (c->red_active)
+			{
+				HIP_TRY(c, hipMemcpyAsync(mine, c->d_red_invalid + c->nblocks, 8, hipMemcpyDeviceToHost, st));
+				HIP_TRY(c, hipStreamSynchronize(st));
+			}
+			uint32_t word = (mine[0] ? 1u : 0u) | (mine[1] ? 2u : 0u);
+			HIP_TRY(c, hipMemcpyAsync(sh.xbuf, &word, 4, hipMemcpyHostToDevice, st));
+			if ((rc = shard_exchange(c, 1, 1))) return rc;
+			uint32_t all = 0;
+			HIP_TRY(c, hipMemcpy(&all, sh.xbuf, 4, hipMemcpyDeviceToHost));
+			if (all)
+			{
+				if (mine[1]) c->red_plan_valid = false;
+				if (mine[0])
+				{
+					std::vector<uint32_t> inv(c->nblocks);
+					HIP_TRY(c, hipMemcpy(inv.data(), c->d_red_invalid, (size_t) c->nblocks * 4, hipMemcpyDeviceToHost));
+					uint32_t cnt = 0;
+					for (uint32_t b = b_lo; b < b_hi; ++b) if (inv[b] && !c->red_full[b]) { c->red_force_full[b] = 1; ++cnt; }
+					c->red_plan_valid = false;
+					R.redone += cnt;
+				}
+				R.redo = true; *overflow_out = false;
+				HIP_TRY(c, hipEventRecord(c->ev[4], st));
+				HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
+				HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
+				HIP_TRY(c, hipStreamWaitEvent(st, c->ev_part[15], 0));
+				{ float f = 0; HIP_TRY(c, hipEventSynchronize(c->ev[4])); HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); R.ms_c += f; }
+				return FSEQ_OK;
+			}
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
 		// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
@@ -2408,7 +2456,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	if (keyspace) HIP_TRY(c, hipMemcpyAsync(h_flags + 4, c->d_flags + 64, 12, hipMemcpyDeviceToHost, st));
 	h_flags[6 + 1] = 0; h_flags[6 + 2] = 0;
 	uint32_t *const h_red = h_flags + 7;                         // {a block's lists not proven, the plan's counts have changed}
-	if (c->red_active) HIP_TRY(c, hipMemcpyAsync(h_red, c->d_red_invalid + c->nblocks, 8, hipMemcpyDeviceToHost, st));
+	if (c->red_active && !sharded) HIP_TRY(c, hipMemcpyAsync(h_red, c->d_red_invalid + c->nblocks, 8, hipMemcpyDeviceToHost, st));      // (sharded: agreed on before the DP)
 	HIP_TRY(c, hipStreamSynchronize(st));
 	R.redo = false;
 	if (c->red_active && h_red[1])
@@ -2499,35 +2547,42 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 {
 	FSEQ_LONG_LOCALS(c);
-	size_t const S2 = c->segments.size();
-	if (!S2) return FSEQ_OK;
+	size_t const S2all = c->segments.size();
+	if (!S2all) return FSEQ_OK;
 	ChainSnapSet cs{};
 	if (!c->use_stream)
 	{
 		if (!select_chain_snap(ks.T, ks.E, &cs)) return fail(c, FSEQ_E_UNSUPPORTED, "pass 2: no chain step for this configuration");
 		HIP_TRY(c, cs.prepare());
 	}
-	c->snap_slot.assign(S2, -1);
-	std::vector<uint64_t> rbs(S2);
-	std::vector<uint32_t> task_blk(S2), ncls0(S2);
-	// tasks of reduced blocks by configuration: workgroups {block, first task, count}; tasks of the other blocks: old groups
+	c->snap_slot.assign(S2all, -1);
+	// my tasks (sharded: a boundary belongs to the rank whose blocks hold the state in front of it), in the order of the boundaries
+	std::vector<uint64_t> rbs;
+	std::vector<uint32_t> task_blk, ncls0;
+	// tasks of reduced blocks by configuration: workgroups {block, first task, count, start column}; tasks of the other blocks: old groups
 	struct Wg { uint32_t blk, first, count, start; };
 	std::vector<std::vector<Wg>> wgs((size_t) reduced_config_count());
 	std::vector<uint64_t> o_rbs, o_srcs;
 	std::vector<uint2> o_grp;
 	std::vector<uint32_t> o_slot;
 	uint64_t cells = 0;
-	for (size_t i = 0; i < S2; ++i)
+	for (size_t si = 0; si < S2all; ++si)
 	{
-		uint64_t const rb = c->segments[i].rb;
-		c->snap_slot[i] = (int64_t) i;
-		rbs[i] = rb;
+		uint64_t const rb = c->segments[si].rb;
+		if (sharded)
+		{
+			uint32_t const owner = (uint32_t) std::min<uint64_t>(rb / ((uint64_t) sh.bpr * c->B), sh.active - 1u);
+			if (owner != sh.rank) continue;
+		}
+		size_t const i = rbs.size();
+		c->snap_slot[si] = (int64_t) i;
+		rbs.push_back(rb);
 		bool const border = rb % c->B == 0;
 		uint32_t const blk = border ? (uint32_t) (rb / c->B) : (uint32_t) std::min<uint64_t>(rb / c->B, c->nblocks - 1u);
-		task_blk[i] = blk;
-		ncls0[i] = 0;                                             // a border: the copy; else the sweep fills it in
+		task_blk.push_back(blk);
+		ncls0.push_back(0u);                                       // a border: the copy; else the sweep fills it in
 		if (border) continue;
-		int const cf = c->red_config_snap_of[blk];
+		int const cf = blk < c->red_config_snap_of.size() ? c->red_config_snap_of[blk] : -1;
 		if (cf >= 0 && c->red_cnt_host[blk] != RED_NONE)
 		{
 			// the sweep starts at the last state phase C dropped in front of the boundary (or at the block's first column)
@@ -2546,6 +2601,25 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 			o_rbs.push_back(rb); o_slot.push_back((uint32_t) i);
 		}
 	}
+	size_t const S2 = rbs.size();
+	auto finish = [&]() -> int {
+		if (sharded)
+		{
+			// R of SURVEY.md 8(d) is the sum over the ranks: one slot pair per rank
+			uint32_t slots[2] = {(uint32_t) R.pass2_cells, (uint32_t) (R.pass2_cells >> 32)};
+			std::vector<uint32_t> all(2 * sh.world);
+			HIP_TRY(c, hipMemsetAsync(sh.xbuf, 0, all.size() * 4, st));
+			HIP_TRY(c, hipMemcpyAsync(sh.xbuf + 2 * sh.rank, slots, 8, hipMemcpyHostToDevice, st));
+			int rc2;
+			if ((rc2 = shard_exchange(c, all.size(), 0))) return rc2;
+			HIP_TRY(c, hipMemcpy(all.data(), sh.xbuf, all.size() * 4, hipMemcpyDeviceToHost));
+			R.pass2_cells = 0;
+			for (uint32_t g = 0; g < sh.world; ++g) R.pass2_cells += (uint64_t) all[2 * g] | ((uint64_t) all[2 * g + 1] << 32);
+			c->sh.closed = true;                                 // the last exchange of the run
+		}
+		return FSEQ_OK;
+	};
+	if (!S2) { R.pass2_cells = 0; return finish(); }
 	if (c->snap_cap < S2)
 	{
 		if ((rc = dev_alloc(c, &c->d_snap_a, S2 * (size_t) m))) return rc;
@@ -2672,7 +2746,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 	float f = 0;
 	HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); R.ms_p2 = f;
 	R.pass2_cells = cells;
-	return FSEQ_OK;
+	return finish();
 }
 
 // ---- pass 2: (a, d) at the merged boundaries

@@ -343,9 +343,10 @@ struct fseq_ctx {
 	// [r5] phase C / pass 2 on representative rows (fseq_reduced.hpp): per block [red_cap] representatives (ascending row id),
 	// their block keys, the reduced start state; the reduced alignment (column k at d_red_msa + k * red_ld)
 	uint32_t *d_red_cnt = nullptr, *d_red_vmin = nullptr, *d_red_rows = nullptr, *d_red_leaf = nullptr, *d_red_a = nullptr, *d_red_d = nullptr;
+	uint32_t *d_red_rows_alloc = nullptr, *d_red_leaf_alloc = nullptr, *d_red_a_alloc = nullptr, *d_red_d_alloc = nullptr;      // (a rank holds its own blocks' rows)
 	uint32_t *d_red_invalid = nullptr, *d_red_blocks = nullptr;
 	uint32_t red_cap = 0, red_blocks_cap = 0;
-	uint8_t *d_red_msa = nullptr;
+	uint8_t *d_red_msa = nullptr, *d_red_msa_alloc = nullptr;
 	size_t red_ld = 0, red_msa_bytes = 0;
 	std::vector<uint32_t> red_cnt_host;      // representatives per block of the last prep (RED_NONE: not reduced)
 	std::vector<uint8_t> red_full;           // blocks this run sends to the kernel on all rows
@@ -353,6 +354,7 @@ struct fseq_ctx {
 	bool red_active = false;                 // this run's phase C went through the representatives (pass 2 follows it)
 	uint32_t *d_red_cls = nullptr, *d_red_headd = nullptr, *d_red_ncls = nullptr, *d_red_taskblk = nullptr, *d_red_wgtasks = nullptr;
 	size_t red_task_cap = 0;
+	uint32_t *d_red_ss_a_alloc = nullptr, *d_red_ss_d_alloc = nullptr;
 	uint32_t *d_red_ss_a = nullptr, *d_red_ss_d = nullptr;      // the reduced states phase C drops every red_ss_stride columns ([q][red_ss_cap])
 	uint32_t red_ss_stride = 0, red_ss_cap = 0;
 	size_t red_ss_words = 0;
