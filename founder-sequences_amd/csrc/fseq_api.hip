@@ -2050,6 +2050,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		launch_reduce_check(st, c->d_red_cnt + b_lo, c->d_red_cnt_plan + b_lo, my_blocks, c->d_red_invalid + nbk);
 		if (!c->red_direct)
 			launch_reduce_msa(st, c->red_listed, c->red_max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+		c->tm.reduced_blocks = c->red_plan_blocks; c->tm.reduced_rows_mean = c->red_plan_rows_mean;
 		*use = true;
 		return FSEQ_OK;
 	}
@@ -2103,7 +2104,14 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (c->tune.debug)
 		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", my_blocks - n_full, my_blocks,
 		        c->tm.reduced_rows_mean, m, max_rows, n_full);
-	if ((uint64_t) n_full * 4u > my_blocks) return FSEQ_OK;
+	// worth it?  The run on all rows is the tuned one (three workgroups per CU, stride states for pass 2): the representatives
+	// take over where they are clearly fewer -- rows to update in all, a block on all rows counted as one and a half (its
+	// boundaries are reached from the block's start) -- below half of the rows (FSEQ_REDUCED_ALWAYS: tests)
+	{
+		uint64_t const rows_all = sum_rows + (uint64_t) n_full * m * 3u / 2u;
+		if (!c->tune.reduced_always && (rows_all * 2u > (uint64_t) my_blocks * m || (uint64_t) n_full * 4u > my_blocks)) return FSEQ_OK;
+		if ((uint64_t) n_full >= my_blocks) return FSEQ_OK;
+	}
 	if (n_full && c->use_stream && !c->s2.T) return FSEQ_OK;     // (the first form of the streamed kernel takes no block list)
 	if (!c->red_direct)
 	{
@@ -2149,6 +2157,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (!c->red_direct)
 		launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
 	c->red_plan_valid = true; c->red_plan_X = X;
+	c->red_plan_blocks = c->tm.reduced_blocks; c->red_plan_rows_mean = c->tm.reduced_rows_mean;
 	*use = true;
 	return FSEQ_OK;
 }
@@ -2337,7 +2346,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			HIP_TRY(c, hipEventRecord(c->ev_part[15], c->stream2));
 		}
 		c->red_active = false;
-		if (red_candidate && use_spec)
+		if (red_candidate)
 		{
 			bool use = false;
 			if ((rc = red_plan(c, X, &use))) return rc;
@@ -2360,7 +2369,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			uint32_t const nb = my_blocks + ((sh.c_end > sh.c_hi) ? 1u : 0u);
 			launch_columns(b_lo, nb);
 		}
-		if (sharded && red_candidate && use_spec)
+		if (sharded && red_candidate)
 		{
 			// the ranks agree on whether the attempt stands BEFORE the DP's exchanges: a rank whose lists could not be proven
 			// on the representatives (or whose plan's counts have changed) makes every rank run the attempt again
