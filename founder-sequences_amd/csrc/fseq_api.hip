@@ -2031,11 +2031,8 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_red_pin), (4 * (size_t) nbk + 64) * 4, hipHostMallocDefault));
 		c->red_pin_words = 4 * (size_t) nbk + 64;
 	}
-	if (!c->red_st[0])
-	{
-		for (auto &strm : c->red_st) HIP_TRY(c, hipStreamCreateWithFlags(&strm, hipStreamNonBlocking));
+	if (!c->red_ev[0])
 		for (auto &evt : c->red_ev) HIP_TRY(c, hipEventCreateWithFlags(&evt, hipEventDisableTiming));
-	}
 	// LDS-resident row counts: the representatives' symbols come from the alignment's own columns (a block stages whole columns)
 	c->red_direct = !c->use_stream;
 	RedPrepArgs A{};
@@ -2169,7 +2166,10 @@ int red_launch_all(fseq_ctx *c, std::vector<RedLaunch> const &ls, RedArgs const 
 {
 	FSEQ_LONG_LOCALS(c);
 	if (ls.empty()) return FSEQ_OK;
-	size_t const nside = std::min<size_t>(ls.size() - 1, 3);
+	// (side streams: the context's second stream first -- every further hardware queue in use slows the dependent launches of
+	// phase B, measured on BASELINE C3: 0.71 ms with none, 0.97 with three)
+	size_t const want_side = c->tune.reduced_serial ? 0u : (c->tune.reduced_side >= 0 ? (size_t) c->tune.reduced_side : 3u);
+	size_t const nside = std::min<size_t>(ls.size() - 1, std::min<size_t>(want_side, 3));
 	if (nside) HIP_TRY(c, hipEventRecord(c->red_ev[3], st));
 	for (size_t i = 0; i < ls.size(); ++i)
 	{
@@ -2182,7 +2182,12 @@ int red_launch_all(fseq_ctx *c, std::vector<RedLaunch> const &ls, RedArgs const 
 		RA.blocks = blocks + ls[i].first;
 		if (wg_tasks) RA.wg_tasks = wg_tasks + 3 * (size_t) ls[i].first;
 		// the largest launches on the side streams, the rest in turn on the context's
-		hipStream_t const s_ = (i >= 1 && i <= nside) ? c->red_st[i - 1] : st;
+		hipStream_t s_ = (i >= 1 && i <= nside) ? (i == 1 ? c->stream2 : c->red_st[i - 2]) : st;
+		if (s_ != st && s_ == nullptr)
+		{
+			HIP_TRY(c, hipStreamCreateWithFlags(&c->red_st[i - 2], hipStreamNonBlocking));
+			s_ = c->red_st[i - 2];
+		}
 		if (s_ != st) HIP_TRY(c, hipStreamWaitEvent(s_, c->red_ev[3], 0));
 		rs.launch(s_, ls[i].count, lds, c->red_direct ? c->d_msa : c->d_red_msa, c->red_direct ? c->ld : c->red_ld, n, c->B, (uint32_t) L, X, stride, ent, hdr, c->npass, c->bsh, RA);
 		if (s_ != st) HIP_TRY(c, hipEventRecord(c->red_ev[i - 1], s_));

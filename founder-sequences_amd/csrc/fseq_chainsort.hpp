@@ -68,14 +68,18 @@ __device__ __forceinline__ uint32_t cs_below(uint64_t mask)
 // key at the boundary's column -- instead of rk[row]
 __device__ __forceinline__ void chain_step_sorted(
 	uint32_t m, uint32_t const *__restrict__ rk, uint32_t const *__restrict__ kd, uint32_t nkeys,
-	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L, uint32_t const *__restrict__ cls = nullptr)
+	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L, uint32_t const *__restrict__ cls = nullptr,
+	uint32_t const *__restrict__ src_a = nullptr, uint32_t const *__restrict__ src_d = nullptr, uint32_t *__restrict__ dst_a = nullptr, uint32_t *__restrict__ dst_d = nullptr)
 {
+	// src_* / dst_* (pass 2): the order in front of the step is read where it lies, the order behind it written where it is wanted
+	// (the workspace then only holds the pairs and the range maxima)
 	uint32_t const tid = threadIdx.x, lane = lane_id();
 	uint32_t const wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 	constexpr uint32_t NW = ST / WAVE;
-	uint32_t const *a0 = w + (size_t) cur * 2u * m, *d0 = a0 + m;
+	uint32_t const *a0 = src_a ? src_a : w + (size_t) cur * 2u * m, *d0 = src_d ? src_d : w + (size_t) cur * 2u * m + m;
 	uint32_t *a1 = w + (size_t) (cur ^ 1u) * 2u * m, *d1 = a1 + m;
 	uint2 *const pairA = reinterpret_cast<uint2 *>(a1);                 // (the output buffers are free until step 3)
+	if (dst_a) { a1 = dst_a; d1 = dst_d; }
 	uint2 *const pairB = reinterpret_cast<uint2 *>(w + 4u * (size_t) m);
 	uint32_t *const pm = w + 6u * (size_t) m, *const sm = w + 7u * (size_t) m, *const tab = w + 8u * (size_t) m;
 	uint32_t const nblk = (m + 63u) / 64u;
@@ -291,11 +295,7 @@ __global__ __launch_bounds__(ST) void k_chain_snap_stream(
 			for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = bstate_a[sb + i]; snap_d[ob + i] = bstate_d[sb + i]; }
 			continue;
 		}
-		for (uint32_t i = tid; i < m; i += ST) { w[i] = bstate_a[sb + i]; w[(size_t) m + i] = bstate_d[sb + i]; }
-		__syncthreads();
-		chain_step_sorted(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap);
-		for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = w[2u * (size_t) m + i]; snap_d[ob + i] = w[3u * (size_t) m + i]; }
-		__syncthreads();
+		chain_step_sorted(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap, bstate_a + sb, bstate_d + sb, snap_a + ob, snap_d + ob);
 	}
 }
 

@@ -134,6 +134,8 @@ struct Tuning {
 	bool no_reduced = false;             // FSEQ_NO_REDUCED: phase C and pass 2 on all rows of every block (the form before round 5)
 	int  reduced_margin = -1;            // FSEQ_REDUCED_MARGIN: counts beyond the list capacity the choice of vmin allows for (tests: 0 makes lists dig below it)
 	bool reduced_always = false;         // FSEQ_REDUCED_ALWAYS: the representatives whenever some block has fewer of them than rows (tests of the mixed runs)
+	int  reduced_side = -1;              // FSEQ_REDUCED_SIDE: side streams the configurations' launches may use (0 .. 3)
+	bool reduced_serial = false;         // FSEQ_REDUCED_SERIAL: the configurations' launches one after the other on the context's stream (by itself: side by side)
 	bool reduced_ew = false;             // FSEQ_REDUCED_EW: small blocks on two-wave workgroups (the list on a wave of its own) instead of one wave
 	int  stream_block = 0;               // FSEQ_STREAM_BLOCK: columns per block the streamed regime aims for when phase C runs on representatives
 	int  reduced_cap = 0;                // FSEQ_REDUCED_CAP: most representatives a block may have (tests: small values send blocks to the run on all rows)
@@ -185,6 +187,8 @@ struct Tuning {
 		else if (n == "FSEQ_REDUCED_CAP") reduced_cap = on ? std::max(1, iv) : 0;
 		else if (n == "FSEQ_REDUCED_EW") reduced_ew = on;
 		else if (n == "FSEQ_REDUCED_ALWAYS") reduced_always = on;
+		else if (n == "FSEQ_REDUCED_SERIAL") reduced_serial = on;
+		else if (n == "FSEQ_REDUCED_SIDE") reduced_side = on ? std::max(0, std::min(3, iv)) : -1;
 		else if (n == "FSEQ_STREAM_BLOCK") stream_block = on ? std::max(64, iv) : 0;
 		else return false;
 		return true;
@@ -197,7 +201,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS", "FSEQ_REDUCED_SERIAL", "FSEQ_REDUCED_SIDE"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
@@ -374,7 +378,7 @@ struct fseq_ctx {
 	bool red_plan_valid = false;
 	uint32_t red_plan_X = 0, red_plan_blocks = 0, red_plan_rows_mean = 0;
 	uint32_t *d_red_cnt_plan = nullptr;
-	hipStream_t red_st[3]{};                 // the configurations' launches side by side
+	hipStream_t red_st[2]{};                 // the configurations' launches side by side: the context's second stream, then these
 	hipEvent_t red_ev[4]{};
 	uint8_t *h_red_pin2 = nullptr;           // pass 2's task lists (pinned)
 	size_t red_pin2_bytes = 0;
