@@ -5,16 +5,18 @@ One "step" = one complete pass of the hot path (everything segmentation_lp_conte
 pBWT pass 1 + DP, traceback, segment merge, pass-2 boundary states) over one synthetic
 founder-mosaic alignment that is already resident in HBM (column-major, 2 bits per cell for
 sigma <= 4, 4 bits for sigma <= 16, else 1 B).
-Workload at N=1: BASELINE.json configs[2] (C3: m=2,504 x n=1,000,000, sigma=4, L=100), the largest configuration
-BASELINE.json labels 1xMI355X (C2 is too small for a roofline fraction to mean anything).
+Workload at N=1 [r5]: BASELINE.json configs[3]'s alignment (C4: m=100,000 x n=5,000,000, sigma=4, L=200) -- the
+configuration the metric's 1/2/4/8-GPU curve is quoted on; its 125 GB of packed cells fit one MI355X.  The other
+single-GPU configurations (C2, C3, C5) are measured in child processes of the same invocation and reported under
+config.other_workloads (a failure or a hang there cannot take the headline line with it).
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-N > 1: ONE alignment (BASELINE.json configs[3], C4: m=100,000 x n=5,000,000, L=200) sharded over the ranks by
-contiguous column blocks (fseq_set_shard; exchanges through torch.distributed / RCCL, founder-sequences_amd/dist.py)
--> "scaling": "strong"; value = the alignment's cells / max-over-ranks time.
+N > 1: the SAME alignment sharded over the ranks by contiguous column blocks (fseq_set_shard; exchanges through
+torch.distributed / RCCL, founder-sequences_amd/dist.py) -> "scaling": "strong"; value = the alignment's cells /
+max-over-ranks time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -47,6 +49,10 @@ WORKLOADS = {
     # BASELINE C4's rows (m = 100,000: HBM-streamed block state) on a column prefix, and C4 itself
     # (5e11 cells = 125 GB at 2 bits per cell: one MI355X holds it; one step takes tens of seconds)
     "C4cols50k": dict(m=100000, n=50000, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0),
+    # [r5] a slice of C4 with the FULL run's geometry (512 blocks of 814 columns: two rounds of the 256 CUs' workgroups of the
+    # reduced column kernel, stride states every 32 columns) -- what the PMC passes are taken on (the full C4 under
+    # rocprofv3 --pmc is a quarter of an hour per pass); its per-cell figures are carried over to C4
+    "C4slice": dict(m=100000, n=416768, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0, block_len=814),
     "C4": dict(m=100000, n=5000000, L=200, K=64, B=10000, mu=5e-5, seed=0x5EED0004, kind=0),
 }
 
@@ -84,81 +90,76 @@ def load_pmc_summary(workload):
 
 
 def load_pmc(workload):
-    """(HBM bytes per step and phase, source) from load_pmc_summary; (None, reason) without one."""
+    """(HBM bytes per step and phase, source) from load_pmc_summary; (None, reason) without one.  C4: the passes are taken on
+    C4slice -- 512 blocks of the full run's geometry -- and its bytes carried over per cell."""
     d = load_pmc_summary(workload)
+    scale, note = 1.0, ""
+    if d is None and workload == "C4":
+        d = load_pmc_summary("C4slice")
+        if d is not None:
+            scale = (WORKLOADS["C4"]["m"] * WORKLOADS["C4"]["n"]) / float(WORKLOADS["C4slice"]["m"] * WORKLOADS["C4slice"]["n"])
+            note = "; taken on C4slice (512 of C4's blocks, the full run's geometry), scaled by cells"
     if d is None:
         return None, "no PMC summary under profiles/ for workload %s on kernel sources %s" % (workload, csrc_sha())
-    return d["phases_hbm_bytes_per_step"], d["_path"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950)"
+    return ({k: v * scale for k, v in d["phases_hbm_bytes_per_step"].items()},
+            d["_path"] + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE x2 on gfx950%s)" % note)
 
 
 N_SIMD = 1024                   # 256 CUs x 4 SIMDs (MI355X_MICROARCH.md)
 NOMINAL_CLOCK_GHZ = 2.4
 
 
-def dominant_kernel_bound(workload, m, n, avg_launch_ms):
-    """What bounds the dominant kernel (phase C), from the PMC passes committed for THIS workload on THESE kernel
-    sources and the launch duration measured live.
+def dominant_kernel_bound(workload, m, n, phase_c_ms, reduced):
+    """What bounds phase C (the per-column update + lists: the phase the step spends most of its time in), from the PMC
+    passes committed for THIS workload on THESE kernel sources and the phase's time measured live.
 
-    LDS-resident kernels (k_columns): the order (a, d) of a block never leaves LDS, so HBM bytes bound nothing;
-    the SIMDs' vector issue does.  frac = SQ_ACTIVE_INST_VALU [quad-cycles, summed over the SIMDs] x 4 /
-    (1024 SIMDs x clock x launch time): the share of all vector issue slots of the launch that issued.  The clock is
-    the effective one of the profiled launch (GRBM_GUI_ACTIVE / 8 XCDs / its duration, MI355X_MICROARCH.md "DVFS
-    give-back"), not an assumed 2.4 GHz.  The LDS pipe's share is put beside it in the same normalisation.
-    Streamed kernel (k_columns_stream2: the order streams through HBM / L2): the HBM fraction priced at the bytes the PMC
-    passes counted (FETCH_SIZE x 2 + WRITE_SIZE), not at the 17 B/cell of the formula, and the vector issue fraction as
-    above; `bound` names the one nearer its ceiling, both are in the line."""
+    [r5] Phase C runs on the blocks' representative rows (k_columns_red, several configurations side by side), whose order
+    lives in LDS: HBM bytes bound nothing, the SIMDs' vector issue does.  frac = SQ_ACTIVE_INST_VALU [quad-cycles, summed over
+    the SIMDs and the phase's kernels] x 4 / (1024 SIMDs x clock x phase time): the share of all vector issue slots of the
+    phase that issued.  The clock is the effective one of the profiled launches (GRBM_GUI_ACTIVE / 8 XCDs / duration), not an
+    assumed 2.4 GHz.  The HBM share -- the bytes the PMC passes counted (FETCH_SIZE x 2 + WRITE_SIZE) over the phase time
+    against 8 TB/s -- is put beside it; `bound` names the one nearer its ceiling.  C4's counters are taken on a slice with the
+    full run's geometry (C4slice: 512 blocks of 814 columns) and carried over per cell."""
     d = load_pmc_summary(workload)
     prefix = None
     if d is None and workload == "C4":
-        # the full C4 under rocprofv3 --pmc is a quarter of an hour per pass: its kernels are profiled on the 50,000-column
-        # prefix (same rows, same tiles, same kernel) and the per-cell figures carried over
-        d = load_pmc_summary("C4cols50k")
-        prefix = "C4cols50k"
-    if d is None or "issue" not in d:
-        return {"bound": None, "frac": None, "note": "no PMC issue summary under profiles/ for workload %s on kernel sources %s "
+        d = load_pmc_summary("C4slice")
+        prefix = "C4slice"
+    if d is None or "phase_totals_per_step" not in d or "phase_c" not in d["phase_totals_per_step"]:
+        return {"bound": None, "frac": None, "note": "no PMC phase summary under profiles/ for workload %s on kernel sources %s "
                 "(profiles/collect_profiles.sh + summarize_pmc.py write it)" % (workload, csrc_sha())}
-    name = None
-    for k, v in d["issue"].items():
-        if "k_columns" in k and "prologue" not in k and (name is None or v.get("avg_ns", 0) > d["issue"][name].get("avg_ns", 0)):
-            name = k
-    if name is None:
-        return {"bound": None, "frac": None, "note": "no k_columns kernel in " + d["_path"]}
-    c = d["issue"][name]
+    c = d["phase_totals_per_step"]["phase_c"]
     scale = 1.0
     if prefix:
         scale = (m * n) / float(WORKLOADS[prefix]["m"] * WORKLOADS[prefix]["n"])
     clock_ghz = c.get("clock_ghz_effective") or NOMINAL_CLOCK_GHZ
-    cycles = clock_ghz * 1e9 * avg_launch_ms * 1e-3
+    cycles = clock_ghz * 1e9 * phase_c_ms * 1e-3
     valu_q = c.get("SQ_ACTIVE_INST_VALU", 0.0) * scale
     lds_q = c.get("SQ_ACTIVE_INST_LDS", 0.0) * scale
     conflict = c.get("SQ_LDS_BANK_CONFLICT", 0.0) * scale
+    allph = d["phase_totals_per_step"]
     out = {
-        "kernel": name,
-        "source": d["_path"] + (" (per-cell figures of the %s prefix scaled to the full workload)" % prefix if prefix else ""),
+        "kernel": "k_reduce_prep + k_reduce_msa + k_columns_red<*> (every configuration of the phase)" if reduced else "k_columns / k_columns_stream2",
+        "source": d["_path"] + (" (per-cell figures of the %s slice -- the full run's block geometry -- scaled to the full workload)" % prefix if prefix else ""),
         "clock_ghz": round(clock_ghz, 3),
-        "clock_source": "GRBM_GUI_ACTIVE / 8 / duration of the profiled launch" if c.get("clock_ghz_effective") else "nominal (no GRBM pass in the summary)",
+        "clock_source": "GRBM_GUI_ACTIVE / 8 / duration of the profiled launches" if c.get("clock_ghz_effective") else "nominal (no GRBM pass in the summary)",
         "lane_instructions_per_cell": round(c.get("SQ_INSTS_VALU", 0.0) * scale * 64.0 / (m * n), 2),
+        "lane_instructions_per_cell_whole_step": round(sum(g.get("SQ_INSTS_VALU", 0.0) for g in allph.values()) * scale * 64.0 / (m * n), 2),
         "valu_issue_frac": round(valu_q * 4.0 / (N_SIMD * cycles), 4) if cycles else None,
         "lds_issue_frac": round(lds_q * 4.0 / (N_SIMD * cycles), 4) if cycles else None,
         "lds_bank_conflict_over_lds_active": round(conflict / lds_q, 3) if lds_q else None,
         "salu_over_valu_insts": round(c.get("SQ_INSTS_SALU", 0.0) / c["SQ_INSTS_VALU"], 3) if c.get("SQ_INSTS_VALU") else None,
-        "pmc_hbm_bytes_per_launch": c.get("hbm_bytes_per_launch_corrected", 0.0) * scale,
+        "pmc_hbm_bytes_per_step": c.get("hbm_bytes_corrected", 0.0) * scale,
     }
-    hbm_frac = out["pmc_hbm_bytes_per_launch"] / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if avg_launch_ms else None
+    hbm_frac = out["pmc_hbm_bytes_per_step"] / (phase_c_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS if phase_c_ms else None
     out["hbm_frac_pmc_bytes"] = round(hbm_frac, 4) if hbm_frac is not None else None
-    if "stream" in name:
-        # the order streams through HBM / L2: the PMC bytes against the HBM peak, or the vector issue slots -- whichever is
-        # nearer its ceiling (with the narrow blocks of round 4, 8.9 B per cell, the issue slots are; both stay in the line)
-        out["pmc_bytes_per_cell"] = round(out["pmc_hbm_bytes_per_launch"] / (m * n), 2)
-        if (out["valu_issue_frac"] or 0.0) > (out["hbm_frac_pmc_bytes"] or 0.0):
-            out["bound"] = "valu_issue"
-            out["frac"] = out["valu_issue_frac"]
-        else:
-            out["bound"] = "hbm"
-            out["frac"] = out["hbm_frac_pmc_bytes"]
-    else:
+    out["pmc_bytes_per_cell"] = round(out["pmc_hbm_bytes_per_step"] / (m * n), 3)
+    if (out["valu_issue_frac"] or 0.0) >= (out["hbm_frac_pmc_bytes"] or 0.0):
         out["bound"] = "valu_issue"
         out["frac"] = out["valu_issue_frac"]
+    else:
+        out["bound"] = "hbm"
+        out["frac"] = out["hbm_frac_pmc_bytes"]
     return out
 
 
@@ -278,7 +279,7 @@ def rowshard_leg(args, w, pkg, fdist, torch, dist, rank, world, local_rank, rehe
 
 
 # BASELINE.json's other single-GPU configurations measured beside the headline: (steps, warm-up)
-OTHER_WORKLOADS = {"C2": (20, 3), "C5": (5, 2), "C4": (2, 1)}
+OTHER_WORKLOADS = {"C2": (20, 3), "C3": (20, 5), "C5": (10, 3)}
 
 
 def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank, local_rank, rehearsal):
@@ -286,7 +287,7 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
     sides, max over ranks); returns {"line": the JSON line without cpu_baseline, "ctx": the context, "extra": []}."""
     w = dict(WORKLOADS[name])
     m, n, L = w["m"], w["n"], w["L"]
-    ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len, list_cap=args.list_cap, device=local_rank)
+    ctx = pkg.SegmentationContext(m, n, L, block_len=args.block_len or w.get("block_len", 0), list_cap=args.list_cap, device=local_rank)
     transport = None
     if world > 1:
         # ONE alignment over the ranks: this rank generates and keeps its own column blocks only
@@ -322,7 +323,14 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
             for k in ("ms_phase_a", "ms_phase_b", "ms_phase_c", "ms_dp", "ms_pass2", "ms_host", "ms_total"):
                 phase[k] = phase.get(k, 0.0) + t[k]
 
-    for _ in range(warmup):
+    # the first run on a fresh context, timed by itself: allocation of the work buffers, the list-capacity estimate, the plan
+    # of the reduced phase C -- what a one-shot caller (the CLI) pays.  It counts as the first warm-up step.
+    torch.cuda.synchronize()
+    t_cold = time.perf_counter()
+    step()
+    torch.cuda.synchronize()
+    cold_ms = (time.perf_counter() - t_cold) * 1e3
+    for _ in range(max(0, warmup - 1)):
         step()
     counted["on"] = True
     # barrier + torch.cuda.synchronize() on both sides of exactly `steps` steps, max over ranks
@@ -344,12 +352,14 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
     # bytes rocprofv3 counted (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section)
     pmc, pmc_src = load_pmc(name)
     launches_c = 1 + t["retries"]
+    reduced = t["reduced_blocks"] > 0
     kernels = {
-        "phase_a k_blockkeys (block keys ranked in key space)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
-        "phase_b k_chain (boundary states)": {"ms": ph["ms_phase_b"], "algorithmic_bytes": 0},
-        "phase_c k_columns (per-column update + lists)": {"ms": ph["ms_phase_c"], "algorithmic_bytes": BYTES_PER_CELL * m * n * launches_c},
+        "phase_a k_blockkeys / k_blocktrie (block keys ranked in key space)": {"ms": ph["ms_phase_a"], "algorithmic_bytes": BYTES_PER_CELL * m * n},
+        "phase_b k_chain / k_cm_* (boundary states)": {"ms": ph["ms_phase_b"], "algorithmic_bytes": 0},
+        ("phase_c k_reduce_prep + k_columns_red (per-column update + lists on the blocks' representative rows)" if reduced else
+         "phase_c k_columns (per-column update + lists)"): {"ms": ph["ms_phase_c"], "algorithmic_bytes": BYTES_PER_CELL * m * n * launches_c},
         "phase_d k_dp<SPEC> sweeps + rebuild kernels": {"ms": ph["ms_dp"], "algorithmic_bytes": 0},
-        "pass_2 k_colblock<SNAP>": {"ms": ph["ms_pass2"], "algorithmic_bytes": BYTES_PER_CELL * R},
+        ("pass_2 k_columns_red (class tables) + k_chain_snap (one chain step per boundary)" if reduced else "pass_2 k_colblock<SNAP>"): {"ms": ph["ms_pass2"], "algorithmic_bytes": BYTES_PER_CELL * R},
         "host (traceback walk, merge, copies)": {"ms": ph["ms_host"], "algorithmic_bytes": 0},
     }
     traffic = None
@@ -366,17 +376,21 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
     # the dominant kernel: what really bounds it (VALU issue for the LDS-resident kernels, PMC-counted HBM bytes for the
     # streamed one); the 17 B/cell figure stays as `algorithmic_frac` -- an accounting device that can exceed 1 because
     # the order of a block never leaves LDS
-    dom = dominant_kernel_bound(name, m, n, ms_c / launches_c)
+    dom = dominant_kernel_bound(name, m, n, ms_c / launches_c, reduced)
     dom_out = {
-        "name": "k_columns (phase C: per-column pBWT update + divergence-histogram top list, one launch over all column blocks)",
+        "name": ("phase C on the blocks' representative rows: k_reduce_prep, k_reduce_msa (streamed rows), k_columns_red in the configurations that hold "
+                 "the blocks, side by side -- the per-column pBWT update + divergence-histogram top list" if reduced else
+                 "k_columns (phase C: per-column pBWT update + divergence-histogram top list, one launch over all column blocks)"),
         "avg_launch_ms": ms_c / launches_c,
         "bound": dom.get("bound"),
         "frac": dom.get("frac"),
         "algorithmic_bytes_per_launch": BYTES_PER_CELL * m * n,
         "algorithmic_achieved_GBps": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9,
         "algorithmic_frac": BYTES_PER_CELL * m * n / (ms_c / launches_c * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-        "algorithmic_frac_note": "17 B/cell over the launch time against 8 TB/s: NOT a fraction of anything for the LDS-resident kernels "
-                                 "(it may exceed 1: the order (a, d) of a block never leaves LDS); `frac` is the bound that can be approached",
+        "algorithmic_frac_note": "17 B/cell over the phase time against 8 TB/s: NOT a fraction of anything (it exceeds 1): the order (a, d) of a block "
+                                 "never leaves LDS, and since round 5 a column updates the block's representative rows only -- the rows that "
+                                 "can differ in what the DP reads --, not all m; `frac` is the bound that can be approached",
+        "rows_updated_per_column_mean": t["reduced_rows_mean"] if reduced else m,
     }
     dom_out.update({k: v for k, v in dom.items() if k not in ("bound", "frac")})
     out = {
@@ -407,6 +421,8 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
             # round 4 the N = 1 line also carries it under config.other_workloads)
             "single_gpu_same_workload": single_gpu_reference(name) if world > 1 else None,
             "alignments_in_flight_per_gpu": max(1, args.concurrent),
+            "cold_first_run_ms": round(cold_ms, 3),
+            "reduced_blocks": t["reduced_blocks"], "reduced_rows_mean": t["reduced_rows_mean"], "reduced_redone": t["reduced_redone"],
             "block_len": t["block_len"], "n_blocks": t["n_blocks"], "list_cap": t["list_cap_used"],
             "dp_chunks": t["dp_chunks"], "dp_sweeps": t["dp_sweeps"],
             "segments": int(res.segment_count), "dp_segments": int(res.dp_segment_count),
@@ -418,8 +434,10 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
         },
         "roofline": {
             "bound": "hbm",
-            "scope": "whole path, SURVEY.md 8(d): 17 B x (m*n + R) / step time; the block state lives in LDS, so the bytes "
-                     "HBM really moves (traffic) are far below this algorithmic figure; the kernel-level bound is under dominant_kernel",
+            "scope": "whole path, SURVEY.md 8(d)'s ACCOUNTING figure: 17 B x (m*n + R) / step time -- what a column-at-a-time implementation that "
+                     "streams (a, d) of all m rows through HBM would move.  This implementation keeps a block's order in LDS and updates its "
+                     "representative rows only, so frac exceeds 1 and is not a fraction of a physical limit; the bytes HBM really moves are under "
+                     "`traffic` (hbm_frac_measured = traffic / step time / peak), the bound that can be approached under dominant_kernel",
             "achieved": path_gbps,
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",
@@ -427,6 +445,7 @@ def run_workload(pkg, fdist, torch, dist, name, steps, warmup, args, world, rank
             "frac_vs_measured_copy_6290": path_gbps / 6290.0,
             "traffic": traffic,
             "traffic_source": pmc_src,
+            "hbm_frac_measured": (traffic / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS) if traffic else None,
             "algorithmic_bytes_per_step": path_bytes,
             "dominant_kernel": dom_out,
             "kernels": kernels,
@@ -450,7 +469,7 @@ def main():
     ap.add_argument("--concurrent", type=int, default=1,
                     help="alignments in flight per GPU (one context + host thread each); 1 = the headline single-alignment workload")
     ap.add_argument("--no-other-workloads", action="store_true",
-                    help="N = 1 without --workload also measures C2, C5 and C4 (config.other_workloads); this skips them")
+                    help="N = 1 without --workload also measures C2, C3 and C5 in child processes (config.other_workloads); this skips them")
     ap.add_argument("--rowshard-cols", type=int, default=0,
                     help="instead of the headline step: the north-star row split (fseq_rowshard_pbwt) over this many columns of the "
                          "workload, one JSON line of its own (columns/s; latency-bound by design, DESIGN.md section 6)")
@@ -486,7 +505,7 @@ def main():
     fdist = importlib.import_module("founder-sequences_amd.dist")
     headline_default = args.workload is None
     if args.workload is None:
-        args.workload = "C3" if world == 1 else "C4"
+        args.workload = "C4"
     w = dict(WORKLOADS[args.workload])
     m, n, L = w["m"], w["n"], w["L"]
     if args.rowshard_cols:
@@ -522,24 +541,28 @@ def main():
     ctx.close()
     for e in run["extra"]:
         e.close()
-    # The other single-GPU configurations of BASELINE.json, each with its own small step count, in the same invocation
-    # (only when the driver's plain command is run: no --workload given): C2 (configs[1]), C5 (configs[4]'s alignment on
-    # one GPU) and C4 (configs[3]'s alignment on ONE GPU: the N = 1 anchor of the scaling curve).  Not part of `value`.
+    # The other single-GPU configurations of BASELINE.json, each with its own step count, in the same invocation (only when
+    # the driver's plain command is run: no --workload given): C2 (configs[1]), C3 (configs[2]) and C5 (configs[4]'s
+    # alignment on one GPU).  Each in a CHILD PROCESS of its own with a time limit: a failure, a hang or a GPU fault there
+    # cannot take the headline line with it.  Not part of `value`.
     if world == 1 and headline_default and not args.no_other_workloads and args.concurrent == 1:
+        import subprocess
         others_out = {}
         for name, (k_steps, k_warm) in OTHER_WORKLOADS.items():
             t0 = time.perf_counter()
             try:
-                r = run_workload(pkg, fdist, torch, dist, name, k_steps, k_warm, args, world, rank, local_rank, rehearsal)
-                r["ctx"].close()
-                ln = r["line"]
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(k_steps), "--warmup", str(k_warm),
+                                     "--no-cpu-baseline", "--no-other-workloads"], capture_output=True, text=True, timeout=300)
+                ln = json.loads(cp.stdout.strip().splitlines()[-1])
                 others_out[name] = {
                     "value": ln["value"], "unit": "cells/s", "ms_per_step": ln["ms_per_step"], "steps": k_steps, "warmup": k_warm,
                     "workload": ln["config"]["workload"], "phases_ms": ln["config"]["phases_ms"], "pass2_cells": ln["config"]["pass2_cells"],
+                    "cold_first_run_ms": ln["config"]["cold_first_run_ms"],
+                    "reduced_blocks": ln["config"]["reduced_blocks"], "reduced_rows_mean": ln["config"]["reduced_rows_mean"],
                     "block_len": ln["config"]["block_len"], "n_blocks": ln["config"]["n_blocks"], "list_cap": ln["config"]["list_cap"],
                     "dp_sweeps": ln["config"]["dp_sweeps"], "segments": ln["config"]["segments"], "max_segment_size": ln["config"]["max_segment_size"],
                     "path_frac": ln["roofline"]["frac"], "path_achieved_GBps": ln["roofline"]["achieved"],
-                    "traffic": ln["roofline"]["traffic"],
+                    "traffic": ln["roofline"]["traffic"], "hbm_frac_measured": ln["roofline"]["hbm_frac_measured"],
                     "dominant_kernel": ln["roofline"]["dominant_kernel"],
                     "wall_s_incl_setup": round(time.perf_counter() - t0, 2),
                 }

@@ -26,11 +26,27 @@ def find(pattern):
 
 
 def per_kernel(path):
-    """{kernel: {counter: (sum, launches, summed dispatch duration in ns)}} from a rocprofv3 counter_collection.csv"""
+    """{kernel: {counter: (sum, launches, summed dispatch duration in ns)}} from a rocprofv3 counter_collection.csv.
+    [r5] k_columns_red runs twice per step under one name: with the lists as its output (phase C) and with the class tables
+    (pass 2's sweeps, behind the DP); the dispatches behind a k_dp / k_tb_* launch and in front of the next phase A get the
+    suffix " #tables" so that the two are accounted apart."""
     acc = {}
     with open(path, newline="") as f:
-        for row in csv.DictReader(f):
-            name = row["Kernel_Name"].split("(")[0]
+        rows = list(csv.DictReader(f))
+    disp = {}
+    for row in rows:
+        disp.setdefault(int(row["Dispatch_Id"]), row["Kernel_Name"].split("(")[0])
+    behind_dp = False
+    suffix = {}
+    for did in sorted(disp):
+        nm = disp[did]
+        if "k_blockkeys" in nm or "k_blocktrie" in nm or "k_colblock<" in nm and ", 0," in nm or "k_synth" in nm:
+            behind_dp = False
+        if "k_dp<" in nm or "k_tb_" in nm:
+            behind_dp = True
+        suffix[did] = " #tables" if (behind_dp and "k_columns_red" in nm) else ""
+    for row in rows:
+            name = row["Kernel_Name"].split("(")[0] + suffix[int(row["Dispatch_Id"])]
             a = acc.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0, 0.0])
             a[0] += float(row["Counter_Value"])
             a[1] += 1
@@ -54,11 +70,13 @@ def phase_of(name):
     mo = re.search(r"k_colblock<[^>]*?,\s*(\d),\s*(true|false)>", name) or re.search(r"k_colblock_stream<(\d)>", name)
     if mo:
         return "phase_a" if mo.group(1) == "0" else "pass_2"
-    if "k_blockkeys" in name:
+    if "k_blockkeys" in name or "k_blocktrie" in name:
         return "phase_a"
-    if "k_chain" in name or "k_boundary_recent" in name:
+    if "#tables" in name or "k_chain_snap" in name:
+        return "pass_2"
+    if "k_chain" in name or "k_boundary_recent" in name or "k_cm_" in name:
         return "phase_b"
-    if "k_columns" in name:
+    if "k_columns" in name or "k_reduce_" in name:
         return "phase_c"
     if "k_dp<" in name or "k_spec_" in name:
         return "phase_d"
@@ -126,6 +144,27 @@ def main():
         if k in kernels:
             d["hbm_bytes_per_launch_corrected"] = kernels[k]["hbm_bytes_per_launch_corrected"]
         issue[k] = d
+    # [r5] per phase and step: every SQ counter summed over the phase's kernels (phase C is several configurations of
+    # k_columns_red side by side: bench.py prices the phase, not one of its launches)
+    groups = {}
+    for k, cs in counters.items():
+        ph = phase_of(k)
+        if not ph:
+            continue
+        g = groups.setdefault(ph, {})
+        for cname, v in cs.items():
+            if cname.startswith("SQ_"):
+                g[cname] = g.get(cname, 0.0) + v["sum"] / nsteps
+        if k in kernels:
+            g["hbm_bytes_corrected"] = g.get("hbm_bytes_corrected", 0.0) + kernels[k]["hbm_bytes_per_step_corrected"]
+        gr = cs.get("GRBM_GUI_ACTIVE")
+        if gr and gr.get("duration_ns"):
+            g["_grbm"] = g.get("_grbm", 0.0) + gr["sum"]
+            g["_grbm_ns"] = g.get("_grbm_ns", 0.0) + gr["duration_ns"]
+    for g in groups.values():
+        if g.get("_grbm_ns"):
+            g["clock_ghz_effective"] = g["_grbm"] / 8.0 / g["_grbm_ns"]
+        g.pop("_grbm", None); g.pop("_grbm_ns", None)
     out = {
         "command": "rocprofv3 --pmc <COUNTER> --output-format csv -- python3 bench.py --workload %s --steps 5 --warmup 2 "
                    "--no-cpu-baseline --no-batched (one pass per counter set, profiles/collect_profiles.sh)" % workload,
@@ -138,6 +177,7 @@ def main():
         "issue_units": "SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES / SQ_WAIT_* in quad-cycles summed over the SIMDs, SQ_INSTS_* in wave-instructions, "
                        "GRBM_GUI_ACTIVE in cycles summed over the 8 XCDs; averages per launch",
         "issue": issue,
+        "phase_totals_per_step": groups,
     }
     with open(os.path.join(HERE, "%s_pmc_traffic_%s.json" % (prefix, workload)), "w") as f:
         json.dump(out, f, indent=1)
