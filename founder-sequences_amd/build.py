@@ -21,11 +21,27 @@ def hipcc():
     raise RuntimeError("hipcc not found")
 
 
+FLAGS_FILE = os.path.join(OBJ_DIR, "hipcc_flags.txt")
+
+
+def extra_flags():
+    return os.environ.get("FSEQ_HIPCC_FLAGS", "").split()
+
+
 def needs_build():
+    """Out of date: a source is newer than the library, or the library was built with other FSEQ_HIPCC_FLAGS than the ones in
+    force now (a diagnostic build -- cycle stamps -- must not be taken for the product: its library is newer than every source)."""
     if not os.path.exists(OUT):
         return True
     t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    if any(os.path.getmtime(d) > t for d in DEPS):
+        return True
+    try:
+        with open(FLAGS_FILE) as f:
+            built_with = f.read().split()
+    except OSError:
+        built_with = []
+    return built_with != extra_flags()
 
 
 LAST_ACTION = {}        # target -> "compiled" | "reused": what the last build() / build_cli() / build_aux() call did
@@ -39,7 +55,7 @@ def build(force=False, verbose=False):
     # FSEQ_HIPCC_FLAGS: extra flags for diagnostic builds (-DFSEQ_DP_STAMPS, -DFSEQ_DP_STATS)
     # roctx ranges per phase when the image has the library (rocprofv3 --marker-trace shows them)
     have_roctx = os.path.exists("/opt/rocm/lib/librocprofiler-sdk-roctx.so") and os.path.exists("/opt/rocm/include/rocprofiler-sdk-roctx/roctx.h")
-    cflags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + os.environ.get("FSEQ_HIPCC_FLAGS", "").split() + (["-DFSEQ_WITH_ROCTX"] if have_roctx else [])
+    cflags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + extra_flags() + (["-DFSEQ_WITH_ROCTX"] if have_roctx else [])
     ldflags = ["-L/opt/rocm/lib", "-lrocprofiler-sdk-roctx", "-Wl,-rpath,/opt/rocm/lib"] if have_roctx else []
     os.makedirs(OBJ_DIR, exist_ok=True)
     # the translation units side by side (the kernel TU is ~50 s of hipcc, the joiners a few)
@@ -59,6 +75,8 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    with open(FLAGS_FILE, "w") as f:
+        f.write(" ".join(extra_flags()))
     return OUT
 
 

@@ -2218,7 +2218,10 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	// [r5] phase C on representative rows: the default wherever the lists are consumed by the speculative DP behind phase C
 	// (sharded: a rank's own blocks; its halo block has no state behind it to take the classes from and runs on all rows)
 	bool const red_candidate = !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
+	double const t_att = now_ms();
+	auto mark = [&](char const *what) { if (c->tune.debug) fprintf(stderr, "[fseq]   attempt +%.3f ms %s\n", now_ms() - t_att, what); };
 	if ((rc = ensure_work_buffers(c, X, !red_candidate))) return rc;
+	mark("lists allocated");
 	// ---- phase C + D
 #if defined(FSEQ_DP_STAMPS) || defined(FSEQ_DP_STATS)
 	HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 1024, st));
@@ -2355,10 +2358,12 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		{
 			bool use = false;
 			if ((rc = red_plan(c, X, &use))) return rc;
+			mark("reduced plan");
 			if (use)
 			{
 				c->red_active = true;
 				if ((rc = red_columns(c))) return rc;
+				mark("reduced columns queued");
 				// the blocks that run on all rows, in one launch (no stride states: pass 2 reaches their boundaries from the block's start)
 				if (c->red_nfull) launch_columns(0, c->red_nfull, nullptr, 0, c->d_red_blocks + c->red_full_at);
 				// sharded: the block behind mine for as far as the halo reaches, on all rows (k_columns stops at n_c)
@@ -2460,6 +2465,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[5], st));
 	HIP_TRY(c, hipGetLastError());
+	mark("DP queued");
 
 	if ((rc = pin_reserve(c, 64))) return rc;
 	uint32_t *const h_flags = pin_take<uint32_t>(c, 12);
@@ -2921,14 +2927,21 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	c->tm.n_blocks = c->nblocks;
 	double const t_begin = now_ms();
 
+	// (FSEQ_DEBUG: where the host's wall time of a run goes -- a first run on a context allocates, loads code objects, plans)
+	auto mark = [&](char const *what) { if (c->tune.debug) fprintf(stderr, "[fseq] +%.3f ms %s\n", now_ms() - t_begin, what); };
 	if ((rc = ensure_work_buffers(c, 0))) return rc;
+	mark("work buffers");
 	if ((rc = long_phase_a(c, R))) return rc;
+	mark("phase A queued");
 	if ((rc = long_phase_b(c, R))) return rc;
+	mark("phase B queued");
 	if ((rc = long_list_capacity(c, R))) return rc;
+	mark("list capacity");
 	while (true)
 	{
 		bool overflow = false;
 		if ((rc = long_attempt(c, R, &overflow))) return rc;
+		mark("attempt done");
 		if (R.redo) continue;                  // (the same capacity; the blocks that were flagged run on all rows now)
 		// (sharded: the thresholds are the same on every rank, so every rank takes the same way here)
 		if (!overflow) break;
@@ -2940,6 +2953,7 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	c->X_hint = R.X;                         // later runs on this context start with the capacity that worked
 	c->res.segment_count = c->segments.size();
 	if ((rc = long_pass2(c, R))) return rc;
+	mark("pass 2 done");
 	uint32_t const X = R.X, retries = R.retries;
 	double const ms_c = R.ms_c, ms_dp = R.ms_dp, ms_host = R.ms_host, ms_p2 = R.ms_p2;
 	uint64_t const pass2_cells = R.pass2_cells;
