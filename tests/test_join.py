@@ -213,3 +213,78 @@ def test_config_c2_full_size_founders_match_the_oracle():
     operm = go.greedy_match(m, ref["max_segment_size"], segs, ref["a"], ref["d"])
     want = hashlib.sha256(b"".join(x + b"\n" for x in go.founders(msa, segs, operm, ref["max_segment_size"]))).hexdigest()
     assert got == want
+
+
+@pytest.mark.gpu
+def test_config_c3_full_size_bipartite_joiner_against_independent_checks(tmp_path):
+    """BASELINE config C3 -- the configuration that names --segment-joining=bipartite-matching -- at full size (m = 2,504 x
+    n = 1,000,000, L = 100) through the library's own path (device segmentation, fseq_join_bipartite), checked against things
+    the library did not compute: for 240 adjacent segment pairs spread over the alignment the total |rows_l n rows_r| its
+    chained permutations realise equals the OPTIMAL weight of the pair's assignment problem by scipy's solver on classes
+    rebuilt from the boundary states with oracle/join_oracle.py (merge_segments_task.cc:62-67,103-131); every slot of every
+    sampled segment shows a class representative and the copies follow create_segment_texts_task.cc:43-75's multiset; and
+    the --output-segments file's (SEGMENT, LB, RB, SIZE, row lists) of the sampled segments are the oracle's classes
+    (segmentation_dp_arg.cc:59-111).  Lemon's tie order among equal-weight matchings is parity-unpinned, so the
+    checks are order-free."""
+    import importlib
+    from collections import Counter
+    pkg = importlib.import_module("founder-sequences_amd")
+    c = fso.CONFIGS["C3"]
+    m, n, L = c["m"], c["n"], c["L"]
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.generate_synthetic(c["seed"], c["K"], c["B"], c["mu"], c["kind"])
+    res = ctx.run()
+    X, S = int(res.max_segment_size), int(res.segment_count)
+    red = ctx.reduced_traceback()
+    perm = ctx.join_bipartite()
+    assert perm.shape == (S, X)
+    rng = np.random.default_rng(5)
+    pairs = sorted(set(int(x) for x in rng.integers(1, S, size=260)) | {1, S - 1})[:240]
+    assert len(pairs) >= 200
+    cache = {}
+
+    def seg(s):
+        if s not in cache:
+            a, d = ctx.boundary_state(s)
+            cl = jo.classes(m, int(red["lb"][s]), a, d)
+            assert len(cl) == int(red["segment_size"][s])
+            sl = jo.slot_classes(perm[s], cl)                      # every slot shows a class representative (its smallest row)
+            cnt = Counter(sl)
+            assert set(cnt) == set(range(len(cl)))
+            assert Counter((len(cl[i]), k) for i, k in cnt.items()) == jo.bipartite_copy_multiset(m, X, cl)
+            cache[s] = (cl, sl)
+        return cache[s]
+
+    for s in pairs:
+        cl_l, sl_l = seg(s - 1)
+        cl_r, sl_r = seg(s)
+        best, base = jo.optimal_weight(sl_l, cl_l, sl_r, cl_r)
+        realised = sum(int(base[l, r]) for l, r in zip(sl_l, sl_r))       # founder i keeps slot i across the boundary
+        assert realised == best, s
+        cache.pop(s - 2, None)
+    # the segments file of the same run: the sampled segments' lines against the oracle's classes
+    msa = np.ascontiguousarray(ctx.get_sequences())
+    path = str(tmp_path / "segments_c3.txt")
+    ctx.write_segments(msa, pkg.JOIN_BIPARTITE, path)
+    want = {}
+    for s in pairs[:40]:
+        a, d = ctx.boundary_state(s)
+        want[s] = sorted(sorted(cl) for cl in jo.classes(m, int(red["lb"][s]), a, d))
+    got = {s: [] for s in want}
+    nlines = 0
+    with open(path) as f:
+        header = f.readline().rstrip("\n").split("\t")
+        assert header == ["SEGMENT", "LB", "RB", "SIZE", "SUBSEQUENCE", "SEQUENCES", "COPIED_FROM"]
+        for line in f:
+            nlines += 1
+            r = line.rstrip("\n").split("\t")
+            s = int(r[0])
+            if s in got:
+                assert (int(r[1]), int(r[2]), int(r[3])) == (int(red["lb"][s]), int(red["rb"][s]), int(red["segment_size"][s]))
+                if r[6] == "-":
+                    ids = [int(x) for x in r[5].split(",")]
+                    assert bytes(msa[ids[0], int(r[1]):int(r[2])]).decode() == r[4]
+                    got[s].append(ids)
+    assert nlines == X * S
+    for s in want:
+        assert sorted(got[s]) == want[s], s
