@@ -73,3 +73,26 @@ def test_one_rank_over_rccl():
     p = subprocess.run([sys.executable, os.path.join(HERE, "rccl_transport_worker.py")], env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.STDOUT, text=True, timeout=240)
     assert p.returncode == 0 and "rccl transport ok" in p.stdout, p.stdout[-2000:]
+
+
+def test_bench_in_the_drivers_launch_shape_with_four_ranks():
+    """The driver's N > 1 command -- python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N -- with
+    N = 4 (the pool lets six processes open a card: four ranks, their launcher and this test) as a rehearsal on the one GPU (FSEQ_BENCH_REHEARSAL=1: the ranks share cuda:0, the
+    timing collectives and the exchanges go over gloo): one JSON line from rank 0, "scaling": "strong", four ranks, and the same
+    segmentation as the single-GPU run of the workload (BASELINE C5's alignment: 8,105 merged segments, max size 159) -- through
+    the reduced phase C and pass 2 of every rank's own blocks."""
+    import json
+    env = dict(os.environ, FSEQ_BENCH_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    root = os.path.dirname(HERE)
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "4", "--workload", "C5", "--steps", "2", "--warmup", "1"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["ranks"] == 4 and d["n_gpus"] == 1 and d["scaling"] == "strong" and d["steps"] == 2 and d["value"] > 0
+    assert d["config"]["segments"] == 8105 and d["config"]["max_segment_size"] == 159
+    assert d["config"]["reduced_blocks"] > 0 and "all-reduces" in d["config"]["parallelism"]
