@@ -75,7 +75,7 @@ EXPORTS = [
     "fseq_abi_version", "fseq_strerror", "fseq_create", "fseq_destroy", "fseq_last_error",
     "fseq_set_rows", "fseq_set_matrix", "fseq_set_device_columns", "fseq_generate_synthetic", "fseq_get_matrix",
     "fseq_run_segmentation", "fseq_get_traceback", "fseq_get_segments", "fseq_boundary_state",
-    "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
+    "fseq_short_path_runs", "fseq_join_greedy", "fseq_greedy_match_host", "fseq_write_founders", "fseq_write_founders_device", "fseq_debug_dp", "fseq_debug_block_state", "fseq_debug_column_list", "fseq_get_timings",
     "fseq_rowshard_xbuf_words", "fseq_rowshard_rows", "fseq_rowshard_pbwt",
     "fseq_debug_rmq", "fseq_shard_xbuf_words", "fseq_set_shard", "fseq_shard_columns", "fseq_shard_owner",
     "fseq_set_device_columns_packed", "fseq_debug_dp_schedule", "fseq_run_segmentation_batch", "fseq_join_bipartite", "fseq_join_random", "fseq_bipartite_match_host", "fseq_random_join_host", "fseq_write_segments",
@@ -130,6 +130,7 @@ def load_library():
     L.fseq_join_greedy.argtypes = [vp, vp]
     L.fseq_greedy_match_host.argtypes = [C.c_uint32, C.c_uint32, u64, vp, vp, vp, vp, vp]
     L.fseq_write_founders.argtypes = [vp, C.POINTER(vp), vp, C.c_char_p]
+    L.fseq_write_founders_device.argtypes = [vp, vp, C.c_char_p]
     L.fseq_run_segmentation_batch.argtypes = [vp, sz, vp, vp]
     L.fseq_debug_dp_schedule.argtypes = [u64, u64, u64, vp, vp, vp, vp]
     L.fseq_join_bipartite.argtypes = [vp, vp]
@@ -497,6 +498,11 @@ class SegmentationContext:
         assert msa.dtype == np.uint8 and msa.flags["C_CONTIGUOUS"] and msa.shape == (self.m, self.n)
         rows = (C.c_void_p * self.m)(*[msa.ctypes.data + r * msa.strides[0] for r in range(self.m)])
         self._check(self.L.fseq_write_segments(self.h, rows, joining, path.encode() if path else None))
+
+    def write_founders_device(self, permutations, path):
+        """--output-founders from the alignment resident on the device (no host rows)."""
+        perm = np.ascontiguousarray(permutations, dtype=np.uint32)
+        self._check(self.L.fseq_write_founders_device(self.h, perm.ctypes.data, path.encode() if path else None))
 
     def write_founders(self, msa, permutations, path):
         """msa: the raw input rows as a C-contiguous uint8 array [m, n]."""

@@ -302,4 +302,55 @@ int fseq_write_founders(fseq_ctx *c, uint8_t const *const *rows, uint32_t const 
 	return FSEQ_OK;
 }
 
+
+// [r5] --output-founders straight from the alignment the device holds (k_founders, fseq_joinprep.hpp): no host rows needed.
+// The lines are put together on the device, a batch of rows (<= 256 MB) at a time, and leave in one copy and one write per batch.
+int fseq_write_founders_device(fseq_ctx *c, uint32_t const *permutations, char const *path)
+{
+	if (!c || !permutations || !c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (!c->have_input || !c->d_msa) return fail(c, FSEQ_E_ARG, "no alignment resident on the device");
+	if (c->sh.on) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: a rank holds its own columns only (write the founders from host rows: fseq_write_founders)");
+	(void) hipSetDevice(c->p.device);
+	size_t const X = c->res.max_segment_size, S = c->segments.size();
+	if (!X || !S) return fail(c, FSEQ_E_ARG, "no segments to write");
+	FILE *f = (path && strcmp(path, "-") != 0) ? fopen(path, "wb") : stdout;
+	if (!f) return fail(c, FSEQ_E_ARG, "cannot open the founders output file");
+	hipStream_t st = c->stream;
+	size_t const line = (size_t) c->p.n + 1;
+	size_t const batch = std::max<size_t>(1, std::min<size_t>(X, (size_t) (256u << 20) / line));
+	uint32_t *d_perm = nullptr;
+	uint64_t *d_seg = nullptr;
+	uint8_t *d_lut = nullptr, *d_out = nullptr, *h_out = nullptr;
+	int rc = FSEQ_OK;
+	auto cleanup = [&]() {
+		dev_free(c, &d_perm); dev_free(c, &d_seg); dev_free(c, &d_lut); dev_free(c, &d_out);
+		if (h_out) (void) hipHostFree(h_out);
+		if (f != stdout) fclose(f);
+	};
+	if ((rc = dev_alloc(c, &d_perm, S * X)) || (rc = dev_alloc(c, &d_seg, 2 * S)) || (rc = dev_alloc(c, &d_lut, 256)) || (rc = dev_alloc(c, &d_out, batch * line))) { cleanup(); return rc; }
+	if (hipHostMalloc(reinterpret_cast<void **>(&h_out), batch * line, hipHostMallocDefault) != hipSuccess) { h_out = nullptr; cleanup(); return fail(c, FSEQ_E_OOM, "founders output buffer"); }
+	std::vector<uint64_t> seg(2 * S);
+	for (size_t s = 0; s < S; ++s) { seg[s] = c->segments[s].lb; seg[S + s] = c->segments[s].rb; }
+	bool ok = true;
+	do {
+		if (hipMemcpyAsync(d_perm, permutations, S * X * 4, hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
+		if (hipMemcpyAsync(d_seg, seg.data(), 2 * S * 8, hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
+		if (hipMemcpyAsync(d_lut, c->code_to_byte, 256, hipMemcpyHostToDevice, st) != hipSuccess) { ok = false; break; }
+		for (size_t r0 = 0; r0 < X && ok; r0 += batch)
+		{
+			size_t const nr = std::min(batch, X - r0);
+			uint32_t const rows_per_wg = 16;
+			hipLaunchKernelGGL(k_founders, dim3((uint32_t) S, (uint32_t) ((nr + rows_per_wg - 1) / rows_per_wg)), dim3(256), 0, st, c->d_msa, c->ld, c->p.m, (uint64_t) c->p.n, c->bsh,
+			                   d_perm, (uint32_t) X, d_seg, d_seg + S, (uint32_t) S, (uint32_t) r0, (uint32_t) nr, rows_per_wg, d_lut, d_out);
+			if (hipMemcpyAsync(h_out, d_out, nr * line, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { ok = false; break; }
+			ok = fwrite(h_out, 1, nr * line, f) == nr * line;
+		}
+	} while (false);
+	if (ok && hipGetLastError() != hipSuccess) ok = false;
+	fflush(f);
+	cleanup();
+	if (!ok) return fail(c, FSEQ_E_HIP, "writing the founders from the device failed");
+	return FSEQ_OK;
+}
+
 } // extern "C"

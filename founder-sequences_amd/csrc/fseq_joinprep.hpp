@@ -103,4 +103,37 @@ __global__ __launch_bounds__(JP_T) void k_join_edges(
 	}
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// [r5] --output-founders from the RESIDENT alignment (join_context::output_in_permutation_order, join_context.cc:333-356):
+// line r is, segment after segment, the substring [lb, rb) of row permutations[s][r]; a slot without a row
+// (permutations[s][r] >= m: bipartite_matcher's m_permutation_max) prints '-'.  The alignment is already in HBM, packed
+// column-major; the lines leave in one copy instead of 418,000 host memcpy's of 160 bytes from 2.5 GB of raw rows (BASELINE C3).
+// Workgroup (x, y): segment x, the lines [row0 + y * rows_per_wg, ...) of this batch; a wave writes one line's piece, its
+// lanes along the columns (coalesced stores; the loads hit the segment's ~160 columns in L2).
+// out: [rows of the batch][n + 1] bytes, '\n' at column n (written by the workgroups of the last segment).
+// ------------------------------------------------------------------------------------------------
+static __global__ __launch_bounds__(256) void k_founders(
+	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t bsh, uint32_t const *__restrict__ perm, uint32_t X,
+	uint64_t const *__restrict__ seg_lb, uint64_t const *__restrict__ seg_rb, uint32_t S, uint32_t row0, uint32_t nrows, uint32_t rows_per_wg,
+	uint8_t const *__restrict__ code_to_byte, uint8_t *__restrict__ out)
+{
+	__shared__ uint8_t lut[256];
+	lut[threadIdx.x] = code_to_byte[threadIdx.x];
+	__syncthreads();
+	uint32_t const s = blockIdx.x;
+	uint64_t const lb = seg_lb[s], rb = seg_rb[s];
+	uint32_t const bits = 8u >> bsh, cmask = (1u << bits) - 1u, wv = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	uint32_t const r_lo = blockIdx.y * rows_per_wg, r_hi = min(nrows, r_lo + rows_per_wg);
+	for (uint32_t r = r_lo + wv; r < r_hi; r += 4u)
+	{
+		uint32_t const src = perm[(size_t) s * X + row0 + r];
+		uint8_t *const line = out + (size_t) r * (n + 1u);
+		uint32_t const off = src >> bsh, sh = (src & ((1u << bsh) - 1u)) * bits;
+		for (uint64_t k = lb + lane; k < rb; k += 64u)
+			line[k] = src < m ? lut[(msa[k * ld + off] >> sh) & cmask] : (uint8_t) '-';
+		if (s + 1u == S && lane == 0) line[n] = (uint8_t) '\n';
+	}
+}
+
 } // namespace fseq

@@ -315,7 +315,9 @@ int main(int argc, char **argv)
 	}
 	if (FSEQ_OK != rc) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	std::cerr << "Outputting the founders…" << std::endl;
-	if (FSEQ_OK != (rc = fseq_write_founders(ctx, rows.data(), perm.data(), out_founders))) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
+	// (not sharded: the lines are put together where the alignment already is, on the device; sharded: a rank holds its own columns)
+	rc = sharded ? fseq_write_founders(ctx, rows.data(), perm.data(), out_founders) : fseq_write_founders_device(ctx, perm.data(), out_founders);
+	if (FSEQ_OK != rc) { std::cerr << fseq_last_error(ctx) << std::endl; return EXIT_FAILURE; }
 	if (out_segments)
 	{
 		// segmentation_dp_arg.cc:13-104; with greedy joining the copy-number matrix is empty, so only the

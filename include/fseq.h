@@ -266,6 +266,9 @@ int  fseq_write_segments_host(fseq_ctx *ctx, uint8_t const *const *rows, int joi
  * lines; line r = concatenation over segments of rows[permutations[s][r]][lb_s, rb_s).  rows = the
  * raw input sequences.  path NULL or "-" = stdout. */
 int  fseq_write_founders(fseq_ctx *ctx, uint8_t const *const *rows, uint32_t const *permutations, char const *path);
+/* [ABI 5] the same from the alignment the device holds (uploaded, generated or borrowed): the lines are put together on the
+ * device and leave in one copy per batch of rows; no host rows needed.  Not for sharded runs (a rank holds its own columns). */
+int  fseq_write_founders_device(fseq_ctx *ctx, uint32_t const *permutations, char const *path);
 
 int  fseq_get_timings(fseq_ctx const *ctx, fseq_timings *out);
 

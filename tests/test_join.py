@@ -158,6 +158,10 @@ def test_nongreedy_joiners_through_the_gpu_path(pkg, tmp_path):
     ctx.write_founders(msa, host_perm, path)
     lines = open(path, "rb").read().split(b"\n")[:-1]
     assert len(lines) == X and all(len(x) == n for x in lines)
+    # [r5] the device writer (the lines put together from the resident packed alignment): the same bytes
+    pdev = str(tmp_path / "founders_bp_dev.txt")
+    ctx.write_founders_device(host_perm, pdev)
+    assert open(pdev, "rb").read() == open(path, "rb").read()
     # segments files: bipartite = X lines per segment (texts, row lists, copied-from); random = one line per class
     pb = str(tmp_path / "segments_bp.txt")
     ctx.write_segments(msa, pkg.JOIN_BIPARTITE, pb)
@@ -204,6 +208,8 @@ def test_config_c2_full_size_founders_match_the_oracle():
         path = f.name
     ctx.write_founders(msa, perm, path)
     got = hashlib.sha256(open(path, "rb").read()).hexdigest()
+    ctx.write_founders_device(perm, path)                      # [r5] from the resident alignment: the same file
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == got
     os.unlink(path)
     jp = ctx.join_profile()
     # (the class tables and the co-occurrence edges come from the device: a fraction of the S' x m x 8 bytes of states)
@@ -288,3 +294,26 @@ def test_config_c3_full_size_bipartite_joiner_against_independent_checks(tmp_pat
     assert nlines == X * S
     for s in want:
         assert sorted(got[s]) == want[s], s
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,m,n,L", [(0, 300, 2000, 25), (1, 700, 1500, 20), (0, 12000, 900, 10)])
+def test_device_founders_writer_matches_the_host_writer(pkg, tmp_path, kind, m, n, L):
+    """fseq_write_founders_device (k_founders: the lines from the resident packed alignment, 2 / 4 bits per symbol, LDS-resident and
+    streamed row counts, a slot without a row printing '-') against fseq_write_founders from the raw host rows."""
+    msa = np.ascontiguousarray(fso.synth_msa(fso.synth_spec(7 + kind, 8, 300, 2e-3, kind), m, n))
+    ctx = pkg.SegmentationContext(m, n, L)
+    ctx.set_sequences(msa)
+    ctx.run()
+    perm = ctx.join_greedy()
+    a, b = str(tmp_path / "h.txt"), str(tmp_path / "d.txt")
+    ctx.write_founders(msa, perm, a)
+    ctx.write_founders_device(perm, b)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    # a slot without a row (join_context.cc:348-349: m_permutation_max): '-' over the segment
+    perm2 = perm.copy()
+    perm2[0, 0] = (1 << int(m).bit_length()) - 1
+    ctx.write_founders_device(perm2, b)
+    red = ctx.reduced_traceback()
+    first = open(b, "rb").read().split(b"\n")[0]
+    assert first[:int(red["rb"][0])] == b"-" * int(red["rb"][0]) and first[int(red["rb"][0]):] == open(a, "rb").read().split(b"\n")[0][int(red["rb"][0]):]
