@@ -2217,7 +2217,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	bool const keyspace = R.keyspace;
 	// [r5] phase C on representative rows: the default wherever the lists are consumed by the speculative DP behind phase C
 	// (sharded: a rank's own blocks; its halo block has no state behind it to take the classes from and runs on all rows)
-	bool const red_candidate = !c->tune.no_reduced && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks && !c->tune.dp_serial && n >= 2 * L;
+	bool const red_candidate = !c->tune.no_reduced && n >= 2 * L;
 	double const t_att = now_ms();
 	auto mark = [&](char const *what) { if (c->tune.debug) fprintf(stderr, "[fseq]   attempt +%.3f ms %s\n", now_ms() - t_att, what); };
 	if ((rc = ensure_work_buffers(c, X, !red_candidate))) return rc;
@@ -2234,41 +2234,16 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		HIP_TRY(c, hipMemsetAsync(c->d_ent_alloc, 0xFF, ((size_t) (held_hi(c) - held_lo(c)) * c->stride + 256) * sizeof(uint2), st));
 		HIP_TRY(c, hipMemsetAsync(c->d_hdr, 0xFF, (size_t) n * sizeof(uint4), st));
 	}
-	// Phase C in `parts` launches over consecutive block ranges and the DP in as many launches over the
-	// rounds whose lists are complete, on a second stream: the DP of a column prefix runs while later
-	// columns are still being produced.  Only where one workgroup of the column kernel fills a CU (16-bit
-	// and streamed state) and a launch has several waves of them anyway: a part is then ncu - 1
-	// workgroups per wave, which leaves the DP (a whole CU's LDS) a CU of its own.  FSEQ_C_PARTS forces a count.
 	DpSchedule const S = dp_schedule((uint32_t) L, (uint32_t) n);
-	// default: the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp);
-	// the forms that run the serial DP beside phase C remain for FSEQ_DP_SERIAL and the forced test schedules
+	// the DP as chunk-speculative sweeps over the whole chip once every list is written (fseq_dpspec.hpp); the serial kernel for
+	// inputs too short for three chunks (and FSEQ_DP_SERIAL).  [r5] the forms that ran the serial DP beside phase C (in parts, or
+	// fed by host-visible flags) are gone: no default reached them
 	SpecPlan const spec = spec_plan(c, S);
-	bool const use_spec = sharded || (spec.nchunks() > 0 && !c->tune.c_parts && !c->tune.host_flags && !c->tune.dp_chunks);
+	bool const use_spec = sharded || spec.nchunks() > 0;
 	if (sharded && spec.nchunks() < 1) return fail(c, FSEQ_E_UNSUPPORTED, "sharded run: no DP chunk plan");
 	// columns phase C covers here: all, or my blocks plus the halo block's first columns (the lists my last DP round reads)
 	uint64_t const n_c = sharded ? sh.c_end : n;
 	uint32_t spec_overflow = 0, spec_sweeps = 0;
-	uint32_t parts = 1, part_blocks = c->nblocks;
-	if (!use_spec)
-	{
-		int ncu = 0;
-		(void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->p.device);
-		uint32_t const per_cu = c->use_stream ? 1u : ks.columns_resident(c->lds_columns);
-		if (per_cu == 1u && ncu > 1 && c->nblocks >= 2u * (uint32_t) ncu)
-		{
-			uint32_t const wave_blocks = (uint32_t) ncu - 1u;
-			uint32_t const waves = (c->nblocks + wave_blocks - 1) / wave_blocks;
-			part_blocks = wave_blocks * ((waves + 7u) / 8u);
-			parts = (c->nblocks + part_blocks - 1) / part_blocks;
-		}
-		if (c->tune.c_parts)
-		{
-			parts = (uint32_t) std::min<long>(16, std::max<long>(1, c->tune.c_parts));
-			parts = std::min(parts, c->nblocks);
-			part_blocks = (c->nblocks + parts - 1) / parts;
-			parts = (c->nblocks + part_blocks - 1) / part_blocks;
-		}
-	}
 	HIP_TRY(c, hipEventRecord(c->ev[3], st));
 	FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
 	// (list [r5]: workgroup i owns block list[i] instead of b0 + i -- the blocks the reduced phase C hands to the run on all rows)
@@ -2292,60 +2267,6 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			ks.columns(st, nb, c->lds_columns, c->d_msa, c->ld, m, n_c, c->B, c->N2, c->d_bstate_a, c->d_bstate_d, (uint32_t) L, c->X, c->stride, c->d_ent, c->d_hdr, c->npass, c->bsh,
 			           c->snap_stride, c->d_ss_a, c->d_ss_d, b0, done, epoch, c->colmask_ready && c->colmask_use ? c->d_colmask : (uint32_t const *) nullptr, list);
 	};
-	// One-workgroup-per-CU inputs, default: ONE phase C launch whose workgroups tell the host when their
-	// block is in memory; the host launches the DP of the finished column prefix beside it (resumed
-	// launches on the second stream).  Phase C keeps its efficiency (no drain between parts).
-	bool const host_flags = (parts > 1 && !c->tune.c_parts && !c->tune.no_host_flags) || c->tune.host_flags;
-	if (host_flags)
-	{
-		if (c->done_cap < c->nblocks)
-		{
-			if (c->h_done) (void) hipHostFree(c->h_done);
-			c->h_done = nullptr;
-			HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->h_done), (size_t) c->nblocks * 4, hipHostMallocMapped | hipHostMallocCoherent));
-			HIP_TRY(c, hipHostGetDevicePointer(reinterpret_cast<void **>(&c->d_done), c->h_done, 0));
-			memset(c->h_done, 0, (size_t) c->nblocks * 4);
-			c->done_cap = c->nblocks;
-			c->epoch = 0;
-		}
-		uint32_t const epoch = ++c->epoch;
-		hipStream_t const st2 = c->stream2;
-		launch_columns(0, c->nblocks, c->d_done, epoch);
-		HIP_TRY(c, hipEventRecord(c->ev[4], st));
-		HIP_TRY(c, hipGetLastError());
-		// the host follows the completed block prefix and hands the DP the rounds whose lists are complete
-		uint32_t prefix = 0, r_done = 0;
-		uint32_t const min_rounds = c->tune.host_flags ? 1u : std::max(64u, S.nrounds / 12u);   // forced (tests): as many resumed launches as possible
-		bool dp_started = false;
-		double const t_wait0 = now_ms();
-		while (r_done < S.nrounds)
-		{
-			while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
-			uint32_t const r1 = (prefix == c->nblocks) ? S.nrounds : dp_rounds_within(S, std::min<uint64_t>(n, (uint64_t) prefix * c->B));
-			if (r1 > r_done && (r1 - r_done >= min_rounds || prefix == c->nblocks))
-			{
-				if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, r_done, r1, DpSpecArgs{});
-				r_done = r1;
-				continue;
-			}
-			hipError_t const q = hipStreamQuery(st);
-			if (q != hipErrorNotReady && prefix < c->nblocks)
-			{
-				// phase C is over: either it failed (report that, not a time-out) or every flag is there
-				if (q != hipSuccess) return fail(c, FSEQ_E_HIP, "phase C failed", q);
-				while (prefix < c->nblocks && __atomic_load_n(&c->h_done[prefix], __ATOMIC_ACQUIRE) == epoch) ++prefix;
-				if (prefix < c->nblocks) return fail(c, FSEQ_E_HIP, "internal: phase C finished without flagging every block");
-				continue;
-			}
-			if (now_ms() - t_wait0 > 600e3) return fail(c, FSEQ_E_HIP, "timed out waiting for phase C");
-			if (now_ms() - t_wait0 > 50.0) std::this_thread::sleep_for(std::chrono::microseconds(50)); else std::this_thread::yield();
-		}
-		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
-		HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
-	}
-	else if (parts <= 1)
 	{
 		if (use_spec)
 		{
@@ -2416,52 +2337,16 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 			}
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[4], st));
-		// the DP in one launch, or (diagnostic: FSEQ_DP_CHUNKS=k) in k launches over consecutive round ranges,
-		// each resuming from the arrays the one before it flushed
-		uint32_t chunks = 1;
-		if (c->tune.dp_chunks) chunks = (uint32_t) c->tune.dp_chunks;
-		chunks = std::min(chunks, S.nrounds);
 		HIP_TRY(c, hipEventRecord(c->ev_dp[0], st));
 		if (use_spec)
 		{
 			HIP_TRY(c, hipStreamWaitEvent(st, c->ev_part[15], 0));      // the DP arrays were reset beside phase C
 			if ((rc = run_dp_spec(c, S, spec, st, &spec_overflow, &spec_sweeps, true))) return rc;
 		}
-		else if (chunks <= 1)
+		else
 			hipLaunchKernelGGL(k_dp<DP_WHOLE>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
 			                   c->d_flags, 0u, S.nrounds, DpSpecArgs{});
-		for (uint32_t k = 0; !use_spec && chunks > 1 && k < chunks; ++k)
-		{
-			uint32_t const r0 = (uint32_t) ((uint64_t) S.nrounds * k / chunks), r1 = (uint32_t) ((uint64_t) S.nrounds * (k + 1) / chunks);
-			hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-			                   c->d_flags, r0, r1, DpSpecArgs{});
-		}
 		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st));
-	}
-	else
-	{
-		hipStream_t const st2 = c->stream2;
-		uint32_t r_done = 0;
-		bool dp_started = false;
-		for (uint32_t k = 0; k < parts; ++k)
-		{
-			uint32_t const b0 = k * part_blocks, nb = std::min(part_blocks, c->nblocks - b0);
-			launch_columns(b0, nb);
-			HIP_TRY(c, hipEventRecord(c->ev_part[k], st));
-			uint64_t const col_hi = std::min<uint64_t>(n, (uint64_t) (b0 + nb) * c->B);
-			uint32_t const r1 = (k + 1 == parts) ? S.nrounds : dp_rounds_within(S, col_hi);
-			if (r1 > r_done)
-			{
-				HIP_TRY(c, hipStreamWaitEvent(st2, c->ev_part[k], 0));
-				if (!dp_started) { HIP_TRY(c, hipEventRecord(c->ev_dp[0], st2)); dp_started = true; }
-				hipLaunchKernelGGL(k_dp<DP_PARTIAL>, dim3(1), dim3(1024), dp_lds_bytes(), st2, c->dp, c->d_ent, c->d_hdr, c->stride, m, (uint32_t) n, (uint32_t) L,
-				                   c->d_flags, r_done, r1, DpSpecArgs{});
-				r_done = r1;
-			}
-		}
-		HIP_TRY(c, hipEventRecord(c->ev[4], st));
-		HIP_TRY(c, hipEventRecord(c->ev_dp[1], st2));
-		HIP_TRY(c, hipStreamWaitEvent(st, c->ev_dp[1], 0));
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[5], st));
 	HIP_TRY(c, hipGetLastError());
@@ -2513,7 +2398,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	{
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[3], c->ev[4])); ms_c += f;
-		HIP_TRY(c, hipEventElapsedTime(&f, c->ev_dp[0], c->ev_dp[1])); ms_dp += f;     // overlaps phase C when that runs in parts
+		HIP_TRY(c, hipEventElapsedTime(&f, c->ev_dp[0], c->ev_dp[1])); ms_dp += f;
 	}
 #ifdef FSEQ_DP_STAMPS
 	{
@@ -3133,7 +3018,6 @@ void fseq_destroy(fseq_ctx *c)
 	if (c->h_red_pin2) (void) hipHostFree(c->h_red_pin2);
 	for (auto &s_ : c->red_st) if (s_) (void) hipStreamDestroy(s_);
 	for (auto &e_ : c->red_ev) if (e_) (void) hipEventDestroy(e_);
-	if (c->h_done) (void) hipHostFree(c->h_done);
 	if (c->stream2) (void) hipStreamDestroy(c->stream2);
 	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;

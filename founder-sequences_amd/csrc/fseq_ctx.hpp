@@ -99,9 +99,6 @@ inline double now_ms()
 // path looks at the environment.  Every knob selects among exact alternatives (results never depend on them).
 struct Tuning {
 	bool debug = false;                  // FSEQ_DEBUG: progress notes on stderr
-	bool host_flags = false, no_host_flags = false;   // FSEQ_HOST_FLAGS / FSEQ_NO_HOST_FLAGS: the serial DP beside phase C, fed by host-visible flags
-	int  c_parts = 0;                    // FSEQ_C_PARTS: phase C in this many launches with the serial DP in between
-	int  dp_chunks = 0;                  // FSEQ_DP_CHUNKS: the serial DP in this many resumed launches
 	bool dp_serial = false;              // FSEQ_DP_SERIAL: the serial DP instead of the speculative sweeps
 	int  dp_spec_win = 0, dp_spec_rounds = 0, dp_spec_max_sweeps = 0;      // FSEQ_DP_SPEC_*: tail window, chunk length, sweep budget
 	bool stream_plain_scan = false;      // FSEQ_STREAM_PLAIN_SCAN: streamed phase C with the has-based scan (first form)
@@ -147,10 +144,6 @@ struct Tuning {
 		bool const on = value != nullptr;
 		int const iv = atoi(v.c_str());
 		if (n == "FSEQ_DEBUG") debug = on;
-		else if (n == "FSEQ_HOST_FLAGS") host_flags = on;
-		else if (n == "FSEQ_NO_HOST_FLAGS") no_host_flags = on;
-		else if (n == "FSEQ_C_PARTS") c_parts = on ? std::max(1, iv) : 0;
-		else if (n == "FSEQ_DP_CHUNKS") dp_chunks = on ? std::max(1, iv) : 0;
 		else if (n == "FSEQ_DP_SERIAL") dp_serial = on;
 		else if (n == "FSEQ_DP_SPEC_WIN") dp_spec_win = on ? std::max(1, iv) : 0;
 		else if (n == "FSEQ_DP_SPEC_ROUNDS") dp_spec_rounds = on ? std::max(1, iv) : 0;
@@ -196,7 +189,7 @@ struct Tuning {
 
 	void from_environment()
 	{
-		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_HOST_FLAGS", "FSEQ_NO_HOST_FLAGS", "FSEQ_C_PARTS", "FSEQ_DP_CHUNKS", "FSEQ_DP_SERIAL",
+		static char const *const names[] = {"FSEQ_DEBUG", "FSEQ_DP_SERIAL",
 			"FSEQ_DP_SPEC_WIN", "FSEQ_DP_SPEC_ROUNDS", "FSEQ_DP_SPEC_MAX_SWEEPS", "FSEQ_STREAM_PLAIN_SCAN", "FSEQ_PLAIN_SCAN", "FSEQ_OCCURRENCE_KEYS", "FSEQ_PHASE_A_CLASSIC",
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
@@ -399,8 +392,6 @@ struct fseq_ctx {
 	hipEvent_t ev_dp[2]{};                   // DP begin / end on stream2
 	uint8_t *h_pin = nullptr;                // pinned host staging of a step's small transfers (pin_reserve / pin_take)
 	size_t pin_cap = 0, pin_used = 0;
-	uint32_t *h_done = nullptr, *d_done = nullptr;   // per-block "lists are in memory" flags in host-coherent memory (host / device view)
-	uint32_t done_cap = 0, epoch = 0;
 };
 
 

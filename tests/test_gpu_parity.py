@@ -1017,28 +1017,6 @@ def test_native_batch_runner(pkg):
             assert np.array_equal(red[f], ref["reduced"][f])
 
 
-@pytest.mark.parametrize("parts,chunks", [(-1, 0), (3, 0), (16, 0), (0, 5), (0, 1000000)])
-def test_phase_c_in_parts_overlapped_with_resumed_dp(pkg, monkeypatch, parts, chunks):
-    """The DP of the finished column prefix running beside phase C on a second stream -- what large 16-bit /
-    streamed inputs do by themselves: ONE phase C launch whose workgroups flag the host, which launches
-    resumed DP kernels (parts = -1: forced, as many launches as possible), or phase C launched in parts --
-    and the DP alone in several resumed launches: the LDS rings restored from HBM must give bit-identical
-    results, also on the pipelined schedule (L >= 96) and on the streamed kernels."""
-    monkeypatch.setenv("FSEQ_POISON_LISTS", "1")            # a list read before phase C wrote it must not look right by accident
-    if parts < 0:
-        monkeypatch.setenv("FSEQ_HOST_FLAGS", "1")
-    elif parts:
-        monkeypatch.setenv("FSEQ_C_PARTS", str(parts))
-    if chunks:
-        monkeypatch.setenv("FSEQ_DP_CHUNKS", str(chunks))
-    # chunks = 1000000: every round its own launch, the drain round and the final cell included
-    for (m, n, L, K, Brec, mu, seed, kind, B) in [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 50), (900, 5000, 100, 10, 300, 1e-3, 52, 1, 64),
-                                                  (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0),
-                                                  (200, 4000, 250, 6, 400, 2e-3, 55, 0, 100), (120, 3000, 140, 5, 300, 3e-3, 56, 0, 64)]:
-        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
-        compare_long(pkg, msa, L, block_len=B)
-
-
 SPEC_SHAPES = [(300, 6000, 25, 8, 200, 2e-3, 51, 0, 50), (900, 5000, 100, 10, 300, 1e-3, 52, 1, 64),
                (12000, 1500, 20, 12, 120, 3e-4, 53, 0, 30), (40, 9000, 7, 4, 60, 1e-2, 54, 0, 0),
                (200, 4000, 250, 6, 400, 2e-3, 55, 0, 100), (120, 3000, 140, 5, 300, 3e-3, 56, 0, 64),
@@ -1184,45 +1162,6 @@ def test_speculative_dp_with_short_lists_retries(pkg, monkeypatch):
     msa = fso.synth_msa(fso.synth_spec(61, 8, 200, 2e-3, 0), 300, 6000)
     ctx, _ = compare_long(pkg, msa, 25, block_len=50, list_cap=2)
     assert ctx.timings()["retries"] >= 1 and ctx.timings()["dp_chunks"] >= 2
-
-
-def test_host_flag_overlap_under_load(pkg, monkeypatch):
-    """The serial DP beside phase C (round 1's path for large inputs, still there under FSEQ_HOST_FLAGS: one phase C
-    launch flagging the host, resumed DP launches beside it), repeated while another context keeps the chip unevenly
-    busy: every run must equal the default run (chunk-speculative DP after phase C)."""
-    import threading
-    m, n, L = 10000, 600000, 100                      # 600 blocks of 1000 columns, one workgroup per CU
-    monkeypatch.setenv("FSEQ_NO_HOST_FLAGS", "1")
-    ref = pkg.SegmentationContext(m, n, L)
-    ref.generate_synthetic(0x5EED0005, 32, 5000, 1e-4, 1)
-    ref.run()
-    want, want_tb = ref.reduced_traceback().copy(), ref.traceback().copy()
-    a0, d0 = ref.boundary_state(len(want) // 2)
-    ref.close()
-    monkeypatch.delenv("FSEQ_NO_HOST_FLAGS")
-    monkeypatch.setenv("FSEQ_HOST_FLAGS", "1")
-    monkeypatch.setenv("FSEQ_POISON_LISTS", "1")
-    stop = []
-
-    def noise():
-        c = pkg.SegmentationContext(2500, 100000, 50)
-        c.generate_synthetic(1, 16, 2000, 1e-4, 0)
-        while not stop:
-            c.run()
-
-    th = threading.Thread(target=noise)
-    th.start()
-    try:
-        ctx = pkg.SegmentationContext(m, n, L)
-        ctx.generate_synthetic(0x5EED0005, 32, 5000, 1e-4, 1)
-        for _ in range(4):
-            ctx.run()
-            assert np.array_equal(ctx.reduced_traceback(), want) and np.array_equal(ctx.traceback(), want_tb)
-            a, d = ctx.boundary_state(len(want) // 2)
-            assert np.array_equal(a, a0) and np.array_equal(d, d0)
-    finally:
-        stop.append(1)
-        th.join()
 
 
 def test_progress_counters_and_callback(pkg):

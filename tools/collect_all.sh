@@ -7,11 +7,11 @@ tag=${1:-rXX}
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 mkdir -p gpurun_out/$tag
-for wl in C3 C5 C4cols50k C2; do
+for wl in C4slice C3 C5 C2; do
 	bash profiles/collect_profiles.sh ${tag}_$wl $wl > gpurun_out/$tag/collect_$wl.log 2>&1 || echo "collect_profiles failed for $wl"
 done
-python3 bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench_default.json 2> gpurun_out/$tag/bench_default.err
-for wl in C2 C5 C4; do
+python3 bench.py --steps 5 --warmup 2 > gpurun_out/$tag/bench_default.json 2> gpurun_out/$tag/bench_default.err
+for wl in C2 C3 C5; do
 	python3 bench.py --workload $wl --steps 5 --warmup 2 > gpurun_out/$tag/bench_$wl.json 2> gpurun_out/$tag/bench_$wl.err
 done
 echo "collect_all done"
