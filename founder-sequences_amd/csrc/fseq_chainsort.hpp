@@ -98,10 +98,16 @@ __device__ __forceinline__ void chain_step_sorted(
 		bool const first = p == 0;
 		uint2 const *src = ((npass - p) & 1u) ? pairA : pairB;          // (unused in the first pass)
 		uint2 *dst = ((npass - p) & 1u) ? pairB : pairA;
-		auto load = [&](uint32_t i) -> uint2 {
-			// first pass: the pairs are made on the way (rank of the row at position i, i)
-			return first ? make_uint2(cls ? cls[rk[a0[i]]] : rk[a0[i]], i) : src[i];
+		// first pass: the pairs are made on the way (rank of the row at position i, i) -- a chain of dependent gathers
+		// (position -> row -> rank [-> class]), followed once: the counting sweep leaves the key in the suffix-maxima buffer
+		// (free until step 2), the scatter sweep reads it there
+		auto load_count = [&](uint32_t i) -> uint2 {
+			if (!first) return src[i];
+			uint32_t const key = cls ? cls[rk[a0[i]]] : rk[a0[i]];
+			sm[i] = key;
+			return make_uint2(key, i);
 		};
+		auto load = [&](uint32_t i) -> uint2 { return first ? make_uint2(sm[i], i) : src[i]; };
 		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] = 0;
 		// (a wave's histogram row is its own: no barrier between clearing and counting; LDS operations of a wave stay in order)
 		// U groups of 64 positions per iteration: their (dependent: position -> row -> rank) loads in flight together -- one
@@ -111,7 +117,7 @@ __device__ __forceinline__ void chain_step_sorted(
 		{
 			uint2 pr[U];
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load(i) : make_uint2(0u, 0u); }
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load_count(i) : make_uint2(0u, 0u); }
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u)
 				if (i0 + u * 64u + lane < c_hi) atomicAdd(&S.hist[wave][(pr[u].x >> shift) & (nbins - 1u)], 1u);
