@@ -794,7 +794,7 @@ void free_work(fseq_ctx *c)
 	dev_free(c, &c->d_gent); dev_free(c, &c->d_ghdr);
 	dev_free(c, &c->d_snap_a); dev_free(c, &c->d_snap_d); dev_free(c, &c->d_ws); c->d_ws_c = nullptr; dev_free(c, &c->d_cshist); c->cshist_words = 0;
 	c->cols_cap = c->gather_cap = c->snap_cap = c->grp_cap = c->src_cap = 0;
-	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows_alloc); dev_free(c, &c->d_red_leaf_alloc); dev_free(c, &c->d_red_a_alloc); dev_free(c, &c->d_red_d_alloc); c->d_red_rows = c->d_red_leaf = c->d_red_a = c->d_red_d = nullptr;
+	dev_free(c, &c->d_red_cnt); dev_free(c, &c->d_red_cnt_plan); c->red_plan_valid = false; c->red_declined = false; dev_free(c, &c->d_red_vmin); dev_free(c, &c->d_red_rows_alloc); dev_free(c, &c->d_red_leaf_alloc); dev_free(c, &c->d_red_a_alloc); dev_free(c, &c->d_red_d_alloc); c->d_red_rows = c->d_red_leaf = c->d_red_a = c->d_red_d = nullptr;
 	dev_free(c, &c->d_red_invalid); dev_free(c, &c->d_red_blocks); dev_free(c, &c->d_red_msa_alloc); c->d_red_msa = nullptr; c->red_cap = 0; c->red_blocks_cap = 0; c->red_ld = 0; c->red_msa_bytes = 0;
 	dev_free(c, &c->d_red_ss_a_alloc); dev_free(c, &c->d_red_ss_d_alloc); c->d_red_ss_a = c->d_red_ss_d = nullptr; c->red_ss_words = 0;
 	dev_free(c, &c->d_red_cls); dev_free(c, &c->d_red_headd); dev_free(c, &c->d_red_ncls); dev_free(c, &c->d_red_taskblk); dev_free(c, &c->d_red_wgtasks); c->red_task_cap = 0;
@@ -877,7 +877,7 @@ int upload_rows_device_impl(fseq_ctx *c, uint8_t const *const *rows)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	return FSEQ_OK;
 }
 
@@ -918,7 +918,7 @@ int set_alphabet_and_upload(fseq_ctx *c, uint8_t const *base, size_t rs, size_t 
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	return FSEQ_OK;
 }
 
@@ -2024,6 +2024,8 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 		c->red_plan_valid = false;
 	}
 	if (!my_blocks) return FSEQ_OK;                            // (a rank without blocks)
+	// (the last run on this input at this capacity found the representatives not worth it: the same input gives the same answer)
+	if (c->red_declined && c->red_declined_X == X && !c->tune.reduced_always) return FSEQ_OK;
 	if (c->red_pin_words < 4 * (size_t) nbk + 64)
 	{
 		if (c->h_red_pin) (void) hipHostFree(c->h_red_pin);
@@ -2101,13 +2103,18 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (c->tune.debug)
 		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", my_blocks - n_full, my_blocks,
 		        c->tm.reduced_rows_mean, m, max_rows, n_full);
-	// worth it?  The run on all rows is the tuned one (three workgroups per CU, stride states for pass 2): the representatives
-	// take over where they are clearly fewer -- rows to update in all, a block on all rows counted as one and a half (its
-	// boundaries are reached from the block's start) -- below half of the rows (FSEQ_REDUCED_ALWAYS: tests)
+	// worth it?  The run on all rows is the tuned one (three workgroups per CU, stride states for pass 2), and a row of a small
+	// reduced workgroup costs more than a row there: the representatives take over where they are clearly fewer -- rows to
+	// update in all, a block on all rows counted as one and a half (its boundaries are reached from the block's start) -- below
+	// a fifth of the rows (BASELINE C3 / C4 / C5: 8 / 7 / 6 %; C3's shape with ten times the mutations, 40 %: 11.4 ms against
+	// 9.4 on all rows, tools/diversity_sweep.py; FSEQ_REDUCED_ALWAYS: tests)
 	{
 		uint64_t const rows_all = sum_rows + (uint64_t) n_full * m * 3u / 2u;
-		if (!c->tune.reduced_always && (rows_all * 2u > (uint64_t) my_blocks * m || (uint64_t) n_full * 4u > my_blocks)) return FSEQ_OK;
-		if ((uint64_t) n_full >= my_blocks) return FSEQ_OK;
+		if ((!c->tune.reduced_always && (rows_all * 5u > (uint64_t) my_blocks * m || (uint64_t) n_full * 4u > my_blocks)) || (uint64_t) n_full >= my_blocks)
+		{
+			c->red_declined = true; c->red_declined_X = X;
+			return FSEQ_OK;
+		}
 	}
 	if (n_full && c->use_stream && !c->s2.T) return FSEQ_OK;     // (the first form of the streamed kernel takes no block list)
 	if (!c->red_direct)
@@ -3096,7 +3103,7 @@ int fseq_set_device_columns(fseq_ctx *c, void const *d_codes, size_t ld, uint32_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -3120,7 +3127,7 @@ int fseq_set_device_columns_packed(fseq_ctx *c, void const *d_packed, size_t ld_
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	(void) hipSetDevice(c->p.device);
 	return check_borrowed_codes(c);
 }
@@ -3224,7 +3231,7 @@ int fseq_generate_synthetic(fseq_ctx *c, fseq_synth_spec const *spec)
 	c->have_result = false;
 	c->kernels_ready = false;
 	c->X_hint = 0;
-	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->colmask_ready = false; c->shard_dp_full_sticky = false; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	return FSEQ_OK;
 }
 
@@ -3282,7 +3289,7 @@ int fseq_debug_set_tuning(fseq_ctx *c, char const *name, char const *value)
 	c->have_result = false;
 	c->kernels_ready = false;
 	// (what the last run saw belongs to the old geometry: a block the tree or the trie ranked then may be given up now)
-	c->bk_given_up = -1; c->bt_given_up = -1; c->red_force_full.clear(); c->red_plan_valid = false;
+	c->bk_given_up = -1; c->bt_given_up = -1; c->red_force_full.clear(); c->red_plan_valid = false; c->red_declined = false;
 	return FSEQ_OK;
 }
 

@@ -368,6 +368,8 @@ struct fseq_ctx {
 	bool red_direct = false;                 // the representatives' symbols are read from the alignment's own columns (LDS-resident row counts): no reduced alignment
 	// the plan (which block on which configuration) of the last run on this input at capacity red_plan_X: the next run launches
 	// by it without waiting for the counts, and checks on the device that they are what the plan was made from
+	bool red_declined = false;               // the last run on this input (at capacity red_declined_X) found too many representatives: no prep this time
+	uint32_t red_declined_X = 0;
 	bool red_plan_valid = false;
 	uint32_t red_plan_X = 0, red_plan_blocks = 0, red_plan_rows_mean = 0;
 	uint32_t *d_red_cnt_plan = nullptr;

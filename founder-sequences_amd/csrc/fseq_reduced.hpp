@@ -244,14 +244,30 @@ static __global__ __launch_bounds__(256) void k_reduce_msa(
 		sh[i] = (row & (rpb - 1u)) * bits;
 	}
 	if (q >= nq) return;
-	for (uint32_t j = wave_id(); j < nb; j += 4u)
+	// (four columns per iteration: their sixteen gathers in flight together -- a wave is otherwise one round trip to L2 / HBM
+	// per column, and the kernel a third below what the alignment's 125 GB take to read on BASELINE C4)
+	constexpr uint32_t U = 4;
+	for (uint32_t j0 = wave_id(); j0 < nb; j0 += 4u * U)
 	{
-		uint8_t const *const col = msa + (k0 + j) * ld;
-		uint32_t v = 0;
+		uint32_t b[U][4];
 #pragma unroll
-		for (uint32_t i = 0; i < 4; ++i)
-			if (i < rpb) v |= ((col[off[i]] >> sh[i]) & cmask) << (i * bits);
-		red[(k0 + j) * ldr + q] = (uint8_t) v;
+		for (uint32_t u = 0; u < U; ++u)
+		{
+			uint32_t const j = min(j0 + 4u * u, nb - 1u);
+			uint8_t const *const col = msa + (k0 + j) * ld;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; ++i) b[u][i] = i < rpb ? col[off[i]] : 0u;
+		}
+#pragma unroll
+		for (uint32_t u = 0; u < U; ++u)
+		{
+			uint32_t const j = j0 + 4u * u;
+			uint32_t v = 0;
+#pragma unroll
+			for (uint32_t i = 0; i < 4; ++i)
+				if (i < rpb) v |= ((b[u][i] >> sh[i]) & cmask) << (i * bits);
+			if (j < nb) red[(k0 + j) * ldr + q] = (uint8_t) v;
+		}
 	}
 }
 
