@@ -160,6 +160,7 @@ def test_sharded_dp_exchange_modes(pkg, monkeypatch, mode):
     else:
         monkeypatch.setenv("FSEQ_SHARD_DP_WINDOW", mode.split("_")[1])
     monkeypatch.setenv("FSEQ_DP_SPEC_ROUNDS", "7")
+    fell_back = []
     for world, (m, n, L, K, Brec, mu, seed, kind, B) in [(3, (300, 24000, 25, 8, 200, 2e-3, 51, 0, 50)), (4, (2500, 20000, 50, 16, 2000, 1e-4, 0x5EED0002, 0, 0)),
                                                           (2, (12000, 6000, 20, 12, 120, 3e-4, 53, 0, 30))]:
         msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
@@ -171,7 +172,12 @@ def test_sharded_dp_exchange_modes(pkg, monkeypatch, mode):
             assert whole == {True}
         if mode == "window_1024":
             assert whole == {False}
+        fell_back.append(whole == {True})
         assert len({c._transport.calls for c in ctxs}) == 1
+    if mode == "window_64":
+        #  the window that does not hold: on at least one of the inputs a sweep read below it and the run started
+        # again with whole-array exchanges -- the restart is what makes the window exact, so it must have been taken
+        assert any(fell_back), fell_back
 
 
 def test_too_many_ranks_fail_together(pkg):
