@@ -41,6 +41,17 @@ static std::atomic<uint64_t> g_range_pushes{0}, g_range_pops{0};
 #define FSEQ_RANGE_POP() do { g_range_pops.fetch_add(1, std::memory_order_relaxed); } while (0)
 #endif
 
+// a phase's range: popped where the phase ends -- or where the function leaves early (a retry with a larger list capacity, an
+// attempt that runs again, an error), so that pushes and pops stay balanced on every path
+struct RangeScope {
+	bool open = true;
+	explicit RangeScope(char const *name) { FSEQ_RANGE_PUSH(name); (void) name; }
+	void end() { if (open) { FSEQ_RANGE_POP(); open = false; } }
+	~RangeScope() { end(); }
+	RangeScope(RangeScope const &) = delete;
+	RangeScope &operator=(RangeScope const &) = delete;
+};
+
 using namespace fseq;
 
 namespace {
@@ -1557,6 +1568,7 @@ struct LongRun {
 	bool trie_ran = false, trie_alone = false;   // ... the trie over 16-column words (streamed rows); ... without the key-space tree behind it
 	bool redo = false;                       // [r5] lists of some blocks could not be proven on their representatives: the attempt runs again, those blocks on all rows
 	uint32_t redone = 0;
+	bool range_ab_open = false;              // the roctx range of phases A + B spans two functions
 };
 
 // the aliases every phase uses
@@ -1601,6 +1613,7 @@ int long_phase_a(fseq_ctx *c, LongRun &R)
 	HIP_TRY(c, hipEventRecord(c->ev[0], st));
 	progress(c, FSEQ_STAGE_TRACEBACK, 0, n);
 	FSEQ_RANGE_PUSH("fseq pass 1: phases A + B (block keys, boundary states)");
+	R.range_ab_open = true;                  // (popped in long_phase_b; run_long_path pops it when a phase fails in between)
 	bool const keyspace = R.keyspace = c->bk_cap_words && my_blocks && !c->tune.phase_a_classic;
 	// The key-space tree hands the blocks whose merges would slice past their budget to the column sweep (fseq_blockkeys.hpp,
 	// BK_ABORT): per-block flags, the sweep launched over my blocks with the flags as its filter.  What the last run on this
@@ -1805,6 +1818,7 @@ int long_phase_b(fseq_ctx *c, LongRun &R)
 	HIP_TRY(c, hipEventRecord(c->ev[2], st));
 	HIP_TRY(c, hipGetLastError());
 	FSEQ_RANGE_POP();
+	R.range_ab_open = false;
 	progress(c, FSEQ_STAGE_TRACEBACK, n / 5, n);                  // (phases A and B queued: about a fifth of pass 1)
 	if (sync_at(c, 'B')) { fprintf(stderr, "[fseq] phase B queued\n"); HIP_TRY(c, hipStreamSynchronize(st)); fprintf(stderr, "[fseq] phase B done\n"); }
 	return FSEQ_OK;
@@ -2252,7 +2266,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 	uint64_t const n_c = sharded ? sh.c_end : n;
 	uint32_t spec_overflow = 0, spec_sweeps = 0;
 	HIP_TRY(c, hipEventRecord(c->ev[3], st));
-	FSEQ_RANGE_PUSH("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
+	RangeScope range_cd("fseq pass 1: phases C + D (column updates + lists, segmentation DP)");
 	// (list [r5]: workgroup i owns block list[i] instead of b0 + i -- the blocks the reduced phase C hands to the run on all rows)
 	auto launch_columns = [&](uint32_t b0, uint32_t nb, uint32_t *done = nullptr, uint32_t epoch = 0, uint32_t const *list = nullptr) {
 		if (c->use_stream && c->s2.T)
@@ -2434,9 +2448,9 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 		fprintf(stderr, "\n");
 	}
 #endif
-	FSEQ_RANGE_POP();
+	range_cd.end();
 	progress(c, FSEQ_STAGE_TRACEBACK, n, n);
-	FSEQ_RANGE_PUSH("fseq traceback + find_segments_greedy");
+	RangeScope range_tb("fseq traceback + find_segments_greedy");
 	double const th0 = now_ms();
 	bool overflow = (h_flags[0] & 1u) != 0 || spec_overflow != 0;
 	c->tm.dp_sweeps = spec_sweeps;
@@ -2444,7 +2458,7 @@ int long_attempt(fseq_ctx *c, LongRun &R, bool *overflow_out)
 
 	if (!overflow && (rc = long_traceback_and_merge(c, R, th0, &overflow))) return rc;
 	ms_host += now_ms() - th0;
-	FSEQ_RANGE_POP();
+	range_tb.end();
 	if (!overflow) progress(c, FSEQ_STAGE_MERGE, c->traceback.size(), c->traceback.size());
 	if (c->tune.debug) fprintf(stderr, "[fseq] host: traceback + merge %.3f ms\n", now_ms() - th0);
 	*overflow_out = overflow;
@@ -2583,7 +2597,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 	}
 	HIP_TRY(c, hipEventRecord(c->ev[6], st));
 	progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
-	FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
+	RangeScope range_p2("fseq pass 2: boundary states (update_pbwt_task)");
 	// the class tables at the task columns, configuration by configuration
 	if (!ls.empty())
 	{
@@ -2653,7 +2667,7 @@ int long_pass2_reduced(fseq_ctx *c, LongRun &R)
 	HIP_TRY(c, hipEventRecord(c->ev[7], st));
 	HIP_TRY(c, hipGetLastError());
 	HIP_TRY(c, hipStreamSynchronize(st));
-	FSEQ_RANGE_POP();
+	range_p2.end();
 	progress(c, FSEQ_STAGE_SAMPLES, S2, S2);
 	float f = 0;
 	HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); R.ms_p2 = f;
@@ -2727,7 +2741,7 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 		}
 		HIP_TRY(c, hipEventRecord(c->ev[6], st));
 		progress(c, FSEQ_STAGE_SAMPLES, 0, S2);
-		FSEQ_RANGE_PUSH("fseq pass 2: boundary states (update_pbwt_task)");
+		RangeScope range_p2("fseq pass 2: boundary states (update_pbwt_task)");
 		if (grp.empty())
 		{
 		}
@@ -2787,7 +2801,7 @@ int long_pass2(fseq_ctx *c, LongRun &R)
 		HIP_TRY(c, hipEventRecord(c->ev[7], st));
 		HIP_TRY(c, hipGetLastError());
 		HIP_TRY(c, hipStreamSynchronize(st));
-		FSEQ_RANGE_POP();
+		range_p2.end();
 		progress(c, FSEQ_STAGE_SAMPLES, S2, S2);
 		float f = 0;
 		HIP_TRY(c, hipEventElapsedTime(&f, c->ev[6], c->ev[7])); ms_p2 = f;
@@ -2823,9 +2837,10 @@ int run_long_path(fseq_ctx *c, fseq_result *res)
 	auto mark = [&](char const *what) { if (c->tune.debug) fprintf(stderr, "[fseq] +%.3f ms %s\n", now_ms() - t_begin, what); };
 	if ((rc = ensure_work_buffers(c, 0))) return rc;
 	mark("work buffers");
-	if ((rc = long_phase_a(c, R))) return rc;
+	auto close_ab = [&](int code) { if (R.range_ab_open) { FSEQ_RANGE_POP(); R.range_ab_open = false; } return code; };
+	if ((rc = long_phase_a(c, R))) return close_ab(rc);
 	mark("phase A queued");
-	if ((rc = long_phase_b(c, R))) return rc;
+	if ((rc = long_phase_b(c, R))) return close_ab(rc);
 	mark("phase B queued");
 	if ((rc = long_list_capacity(c, R))) return rc;
 	mark("list capacity");

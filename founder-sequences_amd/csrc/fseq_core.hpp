@@ -216,9 +216,22 @@ __device__ __forceinline__ void lds_dma16(void const *g, uint32_t lds_addr)
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
-// a barrier that waits for this wave's LDS operations only (__syncthreads() also drains its global stores: microseconds
-// when a list has just been written)
-__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// N consecutive 32-bit LDS words at a 4N-byte aligned address, as one or two wide reads (ds_read_b64 / ds_read_b128): lanes
+// that each take their own aligned group do not meet in a bank the way they do with N single reads N words apart
+template <int N> __device__ __forceinline__ void lds_read_words(uint32_t const *p, uint32_t (&o)[N])
+{
+	static_assert(N == 2 || N == 4 || N == 8, "two, four or eight words");
+	if constexpr (N == 2) { uint2 const w = *reinterpret_cast<uint2 const *>(p); o[0] = w.x; o[1] = w.y; }
+	else
+	{
+#pragma unroll
+		for (int h = 0; h < N / 4; ++h)
+		{
+			uint4 const w = *reinterpret_cast<uint4 const *>(p + 4 * h);
+			o[4 * h] = w.x; o[4 * h + 1] = w.y; o[4 * h + 2] = w.z; o[4 * h + 3] = w.w;
+		}
+	}
+}
 
 // -DFSEQ_KC_STAMPS: cycle stamps of a column step per wave (k_columns prints them)
 #ifdef FSEQ_KC_STAMPS

@@ -698,7 +698,7 @@ template <int T, int E, int SIGMA, bool PK>
 __host__ __device__ inline size_t columns_lds_bytes(uint32_t B)
 {
 	constexpr size_t CAP = (size_t) T * E;
-	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(PK ? (CAP + B + 1) / 2 : CAP + B, 4) + carve_bytes(CAP, 4)
+	return 2 * carve_bytes(CAP, PK ? 2 : 4) + 2 * carve_bytes(CAP, 1) + carve_bytes(PK ? (CAP + B + 9) / 2 : CAP + B + 8, 4) + carve_bytes(CAP, 4)
 	     + carve_bytes(1, sizeof(StepScratch<T, SIGMA>)) + carve_bytes(T / WAVE + 1, 4) + (columns_run_words(T, E, SIGMA, PK) ? carve_bytes(columns_run_words(T, E, SIGMA, PK), 4) : 0);
 }
 
@@ -788,7 +788,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 	AT *d_l = cv.take<AT>(CAP);
 	uint8_t *sym0 = cv.take<uint8_t>(RED ? red.symcap : CAP);
 	uint8_t *sym1 = cv.take<uint8_t>(RED ? red.symcap : CAP);
-	uint32_t *cnt_l = cv.take<uint32_t>(PK ? (CAP + B + 1) / 2 : CAP + B);
+	uint32_t *cnt_l = cv.take<uint32_t>(PK ? (CAP + B + 9) / 2 : CAP + B + 8);
 	uint32_t *V_l = cv.take<uint32_t>(CAP);
 	StepScratch<T, SIGMA> &scr = *cv.take<StepScratch<T, SIGMA>>(1);
 	uint32_t *sscr = cv.take<uint32_t>(T / WAVE + 1);
@@ -856,7 +856,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 		}
 	}
 	__syncthreads();                          // the sort buffer (overlaying cnt_l) is dead from here
-	for (uint32_t i = tid; i < (PK ? (D0 + nb + 1u) / 2u : D0 + nb); i += T) cnt_l[i] = 0;
+	for (uint32_t i = tid; i < (PK ? (D0 + nb + 9u) / 2u : D0 + nb + 8u); i += T) cnt_l[i] = 0;     // (+8: the list reads aligned groups of ids)
 	__syncthreads();
 
 	// ---- ids + initial histogram
@@ -1116,27 +1116,53 @@ __device__ __forceinline__ void columns_body(char *smem,
 			uint64_t const k = k0 + j;
 			uint32_t const thr = (k + 2 > (uint64_t) L) ? (uint32_t) (k + 2 - L) : 0u;
 			uint2 *out = ent + k * (size_t) stride;
+			constexpr int IPL = (RED && T >= 256) ? 8 : 4;
 			int32_t const top = (int32_t) (D0 + j);
 			uint32_t cumN = 0, nent = 1, R = 0;       // cumN: count of the values below thr taken so far
 			// RED: exact -- id 0 (value 0, with the rows left out) follows behind the loop; else the ids below red_idmin are values
 			// below vmin, which the representatives cannot vouch for
 			int32_t const id_lo = (RED && red_exact) ? 1 : 0;
 			bool red_stopped = false, red_bad = false;
-			for (int32_t base = top; base >= id_lo; base -= 256)
+			// [r5] IPL ids per lane and round: eight for the reduced configurations of 256 threads and more -- their lists are hundreds
+			// of entries long (BASELINE C4: ~280 of ~500 ids visited per column), and the fixed part of a round (two scans, the ballots, the
+			// maximum) was paid twice a column by the one wave every row wave then waits for
+			// ids in aligned groups of IPL per lane, read as 8- and 16-byte LDS words: with one 4-byte read per id the lanes'
+			// addresses were IPL words apart -- an IPL-way bank conflict on every read of the one wave each column waits for
+			// (BASELINE C4: 3,900 of the list's 6,100 cycles per column).  The ids above top (at most IPL - 1) have count 0:
+			// cnt_l is zeroed that far.
+			for (int32_t base = top | (IPL - 1); base >= id_lo; base -= 64 * IPL)
 			{
-				// lane l holds the ids base - 4l - q, q = 0..3: descending ids = descending values, lane-major
-				uint32_t c[4], v[4];
+				// lane l holds the ids base - IPL l - q, q = 0 .. IPL - 1: descending ids = descending values, lane-major
+				uint32_t c[IPL], v[IPL];
 				uint32_t lane_c = 0, lane_o = 0, lane_rc = 0;
-				bool cand[4];
+				bool cand[IPL];
 #ifdef FSEQ_KC_STAMPS
 				kcs.acc[4] += 1;
 #endif
+				int32_t const hi = base - IPL * (int32_t) lane;     // = IPL - 1 (mod IPL): the group is [lo, hi], all of it >= 0 or none
+				int32_t const lo = hi - (IPL - 1);
+				uint32_t cw[IPL], vw[IPL];
 #pragma unroll
-				for (int q = 0; q < 4; ++q)
+				for (int q = 0; q < IPL; ++q) { cw[q] = 0; vw[q] = 0; }
+				if (hi >= 0)
 				{
-					int32_t const i = base - 4 * (int32_t) lane - q;
-					c[q] = (i >= id_lo) ? cnt_get<PK>(cnt_l, (uint32_t) i) : 0u;
-					v[q] = (i < 0) ? 0u : (((uint32_t) i < D0) ? V_l[i] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
+					if constexpr (PK)
+					{
+						uint32_t w[IPL / 2];
+						lds_read_words<IPL / 2>(cnt_l + ((uint32_t) lo >> 1), w);
+#pragma unroll
+						for (int q = 0; q < IPL; ++q) cw[q] = (q & 1) ? (w[q >> 1] >> 16) : (w[q >> 1] & 0xFFFFu);
+					}
+					else
+						lds_read_words<IPL>(cnt_l + lo, cw);
+					if ((uint32_t) lo < D0) lds_read_words<IPL>(V_l + lo, vw);     // (past D0: words nobody reads)
+				}
+#pragma unroll
+				for (int q = 0; q < IPL; ++q)
+				{
+					int32_t const i = hi - q;
+					c[q] = (i >= id_lo) ? cw[IPL - 1 - q] : 0u;
+					v[q] = (i < 0) ? 0u : (((uint32_t) i < D0) ? vw[IPL - 1 - q] : (uint32_t) (k0 + ((uint32_t) i - D0) + 1u));
 					bool const nz = c[q] > 0;
 					bool const rec = nz && v[q] >= thr;       // the values >= thr are a prefix of the non-zero entries
 					cand[q] = nz && !rec;
@@ -1144,6 +1170,9 @@ __device__ __forceinline__ void columns_body(char *smem,
 					lane_o += cand[q] ? 1u : 0u;
 					lane_rc += rec ? c[q] : 0u;
 				}
+#ifdef FSEQ_KC_STAMPS
+				long long const kc_e1 = clock64();
+#endif
 				// one scan for the counts (< 2^16 in all: m <= 65535) and the candidate numbers, one for the lump
 				uint32_t const inc = wave_incl_add(lane_c | (lane_o << 16));
 				uint32_t const r_tot = readlane_u32(wave_incl_add(lane_rc), 63);
@@ -1151,9 +1180,12 @@ __device__ __forceinline__ void columns_body(char *smem,
 				uint32_t run_c = (inc & 0xFFFFu) - lane_c;   // counts in front of this lane's entries
 				uint32_t run_o = (inc >> 16) - lane_o;       // candidates in front of them
 				uint32_t lastP = 0;
-				bool tk[4];
+				bool tk[IPL];
+#ifdef FSEQ_KC_STAMPS
+				long long const kc_e2 = clock64();
+#endif
 #pragma unroll
-				for (int q = 0; q < 4; ++q)
+				for (int q = 0; q < IPL; ++q)
 				{
 					// a candidate is taken while the below-thr counts in front of it do not exceed X
 					uint32_t const excN = cumN + run_c - r_tot;
@@ -1163,7 +1195,13 @@ __device__ __forceinline__ void columns_body(char *smem,
 					run_o += cand[q] ? 1u : 0u;
 					run_c += c[q];
 				}
-				uint32_t const taken = (uint32_t) (__popcll(__ballot(tk[0])) + __popcll(__ballot(tk[1])) + __popcll(__ballot(tk[2])) + __popcll(__ballot(tk[3])));
+#ifdef FSEQ_KC_STAMPS
+				long long const kc_e3 = clock64();
+				kcs.acc[0] += kc_e1 - kc_l0; kcs.acc[1] += kc_e2 - kc_e1; kcs.acc[2] += kc_e3 - kc_e2;
+#endif
+				uint32_t taken = 0;
+#pragma unroll
+				for (int q = 0; q < IPL; ++q) taken += (uint32_t) __popcll(__ballot(tk[q]));
 				// the taken entries are a prefix of the candidates: the largest inclusive count among them is the new cumN
 				uint32_t mx = lastP;
 				mx = max(mx, dpp_mov<DPP_ROW_SHR1, 0xF>(0u, mx));
@@ -1215,7 +1253,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 		printf("kc stamps block %u wave %u: work %lld wait %lld cycles per column (%u columns); step: to barrier 1 %lld, wait %lld, between %lld, wait 1b %lld\n",
 		       blockIdx.x, wave_id(), kc_work / nb, kc_wait / nb, nb, kcs.acc[0] / nb, kcs.acc[1] / nb, kcs.acc[2] / nb, kcs.acc[3] / nb);
 	if (lane_id() == 0 && wave_id() == 0 && (blockIdx.x == 100 || blockIdx.x == 3000))
-		printf("kc stamps block %u list: %lld rounds x 100 per column, %lld cycles per column, %lld entries x 100 per column, X %u D0 %u\n", blockIdx.x, kcs.acc[4] * 100 / nb, kcs.acc[5] / nb, kcs.acc[6] * 100 / nb, X, D0);
+		printf("kc stamps block %u list: %lld rounds x 100 per column, %lld cycles per column, %lld entries x 100 per column, X %u D0 %u; (last round, from the list's start) reads %lld scans %lld stores %lld\n", blockIdx.x, kcs.acc[4] * 100 / nb, kcs.acc[5] / nb, kcs.acc[6] * 100 / nb, X, D0, kcs.acc[0] / nb, kcs.acc[1] / nb, kcs.acc[2] / nb);
 #endif
 	FSEQ_CLOCK_STAMP(blockIdx.x, 1);
 	// done_host: tell the host that this block's lists and stride states are in memory (fseq_core.hpp)

@@ -109,6 +109,9 @@ def test_lists_below_the_floor_send_the_block_to_all_rows(pkg, always):
         redone += t["reduced_redone"]
         _lists_match(ctx, msa, L, every=11)
     assert redone > 0
+    # an attempt that runs again leaves its phase range like any other (roctx pushes and pops stay balanced)
+    pushes, pops, _ = pkg.debug_ranges()
+    assert pushes == pops
 
 
 def test_blocks_with_too_many_representatives_run_on_all_rows(pkg, always):
