@@ -2062,7 +2062,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	{
 		launch_reduce_check(st, c->d_red_cnt + b_lo, c->d_red_cnt_plan + b_lo, my_blocks, c->d_red_invalid + nbk);
 		if (!c->red_direct)
-			launch_reduce_msa(st, c->red_listed, c->red_max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+			launch_reduce_msa(st, c->red_listed, c->red_max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks, m, c->tune.reduced_msa_gather);
 		c->tm.reduced_blocks = c->red_plan_blocks; c->tm.reduced_rows_mean = c->red_plan_rows_mean;
 		*use = true;
 		return FSEQ_OK;
@@ -2173,7 +2173,7 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	at += c->red_nfull;
 	HIP_TRY(c, hipMemcpyAsync(c->d_red_blocks, h_blocks, (size_t) at * 4, hipMemcpyHostToDevice, st));
 	if (!c->red_direct)
-		launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks);
+		launch_reduce_msa(st, listed, max_rows, c->d_msa, c->ld, c->d_red_msa, c->red_ld, c->d_red_cnt, c->d_red_rows, cap, n, c->B, c->bsh, c->d_red_blocks, m, c->tune.reduced_msa_gather);
 	c->red_plan_valid = true; c->red_plan_X = X;
 	c->red_plan_blocks = c->tm.reduced_blocks; c->red_plan_rows_mean = c->tm.reduced_rows_mean;
 	*use = true;

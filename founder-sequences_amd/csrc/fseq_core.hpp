@@ -216,6 +216,10 @@ __device__ __forceinline__ void lds_dma16(void const *g, uint32_t lds_addr)
 	             : "=&s"(keep) : "v"(g), "s"(lds_addr) : "memory");
 }
 
+// a barrier that waits for this wave's LDS operations only (__syncthreads() also drains its global stores and whatever LDS-DMA
+// it has in flight)
+__device__ __forceinline__ void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // N consecutive 32-bit LDS words at a 4N-byte aligned address, as one or two wide reads (ds_read_b64 / ds_read_b128): lanes
 // that each take their own aligned group do not meet in a bank the way they do with N single reads N words apart
 template <int N> __device__ __forceinline__ void lds_read_words(uint32_t const *p, uint32_t (&o)[N])

@@ -83,7 +83,7 @@ bool select_chain_snap(uint32_t T, uint32_t E, ChainSnapSet *out);
 hipError_t launch_reduce_prep(hipStream_t, uint32_t grid, RedPrepArgs const &);
 void launch_reduce_check(hipStream_t, uint32_t const *cnt, uint32_t const *planned, uint32_t count, uint32_t *flags);
 void launch_reduce_msa(hipStream_t, uint32_t nblocks_listed, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,
-                       uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks);
+                       uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks, uint32_t m, bool gather_only);
 
 inline double now_ms()
 {
@@ -133,6 +133,7 @@ struct Tuning {
 	bool reduced_always = false;         // FSEQ_REDUCED_ALWAYS: the representatives whenever some block has fewer of them than rows (tests of the mixed runs)
 	int  reduced_side = -1;              // FSEQ_REDUCED_SIDE: side streams the configurations' launches may use (0 .. 3)
 	bool reduced_serial = false;         // FSEQ_REDUCED_SERIAL: the configurations' launches one after the other on the context's stream (by itself: side by side)
+	bool reduced_msa_gather = false;     // FSEQ_REDUCED_MSA_GATHER: the reduced alignment by gathers from memory (by itself: the column through LDS where it fits)
 	bool reduced_ew = false;             // FSEQ_REDUCED_EW: small blocks on two-wave workgroups (the list on a wave of its own) instead of one wave
 	int  stream_block = 0;               // FSEQ_STREAM_BLOCK: columns per block the streamed regime aims for when phase C runs on representatives
 	int  reduced_cap = 0;                // FSEQ_REDUCED_CAP: most representatives a block may have (tests: small values send blocks to the run on all rows)
@@ -182,6 +183,7 @@ struct Tuning {
 		else if (n == "FSEQ_REDUCED_ALWAYS") reduced_always = on;
 		else if (n == "FSEQ_REDUCED_SERIAL") reduced_serial = on;
 		else if (n == "FSEQ_REDUCED_SIDE") reduced_side = on ? std::max(0, std::min(3, iv)) : -1;
+		else if (n == "FSEQ_REDUCED_MSA_GATHER") reduced_msa_gather = on;
 		else if (n == "FSEQ_STREAM_BLOCK") stream_block = on ? std::max(64, iv) : 0;
 		else return false;
 		return true;
@@ -194,7 +196,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS", "FSEQ_REDUCED_SERIAL", "FSEQ_REDUCED_SIDE"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS", "FSEQ_REDUCED_SERIAL", "FSEQ_REDUCED_SIDE", "FSEQ_REDUCED_MSA_GATHER"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}

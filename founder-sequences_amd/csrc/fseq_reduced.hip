@@ -96,10 +96,45 @@ void launch_reduce_check(hipStream_t st, uint32_t const *cnt, uint32_t const *pl
 	if (count) hipLaunchKernelGGL(k_reduce_check, dim3((count + 255u) / 256u), dim3(256), 0, st, cnt, planned, count, flags);
 }
 
+template <int BSH, int R>
+static bool launch_reduce_msa_lds(hipStream_t st, uint32_t nlisted, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,
+                                  uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t const *blocks, uint32_t colbytes)
+{
+	static bool prepared = false;
+	size_t const lds = (size_t) 2 * R * 16384;
+	if (!prepared)
+	{
+		if (hipFuncSetAttribute(reinterpret_cast<void const *>(&k_reduce_msa_lds<BSH, R>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds) != hipSuccess)
+		{
+			(void) hipGetLastError();
+			return false;
+		}
+		prepared = true;
+	}
+	// (a quarter of a block's columns per workgroup: the rows are read four times, the blocks' columns are enough workgroups)
+	hipLaunchKernelGGL((k_reduce_msa_lds<BSH, R>), dim3(nlisted, 4), dim3(1024), lds, st, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes);
+	return true;
+}
+
 void launch_reduce_msa(hipStream_t st, uint32_t nlisted, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,
-                       uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks)
+                       uint32_t const *rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t bsh, uint32_t const *blocks, uint32_t m, bool gather_only)
 {
 	if (!nlisted) return;
+	uint32_t const colbytes = sym_bytes(m, bsh);
+	// the column through LDS where it fits two buffers of at most 32 KB and the representatives the registers of 1,024 threads
+	if (!gather_only && colbytes <= 32768u && cap <= 12288u)
+	{
+		bool const one = colbytes <= 16384u;
+		bool ok = false;
+		switch (bsh)
+		{
+		case 0: ok = one ? launch_reduce_msa_lds<0, 1>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes) : launch_reduce_msa_lds<0, 2>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes); break;
+		case 1: ok = one ? launch_reduce_msa_lds<1, 1>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes) : launch_reduce_msa_lds<1, 2>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes); break;
+		case 2: ok = one ? launch_reduce_msa_lds<2, 1>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes) : launch_reduce_msa_lds<2, 2>(st, nlisted, msa, ld, red, ldr, cnt, rows, cap, n, B, blocks, colbytes); break;
+		default: break;
+		}
+		if (ok) return;
+	}
 	uint32_t const nq = (max_rows + (1u << bsh) - 1u) >> bsh;
 	hipLaunchKernelGGL(k_reduce_msa, dim3(nlisted, (nq + 63u) / 64u), dim3(256), 0, st, msa, ld, red, ldr, cnt, rows, cap, n, B, bsh, blocks);
 }

@@ -271,6 +271,79 @@ static __global__ __launch_bounds__(256) void k_reduce_msa(
 	}
 }
 
+// The same with the alignment's column staged in LDS (a column of at most R x 16 KB: 131,072 rows of 2-bit symbols).  The
+// form above gathers bytes at ~7,000 of BASELINE C4's 100,000 rows straight from memory -- every line of the column comes in
+// for a few of its bytes, by way of some thirty workgroups per block on as many CUs, and the gathers' round trips bound it
+// (3.1 TB/s over the alignment's 125 GB).  Here workgroup (x, y) takes a quarter of block blocks[x]'s columns: a column is
+// R LDS-DMA pieces per lane, contiguous, one column ahead of the one being gathered (s_waitcnt vmcnt(R): the pieces of the
+// column in front have landed, the next one's stay in flight -- loads return in order); the representatives' rows stay in
+// registers (output byte q = thread + 1024 i, its 1 << BSH rows), the gathers are LDS byte reads.
+template <int BSH, int R>
+__global__ __launch_bounds__(1024) void k_reduce_msa_lds(
+	uint8_t const *__restrict__ msa, size_t ld, uint8_t *__restrict__ red, size_t ldr, uint32_t const *__restrict__ cnt,
+	uint32_t const *__restrict__ rows, uint32_t cap, uint64_t n, uint32_t B, uint32_t const *__restrict__ blocks, uint32_t colbytes)
+{
+	constexpr uint32_t RPB = 1u << BSH, BITS = 8u >> BSH, CMASK = (1u << BITS) - 1u;
+	constexpr uint32_t NOUT = (12288u / RPB + 1023u) / 1024u;          // output bytes per thread: 12,288 representatives at most
+	constexpr uint32_t BUF = (uint32_t) R * 16384u;
+	extern __shared__ __attribute__((aligned(16))) char smem[];         // two columns of BUF bytes
+	uint32_t const blk = blocks[blockIdx.x];
+	uint32_t const Lr = cnt[blk];
+	if (Lr == RED_NONE) return;
+	uint32_t const tid = threadIdx.x;
+	uint32_t const nq = (Lr + RPB - 1u) >> BSH;
+	uint64_t const k0 = (uint64_t) blk * B;
+	uint32_t const nb = (uint32_t) (((k0 + B < n) ? k0 + B : n) - k0);
+	uint32_t const per = (nb + gridDim.y - 1u) / gridDim.y;
+	uint32_t const j_lo = min(nb, blockIdx.y * per), j_hi = min(nb, j_lo + per);
+	if (j_lo >= j_hi) return;
+	uint32_t row[NOUT][RPB];
+#pragma unroll
+	for (uint32_t i = 0; i < NOUT; ++i)
+#pragma unroll
+		for (uint32_t r = 0; r < RPB; ++r)
+		{
+			uint32_t const idx = (tid + 1024u * i) * RPB + r;
+			row[i][r] = idx < Lr ? rows[(size_t) blk * cap + idx] : 0u;
+		}
+	uint32_t const base = (uint32_t) (uintptr_t) smem;
+	auto stage = [&](uint64_t k, uint32_t buf) {
+		uint8_t const *const col = msa + k * ld;
+#pragma unroll
+		for (uint32_t r = 0; r < (uint32_t) R; ++r)
+		{
+			// (every wave issues R pieces -- the count s_waitcnt goes by; a piece past the column's bytes re-reads its first)
+			uint32_t const off = r * 16384u + tid * 16u;
+			lds_dma16(col + (off < colbytes ? off : 0u), __builtin_amdgcn_readfirstlane(base + buf * BUF + r * 16384u + wave_id() * 1024u));
+		}
+	};
+	stage(k0 + j_lo, 0u);
+	for (uint32_t j = j_lo; j < j_hi; ++j)
+	{
+		uint32_t const cur = (j - j_lo) & 1u;
+		if (j + 1u < j_hi)
+		{
+			stage(k0 + j + 1u, cur ^ 1u);
+			if constexpr (R == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+		}
+		else
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		lds_only_barrier();
+		uint8_t const *const colb = reinterpret_cast<uint8_t const *>(smem) + cur * BUF;
+#pragma unroll
+		for (uint32_t i = 0; i < NOUT; ++i)
+		{
+			uint32_t const q = tid + 1024u * i;
+			uint32_t v = 0;
+#pragma unroll
+			for (uint32_t r = 0; r < RPB; ++r)
+				v |= (((uint32_t) colb[row[i][r] >> BSH] >> ((row[i][r] & (RPB - 1u)) * BITS)) & CMASK) << (r * BITS);
+			if (q < nq) red[(k0 + j) * ldr + q] = (uint8_t) v;
+		}
+		lds_only_barrier();                   // (everybody has read the column the piece after next lands on)
+	}
+}
+
 // ------------------------------------------------------------------------------------------------
 // Pass 2: one chain step per boundary (k_chain's step with the class tables of k_columns_red as the key block).
 // Workgroup t: boundary task t in block task_blk[t]; ncls[t] == 0: the boundary IS the block's boundary state (a copy).

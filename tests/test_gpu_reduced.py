@@ -41,6 +41,8 @@ SHAPES = [
     (9000, 2000, 40, 200, 400, 2e-4, 64, 0, 128),        # hundreds of founders: 256 .. 1024-thread configurations
     (12000, 2400, 20, 12, 300, 3e-4, 65, 0, 100),        # streamed rows: the reduced alignment, the streamed chain step
     (30000, 1500, 25, 40, 500, 1e-4, 66, 0, 150),
+    (13000, 1200, 20, 12, 300, 3e-4, 69, 1, 100),        # streamed rows of 4-bit symbols
+    (70000, 600, 20, 30, 200, 1e-4, 70, 0, 100),         # a column of more than 16 KB: two LDS-DMA pieces per lane in k_reduce_msa_lds
     (300, 2000, 3, 5, 100, 2e-3, 67, 0, 16),             # L = 3: thresholds right behind the column
     (64, 1500, 200, 4, 300, 1e-3, 68, 0, 50),            # L >> block length: every early block is exact (vmin = 1)
 ]
@@ -60,6 +62,16 @@ def test_reduced_run_matches_oracle(pkg, always, m, n, L, K, Brec, mu, seed, kin
     for i in (0, len(ctx.reduced_traceback()) // 2, len(ctx.reduced_traceback()) - 1):
         a, d = ctx.boundary_state(i)
         assert np.array_equal(a, ref["a"][i]) and np.array_equal(d, ref["d"][i])
+
+
+def test_reduced_alignment_by_gathers(pkg, always):
+    """FSEQ_REDUCED_MSA_GATHER: the representatives' columns gathered from memory (the form for columns that do not fit two LDS
+    buffers) instead of through LDS."""
+    always.setenv("FSEQ_REDUCED_MSA_GATHER", "1")
+    for (m, n, L, K, Brec, mu, seed, kind, B) in [(12000, 2400, 20, 12, 300, 3e-4, 65, 0, 100), (13000, 1200, 20, 12, 300, 3e-4, 69, 1, 100)]:
+        msa = fso.synth_msa(fso.synth_spec(seed, K, Brec, mu, kind), m, n)
+        ctx, _ = compare_long(pkg, msa, L, block_len=B)
+        assert ctx.timings()["reduced_blocks"] > 0
 
 
 def _lists_match(ctx, msa, L, every=5):
