@@ -9,6 +9,7 @@
 #include "fseq_ctx.hpp"
 #include "fseq_join.hpp"
 #include "fseq_joinprep.hpp"
+#include "fseq_joinbip.hpp"
 
 using namespace fseq;
 
@@ -122,6 +123,61 @@ static int fetch_boundary_states(fseq_ctx *c, std::vector<uint32_t> &A, std::vec
 int fseq_join_bipartite(fseq_ctx *c, uint32_t *permutations)
 {
 	if (!c || !permutations) return FSEQ_E_ARG;
+	if (!c->have_result || c->res.short_path) return FSEQ_E_ARG;
+	if (c->segments.empty()) return fail(c, FSEQ_E_ARG, "no segments to join (segmentation failed or was not run)");
+	size_t const m = c->p.m, S = c->segments.size();
+	uint32_t const X = c->res.max_segment_size;
+	// [r5] texts, intersection weights, the matchings and their chaining where the boundary states are (fseq_joinbip.hpp);
+	// falls through to the host joiner when the tables do not fit a workgroup's LDS or cannot be allocated
+	bool tiled = true;                                           // (lb of a segment = rb of the one in front: what k_join_classes goes by)
+	for (size_t i = 0; tiled && i < S; ++i) tiled = c->segments[i].lb == (i ? c->segments[i - 1].rb : 0u);
+	while (tiled && !c->sh.on && X >= 1 && X <= JP_MAX_CLASSES && m <= 0xFFFFFFFFull && S <= 0xFFFFFFFFull && !c->tune.join_host)
+	{
+		(void) hipSetDevice(c->p.device);
+		double const t0 = now_ms();
+		hipStream_t st = c->stream;
+		uint16_t *d_of = nullptr, *d_tpos = nullptr, *d_src = nullptr, *d_match = nullptr;
+		uint32_t *d_rep = nullptr, *d_size = nullptr, *d_count = nullptr, *d_min = nullptr, *d_reprow = nullptr, *d_perm = nullptr;
+		uint64_t *d_rb = nullptr;
+		int rc;
+		auto cleanup = [&]() { dev_free(c, &d_of); dev_free(c, &d_tpos); dev_free(c, &d_src); dev_free(c, &d_match); dev_free(c, &d_rep); dev_free(c, &d_size);
+		                       dev_free(c, &d_count); dev_free(c, &d_min); dev_free(c, &d_reprow); dev_free(c, &d_perm); dev_free(c, &d_rb); };
+		if ((rc = dev_alloc(c, &d_of, S * m)) || (rc = dev_alloc(c, &d_tpos, S * X)) || (rc = dev_alloc(c, &d_src, S * X)) || (rc = dev_alloc(c, &d_match, S * X)) ||
+		    (rc = dev_alloc(c, &d_rep, S * X)) || (rc = dev_alloc(c, &d_size, S * X)) || (rc = dev_alloc(c, &d_count, S)) || (rc = dev_alloc(c, &d_min, S * X)) ||
+		    (rc = dev_alloc(c, &d_reprow, S * X)) || (rc = dev_alloc(c, &d_perm, S * X)) || (rc = dev_alloc(c, &d_rb, S)))
+		{
+			cleanup();
+			if (rc == FSEQ_E_OOM) { c->err.clear(); break; }
+			return rc;
+		}
+		std::vector<uint64_t> rbs(S);
+		for (size_t i = 0; i < S; ++i) rbs[i] = c->segments[i].rb;
+		hipError_t e = hipMemcpyAsync(d_rb, rbs.data(), S * 8, hipMemcpyHostToDevice, st);
+		size_t const lds_match = bip_match_lds_bytes(X), lds_chain = bip_chain_lds_bytes(X);
+		if (e == hipSuccess) e = allow_lds(k_bip_match, lds_match);
+		if (e == hipSuccess) e = allow_lds(k_bip_chain, lds_chain);
+		if (e != hipSuccess) { cleanup(); return fail(c, FSEQ_E_HIP, "bipartite join preparation", e); }
+		// (a segment's classes: the rows that agree on [lb, rb), lb = the segment in front's rb -- the merged segments tile the columns)
+		hipLaunchKernelGGL(k_join_classes, dim3((uint32_t) S), dim3(JP_T), 0, st, c->d_snap_a, c->d_snap_d, d_rb, (uint32_t) m, X, d_of, d_rep, d_size, d_count);
+		hipLaunchKernelGGL(k_bip_minrow, dim3((uint32_t) S), dim3(JP_T), 0, st, d_of, (uint32_t) m, X, d_min);
+		hipLaunchKernelGGL(k_bip_texts, dim3((uint32_t) S), dim3(64), 0, st, d_count, d_size, d_min, (uint32_t) m, X, d_tpos, d_src, d_reprow);
+		if (S > 1)
+			hipLaunchKernelGGL(k_bip_match, dim3((uint32_t) (S - 1)), dim3(64), lds_match, st, d_of, d_count, d_tpos, d_src, (uint32_t) m, X, d_match, (long long *) nullptr);
+		hipLaunchKernelGGL(k_bip_chain, dim3(1), dim3(JB_CHAIN_T), lds_chain, st, d_match, d_reprow, (uint32_t) S, X, d_perm);
+		std::vector<uint32_t> count(S);
+		e = hipMemcpyAsync(count.data(), d_count, S * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipMemcpyAsync(permutations, d_perm, S * X * 4, hipMemcpyDeviceToHost, st);
+		if (e == hipSuccess) e = hipStreamSynchronize(st);
+		if (e == hipSuccess) e = hipGetLastError();
+		cleanup();
+		if (e != hipSuccess) return fail(c, FSEQ_E_HIP, "bipartite join", e);
+		bool sane = true;
+		for (size_t i = 0; sane && i < S; ++i) sane = count[i] >= 1 && count[i] <= X;
+		if (!sane) break;                                         // (implausible class tables: the host joiner builds its own)
+		double const t1 = now_ms();
+		c->jp = fseq_join_profile{0.0, 0.0, 0.0, t1 - t0, t1 - t0, (uint64_t) S * X * 4ull + (uint64_t) S * 4ull};
+		return FSEQ_OK;
+	}
 	std::vector<uint32_t> A, D;
 	std::vector<JoinSegment> segs;
 	int const rc = fetch_boundary_states(c, A, D, segs);

@@ -432,7 +432,9 @@ inline std::vector<SegmentText> create_segment_texts(
 	if (seg_idx < max_segment_size)                                                // :37-80
 	{
 		size_t remaining = max_segment_size - seg_idx;
-		std::sort(texts.begin(), texts.begin() + seg_idx, [](SegmentText const &x, SegmentText const &y) {
+		// (the reference's std::sort leaves the order of equal sizes to the standard library it was built with; here they keep
+		// the classes' pBWT order, which is also what the device form computes, fseq_joinbip.hpp)
+		std::stable_sort(texts.begin(), texts.begin() + seg_idx, [](SegmentText const &x, SegmentText const &y) {
 			return x.sequence_indices.size() > y.sequence_indices.size();
 		});
 		size_t const limit = seg_idx;
