@@ -389,6 +389,11 @@ __device__ __forceinline__ uint2 cm_load(ChainMultiGeom const &g, uint32_t const
 	uint2 const *src = ((g.npass - pass) & 1u) ? g.pairA : g.pairB;
 	return src[i];
 }
+// [r5] the first pass's pairs are made ONCE, by its count sweep, which leaves them in the pair buffer the pass does not
+// write (dead until the second pass overwrites it): rank[row] is a gather at a random row of a table of m words per block --
+// a 64-byte line from memory for 4 bytes, thousands of chains side by side -- and the scatter sweep used to make it again
+// (BASELINE C4, 2,048 chains: 3.5 ms of every step's 9)
+__device__ __forceinline__ uint2 *cm_stage(ChainMultiGeom const &g) { return (g.npass & 1u) ? g.pairA : g.pairB; }
 
 // start state of every chain of the launch into its workspace (and out_state in front of its first block)
 __global__ __launch_bounds__(CM_WG) void k_cm_init(ChainMultiArgs const A)
@@ -427,6 +432,12 @@ __global__ __launch_bounds__(CM_WG) void k_cm_count(ChainMultiArgs const A)
 		uint2 pr[U];
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? cm_load(g, rk, A.pass, i) : make_uint2(0u, 0u); }
+		if (A.pass == 0u)
+		{
+			uint2 *const stage = cm_stage(g);
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; if (i < hi) stage[i] = pr[u]; }
+		}
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 			if (i0 + u * 64u + lane < hi) atomicAdd(&hist[wave][(cm_key(pr[u]) >> shift) & (g.nbins - 1u)], 1u);
@@ -526,7 +537,11 @@ __global__ __launch_bounds__(CM_WG) void k_cm_scatter(ChainMultiArgs const A)
 	{
 		uint2 pr[U];
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? cm_load(g, rk, A.pass, i) : make_uint2(0u, 0u); }
+		for (uint32_t u = 0; u < U; ++u)
+		{
+			uint32_t const i = i0 + u * 64u + lane;
+			pr[u] = i < hi ? (A.pass == 0u ? cm_stage(g)[i] : cm_load(g, rk, A.pass, i)) : make_uint2(0u, 0u);
+		}
 #pragma unroll
 		for (uint32_t u = 0; u < U; ++u)
 		{
