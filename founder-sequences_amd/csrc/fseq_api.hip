@@ -1122,7 +1122,9 @@ void launch_chain(fseq_ctx *c, uint32_t grid, uint32_t const *rank, uint32_t con
 		A.rank = rank; A.keyd = keyd; A.nkeys = nkeys; A.m = m; A.nb_total = nb_total; A.G = G; A.cols_per_block = cols_per_block;
 		A.ws = c->d_ws; A.hist = c->d_cshist; A.start_a = start_a; A.start_d = start_d; A.out_state_a = out_a; A.out_state_d = out_d;
 		A.out_rank = out_rank; A.out_keyd = out_keyd; A.out_nkeys = out_nkeys; A.grp0 = grp0; A.step = 0; A.pass = 0;
-		dim3 const by_row((m + CM_WG - 1u) / CM_WG, grid), by_part((nparts + CM_WG / WAVE - 1u) / (CM_WG / WAVE), grid);
+		A.nchains = grid; A.xcd_map = c->tune.chain_no_xcd_map ? 0u : 1u;
+		uint32_t const grid_y = A.xcd_map ? (grid + 7u) & ~7u : grid;       // (cm_wg: the workgroups of a chain on one XCD)
+		dim3 const by_row((m + CM_WG - 1u) / CM_WG, grid_y), by_part((nparts + CM_WG / WAVE - 1u) / (CM_WG / WAVE), grid_y);
 		hipLaunchKernelGGL(k_cm_init, by_row, dim3(CM_WG), 0, c->stream, A);
 		for (uint32_t s_ = 0; s_ < G; ++s_)
 		{

@@ -332,7 +332,28 @@ struct ChainMultiArgs {
 	uint32_t grp0;
 	uint32_t step;                               // block b0 + step of every chain
 	uint32_t pass;                               // radix pass of the sweep kernels
+	uint32_t nchains;                            // chains of the launch (the grid's y is rounded up to the XCDs)
+	uint32_t xcd_map;                            // the workgroups of a chain on ONE XCD (cm_wg)
 };
+
+// [r5] Which (part group, chain) a workgroup of the part / row kernels takes.  The hardware hands consecutive workgroups to
+// the eight XCDs in turn, so with (x, y) = (part group, chain) taken as they come the twenty-five workgroups of a chain land
+// on all eight -- and each XCD's L2 fetches the chain's tables for an eighth of its gathers: rank[row] of the first count
+// sweep, the pair buffers of the scatter sweeps, d0 / the block maxima of the output sweep are all addressed at random inside
+// arrays of m words that belong to ONE chain (400 KB each at m = 100,000; an L2 is 4 MB).  Here workgroup L goes to XCD
+// L mod 8 and takes chain 8 (slot / nx) + (L mod 8), slot = L / 8: the workgroups of a chain are consecutive slots of one XCD.
+struct CmWg { uint32_t x, chain; bool ok; };
+__device__ __forceinline__ CmWg cm_wg(ChainMultiArgs const &A)
+{
+	CmWg w;
+	if (!A.xcd_map) { w.x = blockIdx.x; w.chain = blockIdx.y; w.ok = blockIdx.y < A.nchains; return w; }
+	uint32_t const nx = gridDim.x, L = blockIdx.y * nx + blockIdx.x;
+	uint32_t const xcd = L & 7u, slot = L >> 3;
+	w.chain = (slot / nx) * 8u + xcd;
+	w.x = slot % nx;
+	w.ok = w.chain < A.nchains;
+	return w;
+}
 
 __host__ __device__ inline uint32_t chainmulti_parts(uint32_t m) { return (m + CM_PART - 1u) / CM_PART; }
 __host__ __device__ inline uint32_t chainmulti_passes(uint32_t m)
@@ -398,12 +419,14 @@ __device__ __forceinline__ uint2 *cm_stage(ChainMultiGeom const &g) { return (g.
 // start state of every chain of the launch into its workspace (and out_state in front of its first block)
 __global__ __launch_bounds__(CM_WG) void k_cm_init(ChainMultiArgs const A)
 {
-	uint32_t const chain = blockIdx.y, grp = chain + A.grp0, m = A.m;
+	CmWg const wg = cm_wg(A);
+	if (!wg.ok) return;
+	uint32_t const chain = wg.chain, grp = chain + A.grp0, m = A.m;
 	uint32_t const b0 = grp * A.G;
 	if (b0 >= A.nb_total) return;
 	uint32_t const kstart = (uint32_t) ((uint64_t) b0 * A.cols_per_block);
 	uint32_t *w = A.ws + (size_t) chain * chainsort_ws_words(m);
-	uint32_t const i = blockIdx.x * CM_WG + threadIdx.x;
+	uint32_t const i = wg.x * CM_WG + threadIdx.x;
 	if (i >= m) return;
 	uint32_t const av = A.start_a ? A.start_a[(size_t) grp * m + i] : i;
 	uint32_t const dv = A.start_d ? A.start_d[(size_t) grp * m + i] : kstart;
@@ -416,10 +439,12 @@ __global__ __launch_bounds__(CM_WG) void k_cm_init(ChainMultiArgs const A)
 __global__ __launch_bounds__(CM_WG) void k_cm_count(ChainMultiArgs const A)
 {
 	__shared__ uint32_t hist[CM_WG / WAVE][CS_BINS];
-	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	CmWg const wg = cm_wg(A);
+	if (!wg.ok) return;
+	ChainMultiGeom const g = chainmulti_geom(A, wg.chain);
 	if (!g.active || A.pass >= g.npass) return;
 	uint32_t const lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint32_t const part = blockIdx.x * (CM_WG / WAVE) + wave, m = A.m;
+	uint32_t const part = wg.x * (CM_WG / WAVE) + wave, m = A.m;
 	uint32_t const lo = part * CM_PART;
 	if (lo >= m) return;
 	uint32_t const hi = min(m, lo + CM_PART);
@@ -520,10 +545,12 @@ __global__ __launch_bounds__(ST) void k_cm_offsets(ChainMultiArgs const A)
 __global__ __launch_bounds__(CM_WG) void k_cm_scatter(ChainMultiArgs const A)
 {
 	__shared__ uint32_t offs[CM_WG / WAVE][CS_BINS];
-	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	CmWg const wg = cm_wg(A);
+	if (!wg.ok) return;
+	ChainMultiGeom const g = chainmulti_geom(A, wg.chain);
 	if (!g.active || A.pass >= g.npass) return;
 	uint32_t const lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	uint32_t const part = blockIdx.x * (CM_WG / WAVE) + wave, m = A.m;
+	uint32_t const part = wg.x * (CM_WG / WAVE) + wave, m = A.m;
 	uint32_t const lo = part * CM_PART;
 	if (lo >= m) return;
 	uint32_t const hi = min(m, lo + CM_PART);
@@ -560,9 +587,11 @@ __global__ __launch_bounds__(CM_WG) void k_cm_scatter(ChainMultiArgs const A)
 // the new order of every chain (and out_state behind the block, where the contract asks for it)
 __global__ __launch_bounds__(CM_WG) void k_cm_output(ChainMultiArgs const A)
 {
-	ChainMultiGeom const g = chainmulti_geom(A, blockIdx.y);
+	CmWg const wg = cm_wg(A);
+	if (!wg.ok) return;
+	ChainMultiGeom const g = chainmulti_geom(A, wg.chain);
 	if (!g.active) return;
-	uint32_t const m = A.m, p = blockIdx.x * CM_WG + threadIdx.x;
+	uint32_t const m = A.m, p = wg.x * CM_WG + threadIdx.x;
 	if (p >= m) return;
 	uint32_t const nblk = (m + 63u) / 64u;
 	uint32_t const *kd = A.keyd + (size_t) g.b * m;
@@ -593,7 +622,7 @@ __global__ __launch_bounds__(CM_WG) void k_cm_output(ChainMultiArgs const A)
 	}
 	uint32_t const row = cm_row(me);
 	g.a1[p] = row; g.d1[p] = dv;
-	uint32_t const grp = blockIdx.y + A.grp0;
+	uint32_t const grp = wg.chain + A.grp0;
 	uint32_t const b1 = min(A.nb_total, grp * A.G + A.G);
 	// out_state: the state in front of every block of the chain, and behind the last block of the whole sequence
 	if (A.out_state_a && (g.b + 1u < b1 || g.b + 1u == A.nb_total))

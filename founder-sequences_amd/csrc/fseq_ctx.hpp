@@ -133,6 +133,7 @@ struct Tuning {
 	bool reduced_always = false;         // FSEQ_REDUCED_ALWAYS: the representatives whenever some block has fewer of them than rows (tests of the mixed runs)
 	int  reduced_side = -1;              // FSEQ_REDUCED_SIDE: side streams the configurations' launches may use (0 .. 3)
 	bool reduced_serial = false;         // FSEQ_REDUCED_SERIAL: the configurations' launches one after the other on the context's stream (by itself: side by side)
+	bool chain_no_xcd_map = false;       // FSEQ_CHAIN_NO_XCD_MAP: the streamed phase B's workgroups taken as they come (by itself: a chain's on one XCD)
 	bool reduced_msa_gather = false;     // FSEQ_REDUCED_MSA_GATHER: the reduced alignment by gathers from memory (by itself: the column through LDS where it fits)
 	bool reduced_ew = false;             // FSEQ_REDUCED_EW: small blocks on two-wave workgroups (the list on a wave of its own) instead of one wave
 	int  stream_block = 0;               // FSEQ_STREAM_BLOCK: columns per block the streamed regime aims for when phase C runs on representatives
@@ -184,6 +185,7 @@ struct Tuning {
 		else if (n == "FSEQ_REDUCED_SERIAL") reduced_serial = on;
 		else if (n == "FSEQ_REDUCED_SIDE") reduced_side = on ? std::max(0, std::min(3, iv)) : -1;
 		else if (n == "FSEQ_REDUCED_MSA_GATHER") reduced_msa_gather = on;
+		else if (n == "FSEQ_CHAIN_NO_XCD_MAP") chain_no_xcd_map = on;
 		else if (n == "FSEQ_STREAM_BLOCK") stream_block = on ? std::max(64, iv) : 0;
 		else return false;
 		return true;
@@ -196,7 +198,7 @@ struct Tuning {
 			"FSEQ_CHAIN_FAN", "FSEQ_TWO_LEVEL_CHAIN", "FSEQ_BLOCKKEYS_WIDE", "FSEQ_BLOCKKEYS_SINGLE", "FSEQ_BLOCKKEYS_CAP", "FSEQ_STREAM2", "FSEQ_SS_UNPACKED", "FSEQ_SNAP_STRIDE",
 			"FSEQ_POISON_LISTS", "FSEQ_NO_EMITTER_WAVE", "FSEQ_JOIN_HOST", "FSEQ_INJECT_FAILURE_RANK", "FSEQ_SYNC_PHASES", "FSEQ_CHECK_PHASE_A",
 			"FSEQ_SHARD_DP_FULL", "FSEQ_SHARD_DP_WINDOW", "FSEQ_BLOCKKEYS_NO_LIMIT", "FSEQ_CHAIN_STREAM_PASSES", "FSEQ_CHAIN_STREAM_SINGLE", "FSEQ_SS_ABSOLUTE",
-			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS", "FSEQ_REDUCED_SERIAL", "FSEQ_REDUCED_SIDE", "FSEQ_REDUCED_MSA_GATHER"};
+			"FSEQ_NO_BLOCKTRIE", "FSEQ_BLOCKTRIE_ALWAYS", "FSEQ_NO_DENSE_COLUMNS", "FSEQ_NO_REDUCED", "FSEQ_REDUCED_MARGIN", "FSEQ_REDUCED_CAP", "FSEQ_REDUCED_EW", "FSEQ_STREAM_BLOCK", "FSEQ_REDUCED_ALWAYS", "FSEQ_REDUCED_SERIAL", "FSEQ_REDUCED_SIDE", "FSEQ_REDUCED_MSA_GATHER", "FSEQ_CHAIN_NO_XCD_MAP"};
 		for (char const *nm : names)
 			if (char const *v = getenv(nm)) (void) set(nm, v);
 	}
