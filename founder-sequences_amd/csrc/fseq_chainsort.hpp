@@ -264,6 +264,7 @@ __global__ __launch_bounds__(ST) void k_chain_stream_sort(
 		uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
 		if (out_state_a)
 			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = a[i]; out_state_d[(size_t) b * m + i] = d[i]; }
+		if (b + 1 == b1 && !out_rank && b1 != nb_total) break;       // (an expansion's last step: k_chain, fseq_kernels.hpp)
 		chain_step_sorted(m, rank + (size_t) b * m, keyd + (size_t) b * m, nkeys[b], w, cur, S, L);
 		cur ^= 1u;
 	}
@@ -380,7 +381,9 @@ __device__ __forceinline__ ChainMultiGeom chainmulti_geom(ChainMultiArgs const &
 	uint32_t const grp = chain + A.grp0;
 	uint32_t const b0 = grp * A.G, b1 = min(A.nb_total, b0 + A.G);
 	g.b = b0 + A.step;
-	g.active = g.b < b1;
+	// (an expansion -- states wanted, no composite keys -- does not step through a chain's last block unless that is the last
+	// of all: the state behind it is the next chain's start state, k_chain in fseq_kernels.hpp)
+	g.active = g.b < b1 && (A.out_rank != nullptr || g.b + 1u < b1 || g.b + 1u == A.nb_total);
 	uint32_t const nk = g.active ? A.nkeys[g.b] : 1u;
 	uint32_t bits = 1;
 	while (bits < 32u && ((nk - 1u) >> bits) != 0u) ++bits;

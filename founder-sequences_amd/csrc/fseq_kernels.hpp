@@ -543,6 +543,9 @@ __global__ __launch_bounds__(T) void k_chain(
 				if (idx < m) { out_state_a[ob + idx] = a_l[idx]; out_state_d[ob + idx] = d_l[idx]; }
 			}
 		}
+		// [r5] the state behind a chain's last block is the start state of the next chain, which the level above has given it:
+		// an expansion (states wanted, no composite keys) does not step through its last block unless that is the last of all
+		if (b + 1 == b1 && !out_rank && b1 != nb_total) break;
 		// (2) prefetch the next block's rank / keyd into registers
 		// (16-bit configurations, 9+ rows per thread at 128 registers: the 2 E prefetched words were spilled to scratch
 		// across the digit passes -- there the loads only warm L2 now and are issued again in (5))

@@ -441,6 +441,7 @@ __global__ __launch_bounds__(ST) void k_chain_stream(
 		uint32_t const *rk = rank + (size_t) b * m, *kd = keyd + (size_t) b * m;
 		if (out_state_a)
 			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = buf[cur][0][i]; out_state_d[(size_t) b * m + i] = buf[cur][1][i]; }
+		if (b + 1 == b1 && !out_rank && b1 != nb_total) break;       // (an expansion's last step: k_chain, fseq_kernels.hpp)
 		uint32_t const nd = rank_digits(nkeys[b]);
 		rank_digit_counts(rk, m, nd, L);
 		for (uint32_t p = 0; p < nd; ++p)
