@@ -464,6 +464,29 @@ void block_geometry(fseq_ctx *c)
 			uint32_t const cost = (2u * lv - 1u) * (2u * g + 1u);
 			if (cost < best_cost) { best_cost = cost; best_g = g; }
 		}
+		// [r5] streamed rows: a step is a launch sequence over all the chains of a level (fseq_chainsort.hpp), bound by what it
+		// moves, not by its depth -- so the fan weighs the steps in all (the blocks of every level once on the way up, all but
+		// every chain's last on the way down: ~N (2g - 1) / (g - 1)) against the rounds of launches, (2g - 1) per level.
+		// BASELINE C4 (6,143 blocks, 100,000 rows), phase B: fan 3: 69.6 ms, 4: 61.6, 6: 56.5, 8: 54.1, 12: 50.9, 16: 53.7, 32: 57.5
+		KernelSet probe;
+		if (!select_kernels(p.m, c->sigma, &probe, c->tune.no_emitter_wave) && c->nblocks > 8)
+		{
+			double best = 1e300;
+			for (uint32_t g = 2; g <= 64 && g < c->nblocks; ++g)
+			{
+				double steps = 0, rounds = 0;
+				uint64_t cnt = c->nblocks;
+				while (cnt > g)
+				{
+					steps += (double) cnt * (2.0 * g - 1.0) / g;       // up: every item; down: all but the last of every group
+					rounds += 2.0 * g - 1.0;
+					cnt = (cnt + g - 1) / g;
+				}
+				steps += (double) cnt; rounds += (double) cnt;           // the top chain
+				double const cost = steps * 3.5e-3 * ((double) p.m / 1e5) + rounds * 0.05;
+				if (cost < best) { best = cost; best_g = g; }
+			}
+		}
 		if (c->nblocks <= 8) best_g = std::max(1u, c->nblocks);        // one chain
 		if (c->tune.two_level_chain) best_g = std::max(2u, (uint32_t) std::ceil(std::sqrt((double) c->nblocks)));
 		if (c->tune.chain_fan) best_g = (uint32_t) c->tune.chain_fan;
