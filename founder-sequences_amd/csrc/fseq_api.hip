@@ -2142,6 +2142,15 @@ int red_plan(fseq_ctx *c, uint32_t X, bool *use)
 	if (c->tune.debug)
 		fprintf(stderr, "[fseq] reduced phase C: %u of %u blocks on their representatives (mean %u of %u rows, most %u), %u on all rows\n", my_blocks - n_full, my_blocks,
 		        c->tm.reduced_rows_mean, m, max_rows, n_full);
+	if (c->tune.debug)
+		for (int i = 0; i < nconf; ++i)
+			if (!per[(size_t) i].empty())
+			{
+				uint64_t sr = 0;
+				for (uint32_t b : per[(size_t) i]) sr += c->red_cnt_host[b];
+				fprintf(stderr, "[fseq]   configuration of %u rows: %zu blocks, %llu representatives on average\n", sets[(size_t) i].rows, per[(size_t) i].size(),
+				        (unsigned long long) (sr / per[(size_t) i].size()));
+			}
 	// worth it?  The run on all rows is the tuned one (three workgroups per CU, stride states for pass 2), and a row of a small
 	// reduced workgroup costs more than a row there: the representatives take over where they are clearly fewer -- rows to
 	// update in all, a block on all rows counted as one and a half (its boundaries are reached from the block's start) -- below
