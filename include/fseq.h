@@ -242,7 +242,10 @@ int  fseq_greedy_match_host(uint32_t m, uint32_t max_segment_size, uint64_t n_se
  * bipartite_matcher.cc:17-151, create_segment_texts_task.cc:15-81, merge_segments_task.cc:133-195 with
  * INTERSECTION scoring, main.cc:126).  Lemon's MaxWeightedPerfectMatching is replaced by an own
  * Kuhn-Munkres: every matching has the optimal total weight; which optimal matching Lemon picks is
- * not reproduced (parity unpinned). */
+ * not reproduced (parity unpinned).  Texts of equal size keep their classes' pBWT order
+ * (the reference's std::sort leaves it to its standard library).  [r5] fseq_join_bipartite runs on the
+ * device where the boundary states are (csrc/fseq_joinbip.hpp) while a segment has at most 181 texts and
+ * the run is not sharded -- the same permutations, entry for entry, as the host form below. */
 int  fseq_join_bipartite(fseq_ctx *ctx, uint32_t *permutations);
 /* replaces: join_context::join_random_order_and_output (join_context.cc:259-289): std::mt19937(seed),
  * one std::shuffle per segment. */
