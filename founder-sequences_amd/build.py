@@ -5,7 +5,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 # translation units of the library: the path (kernels, geometry, phases, sharding, ABI) and the joiners / writers
-SRCS = [os.path.join(HERE, "csrc", "fseq_api.hip"), os.path.join(HERE, "csrc", "fseq_api_join.hip"), os.path.join(HERE, "csrc", "fseq_reduced.hip")]
+SRCS = [os.path.join(HERE, "csrc", "fseq_api.hip"), os.path.join(HERE, "csrc", "fseq_api_join.hip"), os.path.join(HERE, "csrc", "fseq_reduced.hip"), os.path.join(HERE, "csrc", "fseq_kernelsets.hip"), os.path.join(HERE, "csrc", "fseq_kernelsets_stream.hip")]
 SRC = SRCS[0]
 import glob
 DEPS = sorted(glob.glob(os.path.join(HERE, "csrc", "*"))) + [os.path.join(os.path.dirname(HERE), "include", "fseq.h"),

@@ -56,205 +56,6 @@ using namespace fseq;
 
 namespace {
 
-// EW: phase C keeps wave 0 free of rows for the per-column list (k_columns, fseq_kernels.hpp): m <= (T - 64) * E
-template <int T, int E, int SIGMA, bool PK, bool EW = false>
-struct Launch {
-	static void rank(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0, uint32_t const *only)
-	{
-		// (only: per-block filter, passed in the start-state slot the rank mode does not use -- k_colblock)
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_RANK, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh, rank_, keyd, nkeys,
-		                   only, (uint32_t const *) nullptr, (uint64_t const *) nullptr, (uint2 const *) nullptr,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint64_t const *) nullptr, 0u, (uint32_t const *) nullptr, (uint32_t const *) nullptr, col0,
-		                   (uint64_t) B < (1ull << scan_shift_for(T, E)) ? 1u : 0u);      // (divergences relative to the block start: <= B)
-	}
-	static void snap(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                 uint32_t nblocks, uint32_t npass, uint32_t bsh, uint32_t const *ba, uint32_t const *bd, uint64_t const *rb, uint2 const *grp, uint32_t *sa, uint32_t *sd,
-	                 uint64_t const *task_src, uint32_t snap_stride, uint32_t const *ss_a, uint32_t const *ss_d, uint32_t keyed)
-	{
-		hipLaunchKernelGGL((k_colblock<T, E, SIGMA, MODE_SNAP, PK>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, nblocks, npass, bsh,
-		                   (uint32_t *) nullptr, (uint32_t *) nullptr, (uint32_t *) nullptr, ba, bd, rb, grp, sa, sd, task_src, snap_stride, ss_a, ss_d, (uint64_t) 0, keyed);
-	}
-	static size_t columns_lds(uint32_t B) { return columns_lds_bytes<T, E, SIGMA, PK>(B); }
-	static void columns(hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-	                    uint32_t N2, uint32_t const *ba, uint32_t const *bd, uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t npass, uint32_t bsh,
-	                    uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done_host, uint32_t epoch, uint32_t const *colmask, uint32_t const *blocklist)
-	{
-		if (colmask)
-			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, true>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, colmask, blocklist);
-		else
-			hipLaunchKernelGGL((k_columns<T, E, SIGMA, PK, EW, false>), dim3(grid), dim3(T), lds, st, msa, ld, m, n, B, N2, ba, bd, L, X, stride, ent, hdr, npass, bsh,
-			                   snap_stride, ss_a, ss_d, block0, done_host, epoch, (uint32_t const *) nullptr, blocklist);
-	}
-	static uint32_t columns_resident(size_t lds)
-	{
-		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns<T, E, SIGMA, PK, EW>, T, lds) != hipSuccess || nb < 1) nb = 1;
-		return (uint32_t) nb;
-	}
-	static void chain(hipStream_t st, uint32_t grid, size_t lds, uint32_t const *rank_, uint32_t const *keyd, uint32_t const *nkeys, uint32_t m,
-	                  uint32_t nb_total, uint32_t G, uint64_t cols_per_block, uint32_t const *start_a, uint32_t const *start_d,
-	                  uint32_t *out_a, uint32_t *out_d, uint32_t *out_rank, uint32_t *out_keyd, uint32_t *out_nkeys, uint32_t grp0, uint32_t keyed)
-	{
-		hipLaunchKernelGGL((k_chain<T, E, PK>), dim3(grid), dim3(T), lds, st, rank_, keyd, nkeys, m, nb_total, G, cols_per_block,
-		                   start_a, start_d, out_a, out_d, out_rank, out_keyd, out_nkeys, grp0, keyed);
-	}
-	static hipError_t prepare(size_t lds_columns)
-	{
-		hipError_t e;
-		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_RANK, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_colblock<T, E, SIGMA, MODE_SNAP, PK>, colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>())) != hipSuccess) return e;
-		if ((e = allow_lds(k_chain<T, E, PK>, chain_lds_bytes<T, E, PK>())) != hipSuccess) return e;
-		(void) lds_columns;
-		return hipSuccess;
-	}
-	static hipError_t prepare_columns(size_t lds_columns)
-	{
-		hipError_t const e = allow_lds(k_columns<T, E, SIGMA, PK, EW, false>, lds_columns);
-		return e != hipSuccess ? e : allow_lds(k_columns<T, E, SIGMA, PK, EW, true>, lds_columns);
-	}
-	static KernelSet make()
-	{
-		KernelSet k;
-		k.T = T; k.E = E; k.sigma = SIGMA; k.cap = T * E; k.scan_shift = (uint32_t) scan_shift_for(T, E);
-		k.lds_colblock = colblock_lds_bytes<T, E, SIGMA, MODE_RANK, PK>();
-		k.lds_snap = colblock_lds_bytes<T, E, SIGMA, MODE_SNAP, PK>();
-		k.rank = &rank; k.snap = &snap; k.columns_lds = &columns_lds; k.columns = &columns; k.columns_resident = &columns_resident;
-		k.lds_chain = chain_lds_bytes<T, E, PK>();
-		k.chain = &chain; k.prepare = &prepare; k.prepare_columns = &prepare_columns;
-		return k;
-	}
-};
-
-// phase A in key space, LDS-resident rows (fseq_blockkeys.hpp): the kernel has its own workgroup size, one thread
-// per 8 rows where that fits (blockkeys_threads)
-#define FSEQ_BK_SIZES(X) X(256) X(320) X(512) X(768) X(1024)
-void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-                      uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
-                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced, uint32_t *todo, uint32_t const *only = nullptr)
-{
-	switch (T)
-	{
-#define X(T_) case T_: hipLaunchKernelGGL((k_blockkeys<T_>), dim3(grid), dim3(T_), lds, st, msa, ld, m, n, B, bsh, rank_, keyd, nkeys, col0, \
-	                                          scratch, scratch_per_block, cap_words, sliced, todo, only); break;
-		FSEQ_BK_SIZES(X)
-#undef X
-		default: break;
-	}
-}
-hipError_t prepare_blockkeys(uint32_t T, size_t lds, bool debug)
-{
-	if (debug)
-	{
-		int nb = -1;
-		switch (T)
-		{
-#define X(T_) case T_: (void) allow_lds(k_blockkeys<T_>, lds); (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_blockkeys<T_>, T_, lds); break;
-			FSEQ_BK_SIZES(X)
-#undef X
-			default: break;
-		}
-		fprintf(stderr, "fseq: k_blockkeys<%u> with %zu bytes of LDS: %d workgroups per CU\n", T, lds, nb);
-	}
-	switch (T)
-	{
-#define X(T_) case T_: return allow_lds(k_blockkeys<T_>, lds);
-		FSEQ_BK_SIZES(X)
-#undef X
-		default: return hipErrorInvalidValue;
-	}
-}
-
-// phase A, the trie over 32-bit group words (fseq_blocktrie.hpp): T threads by the row count (12 T classes fit), bits per symbol
-uint32_t blocktrie_threads(uint32_t m, bool stream) { return stream || m > 12u * 512u ? 1024u : m > 12u * 256u ? 512u : 256u; }
-size_t blocktrie_lds(uint32_t T) { return T == 256u ? BtGeom<256>::LDS_BYTES : T == 512u ? BtGeom<512>::LDS_BYTES : BtGeom<1024>::LDS_BYTES; }
-hipError_t launch_blocktrie(uint32_t bits, uint32_t T, hipStream_t st, uint32_t groups, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
-                            uint32_t nblk, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0, uint32_t *ws, size_t per, uint32_t *given_up, uint32_t *todo)
-{
-#define FSEQ_BT_CASE(BITS_, T_) \
-	if (bits == BITS_ && T == T_) \
-	{ \
-		hipError_t const e = allow_lds(k_blocktrie<BITS_, T_>, BtGeom<T_>::LDS_BYTES); \
-		if (e != hipSuccess) return e; \
-		hipLaunchKernelGGL((k_blocktrie<BITS_, T_>), dim3(groups), dim3(T_), BtGeom<T_>::LDS_BYTES, st, msa, ld, m, n, B, nblk, rank_, keyd, nkeys, col0, ws, per, given_up, todo); \
-		return hipSuccess; \
-	}
-	FSEQ_BT_CASE(2, 256) FSEQ_BT_CASE(2, 512) FSEQ_BT_CASE(2, 1024)
-	FSEQ_BT_CASE(4, 256) FSEQ_BT_CASE(4, 512) FSEQ_BT_CASE(4, 1024)
-	FSEQ_BT_CASE(8, 256) FSEQ_BT_CASE(8, 512) FSEQ_BT_CASE(8, 1024)
-#undef FSEQ_BT_CASE
-	return hipErrorInvalidValue;
-}
-
-// phase C from another configuration than phases A, B and pass 2 (the emitter-wave kernels give their threads one
-// row more; the latency-bound chain and snapshot kernels are better off without it)
-template <typename Base, typename Col>
-KernelSet compose_kernels()
-{
-	KernelSet k = Base::make();
-	k.columns_lds = &Col::columns_lds; k.columns = &Col::columns; k.columns_resident = &Col::columns_resident; k.prepare_columns = &Col::prepare_columns;
-	return k;
-}
-
-bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_wave)
-{
-	if (sigma > 256) return false;
-	// 1024-thread configurations spare wave 0 for the per-column lists when the rows allow it (measured: C5 phase C
-	// 86 -> 75 ms with it, while 512-thread workgroups lose as much to the longer per-thread chunks as they gain)
-	bool const ew_ok = !no_emitter_wave;
-#define FSEQ_TRY_EW(T_, E_, PK_)                                                               \
-	if (ew_ok && m <= (uint32_t) ((T_) - 64) * (E_))                                           \
-	{                                                                                          \
-		*out = Launch<T_, E_, 4, PK_, true>::make();                                            \
-		return true;                                                                           \
-	}
-#define FSEQ_TRY(T_, E_, PK_)                                                                  \
-	if (m <= (uint32_t) (T_) * (E_))                                                           \
-	{                                                                                          \
-		*out = Launch<T_, E_, 4, PK_>::make();                                                  \
-		return true;                                                                           \
-	}
-	FSEQ_TRY(64, 1, false)
-	FSEQ_TRY(64, 7, false)
-	FSEQ_TRY(256, 5, false)
-	// 512 threads: the list wave pays since the partition step's scan became cheap (BASELINE C3: phase C 8.2 -> 7.7 ms
-	// with six rows on seven waves and the list on the eighth; 576 threads would keep five rows per thread, but nine
-	// waves per workgroup place three on one SIMD and only one workgroup fits a CU)
-	// [late r3] ... with 16-bit LDS words (value ids are < m + B < 65536 anyway): 48 KiB instead of 70 per workgroup and 80
-	// registers by launch bounds put THREE workgroups on a CU -- a column step is a chain of three barriers and ~6 LDS round
-	// trips, and two workgroups left the SIMDs idle 43 % of the time (BASELINE C3: phase C 5.61 -> 5.08 ms; the unpacking
-	// costs less than the third workgroup brings)
-	if (ew_ok && m > 448u * 5u && m <= 448u * 6u && m <= 512u * 5u)
-	{
-		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 6, 4, true, true>>();
-		return true;
-	}
-	if (ew_ok && m > 256u * 5u && m <= 448u * 5u)
-	{
-		*out = compose_kernels<Launch<512, 5, 4, false>, Launch<512, 5, 4, true, true>>();
-		return true;
-	}
-	FSEQ_TRY(512, 5, false)
-	FSEQ_TRY(512, 7, false)
-	FSEQ_TRY_EW(1024, 5, false)    // (3,585 .. 5,120 rows: e.g. the 5,008 haplotypes of 2,504 diploid samples)
-	FSEQ_TRY(1024, 5, false)
-	FSEQ_TRY_EW(1024, 7, false)
-	FSEQ_TRY(1024, 7, false)
-	// 16-bit LDS state (m <= 11,264).  These kernels want more registers than a wave of a 1024-thread workgroup gets
-	// (~13 per row of E): the fewest rows per thread that hold m, the list wave where the same E allows it
-	// (BASELINE C5, m = 10,000: (1024,10) 56.9 ms of phase C against 61.9 with (1024,11) and the list wave)
-	FSEQ_TRY_EW(1024, 9, true)
-	FSEQ_TRY(1024, 9, true)
-	FSEQ_TRY_EW(1024, 10, true)
-	FSEQ_TRY(1024, 10, true)
-	FSEQ_TRY_EW(1024, 11, true)
-	FSEQ_TRY(1024, 11, true)
-#undef FSEQ_TRY
-#undef FSEQ_TRY_EW
-	return false;
-}
-
 constexpr size_t LDS_LIMIT = 160 * 1024;
 constexpr uint64_t STREAM_BLOCK_TARGET_ALL_ROWS = 1600;   // columns per block the streamed regime aims for (prepare_geometry / block_geometry) ...
 // [r5] ... and when phase C runs on the blocks' representatives: a block of ~800 columns of BASELINE C4 has ~6,600 of them, and
@@ -265,49 +66,6 @@ constexpr uint64_t STREAM_BLOCK_TARGET_REDUCED = 800;
 #define FSEQ_X_FLOOR_VALUE 63u
 #endif
 constexpr uint32_t FSEQ_X_FLOOR = FSEQ_X_FLOOR_VALUE;   // smallest per-column list capacity tried (the estimate and the retries raise it)
-
-// phase C, streamed rows, second form (fseq_stream2.hpp): <threads, rows per thread, 5-byte rows>
-#define FSEQ_S2_CONFIGS(X) X(512, 8, true) X(1024, 4, true) X(1024, 8, true) X(256, 8, true) X(256, 12, true) X(512, 8, false) X(1024, 6, false) X(1024, 8, false) X(256, 8, false) X(256, 12, false)
-template <int T, int E, bool PACK>
-struct LaunchS2 {
-	static size_t lds(uint32_t colbytes) { return stream2_lds_bytes<T, E, PACK>(colbytes); }
-	static hipError_t prepare(size_t bytes)
-	{
-		hipError_t const e = allow_lds(k_columns_stream2<T, E, PACK>, bytes);
-		if (e != hipSuccess) return e;
-		if constexpr (PACK) return allow_lds(k_columns_stream2<T, E, PACK, S2_SNAP>, bytes);
-		return hipSuccess;
-	}
-	static void launch_snap(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
-	                        uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, S2SnapArgs const &SN)
-	{
-		if constexpr (PACK)
-			hipLaunchKernelGGL((k_columns_stream2<T, E, PACK, S2_SNAP>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, 0u, 0u, 0u, (uint2 *) nullptr, (uint4 *) nullptr,
-			                   snap_stride, ss_a, ss_d, 0u, (uint32_t *) nullptr, 0u, 0u, SN);
-	}
-	static void launch(hipStream_t st, uint32_t grid, size_t bytes, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t npass, uint32_t bsh, uint32_t *ws,
-	                   uint32_t L, uint32_t X, uint32_t stride, uint2 *ent, uint4 *hdr, uint32_t snap_stride, uint32_t *ss_a, uint32_t *ss_d, uint32_t block0, uint32_t *done, uint32_t epoch, uint32_t ss_pack,
-	                   uint32_t const *blocklist)
-	{
-		S2SnapArgs SN{};
-		SN.wg_block = blocklist;
-		hipLaunchKernelGGL((k_columns_stream2<T, E, PACK>), dim3(grid), dim3(T), bytes, st, msa, ld, m, n, B, npass, bsh, ws, L, X, stride, ent, hdr, snap_stride, ss_a, ss_d, block0, done, epoch, ss_pack, SN);
-	}
-	static uint32_t resident(size_t bytes)
-	{
-		int nb = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_columns_stream2<T, E, PACK>, T, bytes) != hipSuccess || nb < 1) nb = 1;
-		return (uint32_t) nb;
-	}
-	static Stream2Config make() { return Stream2Config{(uint32_t) T, (uint32_t) E, (uint32_t) s2_key_shift(T * E), PACK ? 1u : 0u, &lds, &prepare, &launch, &resident, PACK ? &launch_snap : nullptr}; }
-};
-bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out)
-{
-#define X(T_, E_, P_) if (T == T_ && E == E_ && (pack != 0) == P_) { *out = LaunchS2<T_, E_, P_>::make(); return true; }
-	FSEQ_S2_CONFIGS(X)
-#undef X
-	return false;
-}
 
 } // namespace
 

@@ -1061,7 +1061,7 @@ __global__ __launch_bounds__(T) void k_blockkeys(
 
 // Phase A, streamed rows (m > 11,264): gridDim.x workgroups, each with its own workspace, take the blocks
 // i, i + gridDim.x, ... of the launch's nblk blocks.
-__global__ __launch_bounds__(1024) void k_blockkeys_stream(
+static __global__ __launch_bounds__(1024) void k_blockkeys_stream(
 	uint8_t const *__restrict__ msa, size_t ld, uint32_t m, uint64_t n, uint32_t B, uint32_t bsh, uint32_t nblk,
 	uint32_t *__restrict__ rank, uint32_t *__restrict__ keyd, uint32_t *__restrict__ nkeys, uint64_t col0,
 	uint32_t *__restrict__ ws, size_t ws_per_group, uint32_t cap_words, uint32_t *__restrict__ sliced, uint32_t wide, uint32_t *__restrict__ todo,

@@ -80,6 +80,18 @@ struct ChainSnapSet {
 	               uint32_t const *task_blk, uint32_t const *cls, uint32_t const *headd, uint32_t const *ncls, uint32_t cap, uint32_t *snap_a, uint32_t *snap_d, uint32_t keyed);
 };
 bool select_chain_snap(uint32_t T, uint32_t E, ChainSnapSet *out);
+
+// the kernel configurations and their launchers (csrc/fseq_kernelsets.hip)
+bool select_kernels(uint32_t m, uint32_t sigma, KernelSet *out, bool no_emitter_wave);
+bool select_stream2(uint32_t T, uint32_t E, uint32_t pack, Stream2Config *out);
+void launch_blockkeys(uint32_t T, hipStream_t st, uint32_t grid, size_t lds, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+                      uint32_t bsh, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0,
+                      uint16_t *scratch, size_t scratch_per_block, uint32_t cap_words, uint32_t *sliced, uint32_t *todo, uint32_t const *only = nullptr);
+hipError_t prepare_blockkeys(uint32_t T, size_t lds, bool debug);
+uint32_t blocktrie_threads(uint32_t m, bool stream);
+size_t blocktrie_lds(uint32_t T);
+hipError_t launch_blocktrie(uint32_t bits, uint32_t T, hipStream_t st, uint32_t groups, uint8_t const *msa, size_t ld, uint32_t m, uint64_t n, uint32_t B,
+                            uint32_t nblk, uint32_t *rank_, uint32_t *keyd, uint32_t *nkeys, uint64_t col0, uint32_t *ws, size_t per, uint32_t *given_up, uint32_t *todo);
 hipError_t launch_reduce_prep(hipStream_t, uint32_t grid, RedPrepArgs const &);
 void launch_reduce_check(hipStream_t, uint32_t const *cnt, uint32_t const *planned, uint32_t count, uint32_t *flags);
 void launch_reduce_msa(hipStream_t, uint32_t nblocks_listed, uint32_t max_rows, uint8_t const *msa, size_t ld, uint8_t *red, size_t ldr, uint32_t const *cnt,

@@ -92,7 +92,7 @@ __host__ __device__ inline size_t stream2_lds_bytes(uint32_t colbytes)
 // Workspace (words): pairs0 2m | pairs1 2m | keys 2m | V m | Vpos m | cnt m + B | D0
 // pack_abits != 0 (PACK kernels): the first 4m words hold words0 m | words1 m | bytes0 m / 4 | .. | bytes1 m / 4 (at 3m) instead
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
+static __global__ __launch_bounds__(ST) void k_columns_stream2_prologue(
 	uint32_t m, uint64_t n, uint32_t B, uint32_t *ws, uint32_t const *__restrict__ bstate_a, uint32_t const *__restrict__ bstate_d, uint32_t block0,
 	uint32_t pack_abits, uint32_t *__restrict__ bs_w = nullptr, uint8_t *__restrict__ bs_h = nullptr, uint32_t const *__restrict__ blocklist = nullptr)
 {

@@ -9,7 +9,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 prefix = sys.argv[1] if len(sys.argv) > 1 else "r02"
 # the library's translation units (founder-sequences_amd/build.py SRCS)
-units = ["fseq_api.hip", "fseq_api_join.hip", "fseq_reduced.hip"]
+units = ["fseq_api.hip", "fseq_api_join.hip", "fseq_reduced.hip", "fseq_kernelsets.hip", "fseq_kernelsets_stream.hip"]
 txt = ""
 for u in units:
     src = os.path.join(ROOT, "founder-sequences_amd", "csrc", u)
