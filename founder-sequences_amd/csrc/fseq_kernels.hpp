@@ -726,11 +726,11 @@ __device__ __forceinline__ void bitonic_sort_lds(uint32_t *sb, uint32_t N2)
 {
 	for (uint32_t k = 2; k <= N2; k <<= 1)
 	{
-		for (uint32_t j = k >> 1; j > 0; j >>= 1)
+		for (uint32_t j = k >> 1, lj = (uint32_t) __builtin_ctz(k) - 1u; j > 0; j >>= 1, --lj)
 		{
 			for (uint32_t i = threadIdx.x; i < N2 / 2; i += T)
 			{
-				uint32_t const lo = ((i / j) * 2u * j) + (i % j);
+				uint32_t const lo = ((i >> lj) << (lj + 1u)) | (i & (j - 1u));      // (j = 2^lj: no division by a run-time j)
 				uint32_t const hi = lo + j;
 				bool const asc = (lo & k) == 0;
 				uint32_t const x = sb[lo], y = sb[hi];
@@ -825,6 +825,62 @@ __device__ __forceinline__ void columns_body(char *smem,
 
 	// ---- sorted distinct divergence values -> V_l[0..D0)
 	uint32_t *sb = reinterpret_cast<uint32_t *>(a_l);   // N2 < 2m words, overlays a_l .. cnt_l
+	uint32_t D0 = 0;
+	bool have_values = false;
+	if constexpr (RED)
+	{
+		// [r5] the distinct values first, by hashing, then the sort of THOSE: a block's representatives hold a few thousand rows
+		// and far fewer values (BASELINE C4: ~1,750 among ~6,600), and the bitonic sort of all rows' values -- 91 steps over 8,192
+		// words, ~150,000 cycles -- was nearly half of what a class-table task of pass 2 costs (its ~16 columns are ~170,000).
+		// sb is the table (up to N2 slots, open addressing; a value that finds no slot within 64 probes, or more distinct
+		// values than V_l sorts in place, takes the sort of all values below).
+		uint32_t &hash_fail = scr.has[0];                       // (the step's scratch is idle in the prologue)
+		// (the table ends in front of V_l, which the distinct values are compacted into while the table is read: the sort buffer
+		// of N2 words may reach into V_l in the 16-bit configurations -- harmless there, its tail is padding by then)
+		uint32_t const avail = (uint32_t) ((reinterpret_cast<char *>(V_l) - reinterpret_cast<char *>(sb)) / 4);
+		uint32_t NT = N2;
+		while (NT > avail) NT >>= 1;
+		uint32_t const hshift = 32u - (uint32_t) __builtin_ctz(NT);
+		for (uint32_t i = tid; i < NT; i += T) sb[i] = PAD_KEY;
+		if (tid == 0) hash_fail = 0u;
+		__syncthreads();
+		auto insert = [&](uint32_t v) {
+			uint32_t h = (v * 2654435761u) >> hshift;
+			for (uint32_t probes = 0; probes < 64u; ++probes)
+			{
+				uint32_t const old = atomicCAS(&sb[h], PAD_KEY, v);
+				if (old == PAD_KEY || old == v) return;
+				h = (h + 1u) & (NT - 1u);
+			}
+			hash_fail = 1u;
+		};
+#pragma unroll
+		for (int e = 0; e < E; ++e)
+			if (p0 + e < m) insert(d[e]);
+		if (red_exact && tid == 0) insert(0u);                   // the value of the rows left out always has an id: 0
+		__syncthreads();
+		if (hash_fail == 0u)
+		{
+			uint32_t const per = (NT + T - 1) / T, start = tid * per;
+			uint32_t mine = 0;
+			for (uint32_t q = 0; q < per; ++q) mine += (start + q < NT && sb[start + q] != PAD_KEY) ? 1u : 0u;
+			uint32_t w = block_excl_add<T>(mine, sscr, &D0);
+			uint32_t N2s = 2;
+			while (N2s < D0) N2s <<= 1;
+			if (N2s <= CAP)
+			{
+				for (uint32_t q = 0; q < per; ++q)
+					if (start + q < NT && sb[start + q] != PAD_KEY) V_l[w++] = sb[start + q];
+				for (uint32_t i = D0 + tid; i < N2s; i += T) V_l[i] = PAD_KEY;
+				__syncthreads();
+				bitonic_sort_lds<T>(V_l, N2s);
+				have_values = true;
+			}
+		}
+		__syncthreads();
+	}
+	if (!have_values)
+	{
 	for (uint32_t i = tid; i < N2; i += T) sb[i] = PAD_KEY;
 	__syncthreads();
 #pragma unroll
@@ -833,7 +889,6 @@ __device__ __forceinline__ void columns_body(char *smem,
 	if (RED && red_exact && tid == 0) sb[m] = 0u;               // the value of the rows left out always has an id: 0
 	__syncthreads();
 	bitonic_sort_lds<T>(sb, N2);
-	uint32_t D0;
 	{
 		uint32_t const per = (N2 + T - 1) / T;
 		uint32_t const start = tid * per;
@@ -857,6 +912,7 @@ __device__ __forceinline__ void columns_body(char *smem,
 				if (v != PAD_KEY && (i == 0 || v != sb[i - 1])) V_l[w++] = v;
 			}
 		}
+	}
 	}
 	__syncthreads();                          // the sort buffer (overlaying cnt_l) is dead from here
 	for (uint32_t i = tid; i < (PK ? (D0 + nb + 9u) / 2u : D0 + nb + 8u); i += T) cnt_l[i] = 0;     // (+8: the list reads aligned groups of ids)
