@@ -66,6 +66,7 @@ __device__ __forceinline__ uint32_t cs_below(uint64_t mask)
 // w + off0 .. and a1 d1 at w + off1 .. (each 2m words, off in {0, 2m}); ends with a barrier.
 // cls (pass 2 behind the reduced phase C, k_chain_snap_stream): the key of a row is cls[rk[row]] -- the class of its block
 // key at the boundary's column -- instead of rk[row]
+template <bool P4 = false>
 __device__ __forceinline__ void chain_step_sorted(
 	uint32_t m, uint32_t const *__restrict__ rk, uint32_t const *__restrict__ kd, uint32_t nkeys,
 	uint32_t *w, uint32_t cur, ChainSortLds &S, StreamLds &L, uint32_t const *__restrict__ cls = nullptr,
@@ -78,9 +79,18 @@ __device__ __forceinline__ void chain_step_sorted(
 	constexpr uint32_t NW = ST / WAVE;
 	uint32_t const *a0 = src_a ? src_a : w + (size_t) cur * 2u * m, *d0 = src_d ? src_d : w + (size_t) cur * 2u * m + m;
 	uint32_t *a1 = w + (size_t) (cur ^ 1u) * 2u * m, *d1 = a1 + m;
-	uint2 *const pairA = reinterpret_cast<uint2 *>(a1);                 // (the output buffers are free until step 3)
+	// P4 [r5]: a pair is ONE word, key << pb | position (pb = bits of m - 1; the caller has checked that the key's bits fit
+	// beside them) -- the sweeps of the sort and the new order move half the bytes
+	using PairT = std::conditional_t<P4, uint32_t, uint2>;
+	uint32_t pb = 1;
+	while (pb < 32u && ((m - 1u) >> pb) != 0u) ++pb;
+	uint32_t const pmask = pb < 32u ? (1u << pb) - 1u : 0xFFFFFFFFu;
+	auto mk = [&](uint32_t key, uint32_t pos) -> PairT { if constexpr (P4) return (key << pb) | pos; else return make_uint2(key, pos); };
+	auto key_of = [&](PairT pr) -> uint32_t { if constexpr (P4) return pr >> pb; else return pr.x; };
+	auto pos_of = [&](PairT pr) -> uint32_t { if constexpr (P4) return pr & pmask; else return pr.y; };
+	PairT *const pairA = reinterpret_cast<PairT *>(a1);                 // (the output buffers are free until step 3)
 	if (dst_a) { a1 = dst_a; d1 = dst_d; }
-	uint2 *const pairB = reinterpret_cast<uint2 *>(w + 4u * (size_t) m);
+	PairT *const pairB = reinterpret_cast<PairT *>(w + 4u * (size_t) m);
 	uint32_t *const pm = w + 6u * (size_t) m, *const sm = w + 7u * (size_t) m, *const tab = w + 8u * (size_t) m;
 	uint32_t const nblk = (m + 63u) / 64u;
 
@@ -96,18 +106,18 @@ __device__ __forceinline__ void chain_step_sorted(
 	{
 		uint32_t const shift = p * db;
 		bool const first = p == 0;
-		uint2 const *src = ((npass - p) & 1u) ? pairA : pairB;          // (unused in the first pass)
-		uint2 *dst = ((npass - p) & 1u) ? pairB : pairA;
+		PairT const *src = ((npass - p) & 1u) ? pairA : pairB;          // (unused in the first pass)
+		PairT *dst = ((npass - p) & 1u) ? pairB : pairA;
 		// first pass: the pairs are made on the way (rank of the row at position i, i) -- a chain of dependent gathers
 		// (position -> row -> rank [-> class]), followed once: the counting sweep leaves the key in the suffix-maxima buffer
 		// (free until step 2), the scatter sweep reads it there
-		auto load_count = [&](uint32_t i) -> uint2 {
+		auto load_count = [&](uint32_t i) -> PairT {
 			if (!first) return src[i];
 			uint32_t const key = cls ? cls[rk[a0[i]]] : rk[a0[i]];
 			sm[i] = key;
-			return make_uint2(key, i);
+			return mk(key, i);
 		};
-		auto load = [&](uint32_t i) -> uint2 { return first ? make_uint2(sm[i], i) : src[i]; };
+		auto load = [&](uint32_t i) -> PairT { return first ? mk(sm[i], i) : src[i]; };
 		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] = 0;
 		// (a wave's histogram row is its own: no barrier between clearing and counting; LDS operations of a wave stay in order)
 		// U groups of 64 positions per iteration: their (dependent: position -> row -> rank) loads in flight together -- one
@@ -115,12 +125,12 @@ __device__ __forceinline__ void chain_step_sorted(
 		constexpr uint32_t U = 4;
 		for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 64u * U)
 		{
-			uint2 pr[U];
+			PairT pr[U];
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load_count(i) : make_uint2(0u, 0u); }
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load_count(i) : mk(0u, 0u); }
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u)
-				if (i0 + u * 64u + lane < c_hi) atomicAdd(&S.hist[wave][(pr[u].x >> shift) & (nbins - 1u)], 1u);
+				if (i0 + u * 64u + lane < c_hi) atomicAdd(&S.hist[wave][(key_of(pr[u]) >> shift) & (nbins - 1u)], 1u);
 		}
 		__syncthreads();
 		// offsets: bins ascending, inside a bin the waves ascending (= the array order: the sort is stable)
@@ -134,14 +144,14 @@ __device__ __forceinline__ void chain_step_sorted(
 		for (uint32_t b = lane; b < nbins; b += 64u) S.hist[wave][b] += S.total[b];
 		for (uint32_t i0 = c_lo; i0 < c_hi; i0 += 64u * U)
 		{
-			uint2 pr[U];
+			PairT pr[U];
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load(i) : make_uint2(0u, 0u); }
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < c_hi ? load(i) : mk(0u, 0u); }
 #pragma unroll
 			for (uint32_t u = 0; u < U; ++u)
 			{
 				bool const in = i0 + u * 64u + lane < c_hi;
-				uint32_t const dg = (pr[u].x >> shift) & (nbins - 1u);
+				uint32_t const dg = (key_of(pr[u]) >> shift) & (nbins - 1u);
 				uint64_t const same = cs_match(dg, in, db);
 				uint32_t const below = cs_below(same);
 				uint32_t const base = S.hist[wave][dg];
@@ -152,7 +162,7 @@ __device__ __forceinline__ void chain_step_sorted(
 		}
 		__syncthreads();
 	}
-	uint2 const *perm = pairB;
+	PairT const *perm = pairB;
 
 	// ---- 2. range maxima of the old d: prefix / suffix maxima inside 64-blocks, sparse table over the block maxima
 	for (uint32_t blk = wave; blk < nblk; blk += NW)
@@ -186,8 +196,9 @@ __device__ __forceinline__ void chain_step_sorted(
 			for (uint32_t u = 0; u < U; ++u)
 			{
 				uint32_t const p = min(p0 + u * ST, m - 1u);
-				me[u] = perm[p];
-				pv[u] = perm[p ? p - 1u : 0u];
+				PairT const pm_ = perm[p], pp_ = perm[p ? p - 1u : 0u];
+				me[u] = make_uint2(key_of(pm_), pos_of(pm_));
+				pv[u] = make_uint2(key_of(pp_), pos_of(pp_));
 			}
 			uint32_t row[U], kdv[U], sv[U], pmv[U], t0[U], t1[U], dlast[U];
 #pragma unroll
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(ST) void k_chain_stream_sort(
 		if (out_state_a)
 			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = a[i]; out_state_d[(size_t) b * m + i] = d[i]; }
 		if (b + 1 == b1 && !out_rank && b1 != nb_total) break;       // (an expansion's last step: k_chain, fseq_kernels.hpp)
-		chain_step_sorted(m, rank + (size_t) b * m, keyd + (size_t) b * m, nkeys[b], w, cur, S, L);
+		chain_step_sorted<false>(m, rank + (size_t) b * m, keyd + (size_t) b * m, nkeys[b], w, cur, S, L);
 		cur ^= 1u;
 	}
 	uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
@@ -302,7 +313,14 @@ __global__ __launch_bounds__(ST) void k_chain_snap_stream(
 			for (uint32_t i = tid; i < m; i += ST) { snap_a[ob + i] = bstate_a[sb + i]; snap_d[ob + i] = bstate_d[sb + i]; }
 			continue;
 		}
-		chain_step_sorted(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap, bstate_a + sb, bstate_d + sb, snap_a + ob, snap_d + ob);
+		// (the classes of a block's representatives and the positions share a word -- at most 12,288 classes, 2^18 rows)
+		uint32_t kb = 1, pbits = 1;
+		while (kb < 32u && ((D - 1u) >> kb) != 0u) ++kb;
+		while (pbits < 32u && ((m - 1u) >> pbits) != 0u) ++pbits;
+		if (kb + pbits <= 32u)
+			chain_step_sorted<true>(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap, bstate_a + sb, bstate_d + sb, snap_a + ob, snap_d + ob);
+		else
+			chain_step_sorted<false>(m, rank + sb, headd + (size_t) task * cap, D, w, 0u, S, L, cls + (size_t) task * cap, bstate_a + sb, bstate_d + sb, snap_a + ob, snap_d + ob);
 	}
 }
 
