@@ -20,6 +20,8 @@
 // Everything but the histograms lives in the workgroup's workspace (L2-resident: a few MB).
 #pragma once
 
+#include <type_traits>
+
 #include "fseq_stream.hpp"
 
 namespace fseq {
@@ -276,7 +278,14 @@ __global__ __launch_bounds__(ST) void k_chain_stream_sort(
 		if (out_state_a)
 			for (uint32_t i = tid; i < m; i += ST) { out_state_a[(size_t) b * m + i] = a[i]; out_state_d[(size_t) b * m + i] = d[i]; }
 		if (b + 1 == b1 && !out_rank && b1 != nb_total) break;       // (an expansion's last step: k_chain, fseq_kernels.hpp)
-		chain_step_sorted<false>(m, rank + (size_t) b * m, keyd + (size_t) b * m, nkeys[b], w, cur, S, L);
+		{
+			uint32_t const nk = nkeys[b];
+			uint32_t kb = 1, pbits = 1;
+			while (kb < 32u && ((nk - 1u) >> kb) != 0u) ++kb;
+			while (pbits < 32u && ((m - 1u) >> pbits) != 0u) ++pbits;
+			if (kb + pbits <= 32u) chain_step_sorted<true>(m, rank + (size_t) b * m, keyd + (size_t) b * m, nk, w, cur, S, L);
+			else chain_step_sorted<false>(m, rank + (size_t) b * m, keyd + (size_t) b * m, nk, w, cur, S, L);
+		}
 		cur ^= 1u;
 	}
 	uint32_t const *a = w + (size_t) cur * 2u * m, *d = a + m;
@@ -384,6 +393,8 @@ __host__ __device__ inline uint32_t chainmulti_passes(uint32_t m)
 
 struct ChainMultiGeom {
 	uint32_t b, npass, db, nbins;
+	uint32_t pb;                                 // bits of a position (m - 1)
+	bool p4;                                     // [r5] a pair is one word, key << pb | position (the key's bits fit beside the position's)
 	bool active;
 	uint32_t *w;
 	uint32_t const *a0, *d0;
@@ -409,6 +420,9 @@ __device__ __forceinline__ ChainMultiGeom chainmulti_geom(ChainMultiArgs const &
 	g.db = (bits + g.npass - 1u) / g.npass;
 	g.nbins = 1u << g.db;
 	uint32_t const cur = A.step & 1u, m = A.m;
+	g.pb = 1;
+	while (g.pb < 32u && ((m - 1u) >> g.pb) != 0u) ++g.pb;
+	g.p4 = bits + g.pb <= 32u;
 	g.w = A.ws + (size_t) chain * chainsort_ws_words(m);
 	g.a0 = g.w + (size_t) cur * 2u * m; g.d0 = g.a0 + m;
 	g.a1 = g.w + (size_t) (cur ^ 1u) * 2u * m; g.d1 = g.a1 + m;
@@ -424,18 +438,37 @@ __device__ __forceinline__ uint32_t cm_key(uint2 p) { return p.x & 0xFFFFFu; }
 __device__ __forceinline__ uint32_t cm_pos(uint2 p) { return p.y & 0xFFFFFu; }
 __device__ __forceinline__ uint32_t cm_row(uint2 p) { return (p.x >> 20) | ((p.y >> 20) << 12); }
 
-// pair of position i for the sweep kernels of pass p: made on the way in the first pass, else from the pass before
-__device__ __forceinline__ uint2 cm_load(ChainMultiGeom const &g, uint32_t const *rk, uint32_t pass, uint32_t i)
-{
-	if (pass == 0u) { uint32_t const row = g.a0[i]; return cm_pack(rk[row], i, row); }
-	uint2 const *src = ((g.npass - pass) & 1u) ? g.pairA : g.pairB;
-	return src[i];
-}
+// [r5] P4: the pairs of a chain whose keys fit beside a position in ONE word (the key blocks of the alignment's own blocks:
+// at most 12 x 1,024 keys; BASELINE C4: eleven of every twelve steps) are that word, key << pb | position, and the new order
+// looks its row up at the old position -- half the bytes through the four sweeps of the sort for one gather more in the last
+template <bool P4>
+struct CmPair {
+	using T = std::conditional_t<P4, uint32_t, uint2>;
+	static __device__ __forceinline__ T pack(ChainMultiGeom const &g, uint32_t key, uint32_t pos, uint32_t row)
+	{
+		if constexpr (P4) { (void) row; return (key << g.pb) | pos; } else { (void) g; return cm_pack(key, pos, row); }
+	}
+	static __device__ __forceinline__ T none() { if constexpr (P4) return 0u; else return make_uint2(0u, 0u); }
+	static __device__ __forceinline__ uint32_t key(ChainMultiGeom const &g, T p) { if constexpr (P4) return p >> g.pb; else { (void) g; return cm_key(p); } }
+	static __device__ __forceinline__ uint32_t pos(ChainMultiGeom const &g, T p) { if constexpr (P4) return p & ((1u << g.pb) - 1u); else { (void) g; return cm_pos(p); } }
+	static __device__ __forceinline__ uint32_t row(ChainMultiGeom const &g, T p) { if constexpr (P4) return g.a0[pos(g, p)]; else { (void) g; return cm_row(p); } }
+	static __device__ __forceinline__ T *bufA(ChainMultiGeom const &g) { return reinterpret_cast<T *>(g.pairA); }
+	static __device__ __forceinline__ T *bufB(ChainMultiGeom const &g) { return reinterpret_cast<T *>(g.pairB); }
+	static __device__ __forceinline__ T *stage(ChainMultiGeom const &g) { return (g.npass & 1u) ? bufA(g) : bufB(g); }
+	// pair of position i for the sweep kernels of pass p: made on the way in the first pass, else from the pass before
+	static __device__ __forceinline__ T load(ChainMultiGeom const &g, uint32_t const *rk, uint32_t pass, uint32_t i)
+	{
+		if (pass == 0u) { uint32_t const r = g.a0[i]; return pack(g, rk[r], i, r); }
+		T const *src = ((g.npass - pass) & 1u) ? bufA(g) : bufB(g);
+		return src[i];
+	}
+};
+
 // [r5] the first pass's pairs are made ONCE, by its count sweep, which leaves them in the pair buffer the pass does not
 // write (dead until the second pass overwrites it): rank[row] is a gather at a random row of a table of m words per block --
 // a 64-byte line from memory for 4 bytes, thousands of chains side by side -- and the scatter sweep used to make it again
 // (BASELINE C4, 2,048 chains: 3.5 ms of every step's 9)
-__device__ __forceinline__ uint2 *cm_stage(ChainMultiGeom const &g) { return (g.npass & 1u) ? g.pairA : g.pairB; }
+// (CmPair::stage)
 
 // start state of every chain of the launch into its workspace (and out_state in front of its first block)
 __global__ __launch_bounds__(CM_WG) void k_cm_init(ChainMultiArgs const A)
@@ -472,22 +505,26 @@ __global__ __launch_bounds__(CM_WG) void k_cm_count(ChainMultiArgs const A)
 	uint32_t const *rk = A.rank + (size_t) g.b * m;
 	uint32_t const shift = A.pass * g.db;
 	for (uint32_t b = lane; b < g.nbins; b += 64u) hist[wave][b] = 0;
-	constexpr uint32_t U = 4;
-	for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
-	{
-		uint2 pr[U];
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? cm_load(g, rk, A.pass, i) : make_uint2(0u, 0u); }
-		if (A.pass == 0u)
+	auto sweep = [&](auto p4_) {
+		using P = CmPair<decltype(p4_)::value>;
+		constexpr uint32_t U = 4;
+		for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
 		{
-			uint2 *const stage = cm_stage(g);
+			typename P::T pr[U];
 #pragma unroll
-			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; if (i < hi) stage[i] = pr[u]; }
+			for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; pr[u] = i < hi ? P::load(g, rk, A.pass, i) : P::none(); }
+			if (A.pass == 0u)
+			{
+				typename P::T *const stage = P::stage(g);
+#pragma unroll
+				for (uint32_t u = 0; u < U; ++u) { uint32_t const i = i0 + u * 64u + lane; if (i < hi) stage[i] = pr[u]; }
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+				if (i0 + u * 64u + lane < hi) atomicAdd(&hist[wave][(P::key(g, pr[u]) >> shift) & (g.nbins - 1u)], 1u);
 		}
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u)
-			if (i0 + u * 64u + lane < hi) atomicAdd(&hist[wave][(cm_key(pr[u]) >> shift) & (g.nbins - 1u)], 1u);
-	}
+	};
+	if (g.p4) sweep(std::true_type{}); else sweep(std::false_type{});
 	if (A.pass == 0u)
 	{
 		uint32_t const nblk = (m + 63u) / 64u;
@@ -577,32 +614,36 @@ __global__ __launch_bounds__(CM_WG) void k_cm_scatter(ChainMultiArgs const A)
 	uint32_t const hi = min(m, lo + CM_PART);
 	uint32_t const *rk = A.rank + (size_t) g.b * m;
 	uint32_t const shift = A.pass * g.db;
-	uint2 *dst = ((g.npass - A.pass) & 1u) ? g.pairB : g.pairA;
 	uint32_t const *in_offs = g.hist + (size_t) part * CS_BINS;
 	for (uint32_t b = lane; b < g.nbins; b += 64u) offs[wave][b] = in_offs[b];
-	constexpr uint32_t U = 4;
-	for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
-	{
-		uint2 pr[U];
-#pragma unroll
-		for (uint32_t u = 0; u < U; ++u)
+	auto sweep = [&](auto p4_) {
+		using P = CmPair<decltype(p4_)::value>;
+		typename P::T *dst = ((g.npass - A.pass) & 1u) ? P::bufB(g) : P::bufA(g);
+		constexpr uint32_t U = 4;
+		for (uint32_t i0 = lo; i0 < hi; i0 += 64u * U)
 		{
-			uint32_t const i = i0 + u * 64u + lane;
-			pr[u] = i < hi ? (A.pass == 0u ? cm_stage(g)[i] : cm_load(g, rk, A.pass, i)) : make_uint2(0u, 0u);
-		}
+			typename P::T pr[U];
 #pragma unroll
-		for (uint32_t u = 0; u < U; ++u)
-		{
-			bool const in = i0 + u * 64u + lane < hi;
-			uint32_t const dg = (cm_key(pr[u]) >> shift) & (g.nbins - 1u);
-			uint64_t const same = cs_match(dg, in, g.db);
-			uint32_t const below = cs_below(same);
-			uint32_t const base = offs[wave][dg];
-			if (in) dst[base + below] = pr[u];
-			// (the read above and this write are LDS operations of one wave: they execute in order)
-			if (in && below == 0u) offs[wave][dg] = base + (uint32_t) __popcll(same);
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				uint32_t const i = i0 + u * 64u + lane;
+				pr[u] = i < hi ? (A.pass == 0u ? P::stage(g)[i] : P::load(g, rk, A.pass, i)) : P::none();
+			}
+#pragma unroll
+			for (uint32_t u = 0; u < U; ++u)
+			{
+				bool const in = i0 + u * 64u + lane < hi;
+				uint32_t const dg = (P::key(g, pr[u]) >> shift) & (g.nbins - 1u);
+				uint64_t const same = cs_match(dg, in, g.db);
+				uint32_t const below = cs_below(same);
+				uint32_t const base = offs[wave][dg];
+				if (in) dst[base + below] = pr[u];
+				// (the read above and this write are LDS operations of one wave: they execute in order)
+				if (in && below == 0u) offs[wave][dg] = base + (uint32_t) __popcll(same);
+			}
 		}
-	}
+	};
+	if (g.p4) sweep(std::true_type{}); else sweep(std::false_type{});
 }
 
 // the new order of every chain (and out_state behind the block, where the contract asks for it)
@@ -616,14 +657,25 @@ __global__ __launch_bounds__(CM_WG) void k_cm_output(ChainMultiArgs const A)
 	if (p >= m) return;
 	uint32_t const nblk = (m + 63u) / 64u;
 	uint32_t const *kd = A.keyd + (size_t) g.b * m;
-	uint2 const *perm = g.pairB;
-	uint2 const me = perm[p], pv = perm[p ? p - 1u : 0u];
-	bool const first = p == 0u || cm_key(pv) != cm_key(me);
-	uint32_t dv;
-	if (first) dv = kd[cm_key(me)];
+	uint32_t key_me, key_pv, pos_me, pos_pv, row;
+	if (g.p4)
+	{
+		using P = CmPair<true>;
+		P::T const me = P::bufB(g)[p], pv = P::bufB(g)[p ? p - 1u : 0u];
+		key_me = P::key(g, me); key_pv = P::key(g, pv); pos_me = P::pos(g, me); pos_pv = P::pos(g, pv); row = P::row(g, me);
+	}
 	else
 	{
-		uint32_t const lo = cm_pos(pv) + 1u, hi = cm_pos(me);            // max of d0[lo .. hi], lo <= hi
+		using P = CmPair<false>;
+		P::T const me = P::bufB(g)[p], pv = P::bufB(g)[p ? p - 1u : 0u];
+		key_me = P::key(g, me); key_pv = P::key(g, pv); pos_me = P::pos(g, me); pos_pv = P::pos(g, pv); row = P::row(g, me);
+	}
+	bool const first = p == 0u || key_pv != key_me;
+	uint32_t dv;
+	if (first) dv = kd[key_me];
+	else
+	{
+		uint32_t const lo = pos_pv + 1u, hi = pos_me;                     // max of d0[lo .. hi], lo <= hi
 		uint32_t const bl = lo >> 6, bh = hi >> 6;
 		if (bl == bh)
 		{
@@ -641,7 +693,6 @@ __global__ __launch_bounds__(CM_WG) void k_cm_output(ChainMultiArgs const A)
 			}
 		}
 	}
-	uint32_t const row = cm_row(me);
 	g.a1[p] = row; g.d1[p] = dv;
 	uint32_t const grp = wg.chain + A.grp0;
 	uint32_t const b1 = min(A.nb_total, grp * A.G + A.G);
