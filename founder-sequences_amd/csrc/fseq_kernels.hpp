@@ -690,7 +690,7 @@ __global__ __launch_bounds__(T) void k_chain(
 // (nine and ten rows of the 16-bit configurations: the two-level form, fseq_core.hpp)
 __host__ __device__ constexpr bool columns_pairwise(int T, int E, int SIGMA, bool PK = false)
 {
-	return SIGMA == 4 && ((E >= 2 && E <= FSEQ_PW_MAX_E && !(T >= 1024 && E >= 7)) || (PK && E >= 9 && T * E <= 10240));
+	return SIGMA == 4 && ((E >= 2 && E <= FSEQ_PW_MAX_E && !(T >= 1024 && E >= 7 && !PK)) || (PK && E >= 9 && T * E <= 10240));
 }
 
 // the resolve of a step as a read of per-thread run slots (partition_step's FM): wherever 4 * T more words of LDS are to be had
