@@ -459,13 +459,18 @@ __global__ __launch_bounds__(BT_T) void k_blocktrie(
 						for (uint32_t j = tid; j < cn; j += BT_T) list[j] = glist[c0 + j];
 						__syncthreads();
 					}
-#pragma unroll 4
-					for (uint32_t j = 0; j < cn; ++j)
+					// [r5] (the waves without an entry of the list do not walk it: a list of a few hundred entries is five waves' worth,
+					// and the walk of all sixteen was a fifth of the phase)
+					if (k0_ + (tid & ~63u) < nl)
 					{
-						uint2 const o = list[j];
-						bool const below = (o.x & 0xFFFFu) == r && o.y < w;
-						pos += below ? 1u : 0u;
-						pred = (below && o.y >= pred) ? o.y : pred;
+#pragma unroll 4
+						for (uint32_t j = 0; j < cn; ++j)
+						{
+							uint2 const o = list[j];
+							bool const below = (o.x & 0xFFFFu) == r && o.y < w;
+							pos += below ? 1u : 0u;
+							pred = (below && o.y >= pred) ? o.y : pred;
+						}
 					}
 				}
 				if (i < nl)
