@@ -114,7 +114,7 @@ def build_aux(force=False):
         out = os.path.join(HERE, "bin", name)
         deps = [src, os.path.join(HERE, "host", "aux_common.hpp")]
         if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-            subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", src, "-o", out], check=True)
+            subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-pthread", src, "-o", out], check=True)
             LAST_ACTION[name] = "compiled"
         else:
             LAST_ACTION.setdefault(name, "reused")

@@ -2,13 +2,18 @@
 // (match-sequences-to-founders/cmdline.ggo:4-16, match_founder_sequences.cc:108-259): thread every input
 // sequence through the founders greedily (keep the set of founders that still match; when it runs empty, or
 // -- with --min-segment-length -- as soon as the current piece has that length, print the piece and start
-// again from all founders) and print SEQUENCE_INDEX LB RB FOUNDER_INDICES.  Sequences are handled in input
-// order (the reference's --single-threaded order).  Host only.
+// again from all founders) and print SEQUENCE_INDEX LB RB FOUNDER_INDICES.  One task per sequence on the host's
+// threads (one thread with --single-threaded), reports in input order.  Host only.
 #include "aux_common.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <getopt.h>
+#include <mutex>
 #include <numeric>
+#include <sstream>
+#include <thread>
 
 namespace {
 
@@ -43,6 +48,7 @@ int main(int argc, char **argv)
 	char const *sequences = nullptr, *founders_path = nullptr;
 	int format = 2;
 	long min_len = 0;
+	bool single_threaded = false;
 	static option const opts[] = {{"sequences", required_argument, nullptr, 's'}, {"founders", required_argument, nullptr, 'f'},
 	                              {"founders-format", required_argument, nullptr, 1000}, {"min-segment-length", required_argument, nullptr, 'l'},
 	                              {"single-threaded", no_argument, nullptr, 1001}, {"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
@@ -58,7 +64,7 @@ int main(int argc, char **argv)
 				else if (0 == strcmp(optarg, "list-file")) format = 2;
 				else { std::cerr << argv[0] << ": invalid argument, \"" << optarg << "\", for option `--founders-format'" << std::endl; return EXIT_FAILURE; }
 				break;
-			case 1001: break;
+			case 1001: single_threaded = true; break;
 			case 'h': std::cout << "Usage: match-sequences-to-founders --sequences-list=sequences-list.txt --founders-list=founders.txt\n"; return EXIT_SUCCESS;
 			default: return EXIT_FAILURE;
 		}
@@ -87,19 +93,23 @@ int main(int argc, char **argv)
 			if (pos < founders[f].size() && founders[f][pos] == c) dst.push_back(f);
 		return dst.size();
 	};
-	auto output_range = [](size_t seq, size_t lb, size_t rb, std::vector<size_t> const &idx) {
-		std::cout << seq << '\t' << lb << '\t' << rb << '\t';
-		for (size_t i = 0; i < idx.size(); ++i) { if (i) std::cout << ','; std::cout << idx[i]; }
-		std::cout << '\n';
-	};
-	auto not_found = [](char c, size_t seq, size_t pos) {
-		std::cerr << "Error: character '" << c << "' (" << +c << ") at " << seq << ':' << pos << " not found in the founders." << std::endl;
-	};
-	for (size_t seq_idx = 0; seq_idx < paths.size(); ++seq_idx)
-	{
-		std::string sequence;
-		if (!aux::read_file(paths[seq_idx], sequence)) { std::cerr << "Unable to open '" << paths[seq_idx] << "'." << std::endl; return EXIT_FAILURE; }
-		// match_sequence_and_report, match_founder_sequences.cc:163-218
+	// One task per input sequence as in match_context::match (match_founder_sequences.cc:218-252): the sequences are matched
+	// side by side on the host's threads, one of them reading from the disk at a time (the reference's reading semaphore,
+	// :232-241).  A task writes into buffers of its own; the reports leave in input order whatever order the tasks finish in
+	// (the reference prints under a lock in completion order: input order is one of those orders, and the only one
+	// --single-threaded gives).
+	struct Report { std::string out, err; bool unreadable = false; };
+	std::vector<Report> reports(paths.size());
+	auto match_sequence_and_report = [&](std::string const &sequence, size_t seq_idx, Report &rep) {   // match_founder_sequences.cc:163-218
+		std::ostringstream out, err;
+		auto output_range = [&](size_t lb, size_t rb, std::vector<size_t> const &idx) {
+			out << seq_idx << '\t' << lb << '\t' << rb << '\t';
+			for (size_t i = 0; i < idx.size(); ++i) { if (i) out << ','; out << idx[i]; }
+			out << '\n';
+		};
+		auto not_found = [&](char c, size_t pos) {
+			err << "Error: character '" << c << "' (" << +c << ") at " << seq_idx << ':' << pos << " not found in the founders.\n";
+		};
 		std::vector<size_t> cur(founders.size()), dst;
 		std::iota(cur.begin(), cur.end(), 0);
 		size_t lb = 0, count = cur.size(), dst_count = 0, chr_idx = 0;
@@ -113,25 +123,54 @@ int main(int argc, char **argv)
 				if (0 == dst_count)
 				{
 					if (0 != min_segment_length && chr_idx - lb < min_segment_length)
-						std::cerr << "Error: segment length " << (lb - chr_idx) << " for sequence " << seq_idx << ':' << chr_idx << " under the given limit." << std::endl;   // (sic: lb - chr_idx, :181)
+						err << "Error: segment length " << (lb - chr_idx) << " for sequence " << seq_idx << ':' << chr_idx << " under the given limit.\n";   // (sic: lb - chr_idx, :181)
 					recheck = true;
 				}
 			}
 			if (recheck)
 			{
-				output_range(seq_idx, lb, chr_idx, cur);
+				output_range(lb, chr_idx, cur);
 				lb = chr_idx;
 				cur.resize(founders.size());
 				std::iota(cur.begin(), cur.end(), 0);
 				dst_count = compare(cur, c, chr_idx, dst);
-				if (0 == dst_count) not_found(c, seq_idx, chr_idx);
+				if (0 == dst_count) not_found(c, chr_idx);
 			}
 			std::swap(count, dst_count);
 			std::swap(cur, dst);
 			++chr_idx;
 		}
-		if (0 == count) { if (chr_idx) not_found(sequence[chr_idx - 1], seq_idx, chr_idx); }
-		else output_range(seq_idx, lb, chr_idx, cur);
+		if (0 == count) { if (chr_idx) not_found(sequence[chr_idx - 1], chr_idx); }
+		else output_range(lb, chr_idx, cur);
+		rep.out = out.str();
+		rep.err = err.str();
+	};
+	std::atomic<size_t> next{0};
+	std::mutex reading;
+	auto worker = [&] {
+		for (size_t seq_idx; (seq_idx = next.fetch_add(1)) < paths.size();)
+		{
+			std::string sequence;
+			bool ok;
+			{ std::lock_guard<std::mutex> one_reader(reading); ok = aux::read_file(paths[seq_idx], sequence); }
+			if (!ok) { reports[seq_idx].unreadable = true; continue; }
+			match_sequence_and_report(sequence, seq_idx, reports[seq_idx]);
+		}
+	};
+	size_t n_threads = single_threaded ? 1 : std::max<size_t>(1, std::thread::hardware_concurrency());
+	n_threads = std::min(n_threads, std::max<size_t>(1, paths.size()));
+	if (1 == n_threads) worker();
+	else
+	{
+		std::vector<std::thread> pool;
+		for (size_t t = 0; t < n_threads; ++t) pool.emplace_back(worker);
+		for (auto &t : pool) t.join();
+	}
+	for (size_t seq_idx = 0; seq_idx < paths.size(); ++seq_idx)
+	{
+		if (reports[seq_idx].unreadable) { std::cout << std::flush; std::cerr << "Unable to open '" << paths[seq_idx] << "'." << std::endl; return EXIT_FAILURE; }
+		std::cerr << reports[seq_idx].err;
+		std::cout << reports[seq_idx].out;
 	}
 	std::cout << std::flush;
 	return EXIT_SUCCESS;

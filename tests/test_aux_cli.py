@@ -158,9 +158,13 @@ def test_match_founder_sequences(tools, tmp_path, min_len, fmt):
         (tmp_path / "founders.in").write_bytes(b"".join(f + b"\n" for f in founders))
     else:
         (tmp_path / "founders.in").write_bytes(b"".join(b">f%d\n" % i + f[:150] + b"\n" + f[150:] + b"\n" for i, f in enumerate(founders)))
-    r = subprocess.run([tools["match_founder_sequences"], "--sequences", str(tmp_path / "seqs.txt"), "--founders", str(tmp_path / "founders.in"),
-                        "--founders-format", fmt, "--min-segment-length", str(min_len), "--single-threaded"], capture_output=True, timeout=120)
+    cmd = [tools["match_founder_sequences"], "--sequences", str(tmp_path / "seqs.txt"), "--founders", str(tmp_path / "founders.in"),
+           "--founders-format", fmt, "--min-segment-length", str(min_len)]
+    r = subprocess.run(cmd + ["--single-threaded"], capture_output=True, timeout=120)
     assert r.returncode == 0, r.stderr
+    # one task per sequence on the host's threads (match_founder_sequences.cc:218-252): the same report, in input order
+    rt = subprocess.run(cmd, capture_output=True, timeout=120)
+    assert rt.returncode == 0 and rt.stdout == r.stdout and rt.stderr == r.stderr
     lines = r.stdout.decode().split("\n")
     assert lines[0] == "SEQUENCE_INDEX\tLB\tRB\tFOUNDER_INDICES" and lines[-1] == ""
     want, errs = [], 0
