@@ -7,6 +7,7 @@ whether the reference would give up (FSEQ_E_NO_REDUCTION, generate_context.cc:19
 
     python tools/diversity_sweep.py > profiles/r04_diversity_sweep.txt
     python tools/diversity_sweep.py C3 --quick      # fewer points
+    python tools/diversity_sweep.py C4 --K=64,1024,4096 --mu=5e-5,1e-3      # chosen points (C4's shape with more founders)
 """
 import importlib
 import json
@@ -36,6 +37,11 @@ def main():
         mus = [1e-4, 1e-3, 1e-2]
         if quick:
             Ks, mus = [w["K"], 1024], [1e-4, 1e-2]
+        for a in sys.argv[1:]:                                     # chosen points: --K=64,4096 --mu=5e-5
+            if a.startswith("--K="):
+                Ks = [int(x) for x in a[4:].split(",")]
+            if a.startswith("--mu="):
+                mus = [float(x) for x in a[5:].split(",")]
         base_ms = None
         for K in Ks:
             for mu in mus:
