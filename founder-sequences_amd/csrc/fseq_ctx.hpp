@@ -463,6 +463,8 @@ inline int dev_alloc(fseq_ctx *c, U **p, size_t count)
 		*p = nullptr;
 		size_t free_b = 0, total_b = 0;
 		(void) hipMemGetInfo(&free_b, &total_b);
+		(void) hipGetLastError();          // the runtime remembers the failure: the checks behind later launches (of this or any
+		                                   // other context of the thread) must not find it
 		char what[160];
 		snprintf(what, sizeof(what), "hipMalloc of %zu bytes (%zu of %zu bytes free on the device)", bytes, free_b, total_b);
 		return fail(c, e == hipErrorOutOfMemory ? FSEQ_E_OOM : FSEQ_E_HIP, what, e);
