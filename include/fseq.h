@@ -34,7 +34,9 @@ enum {
 	FSEQ_E_ARG          = 1,   /* bad argument / call order */
 	FSEQ_E_NO_REDUCTION = 2,   /* max segment size >= m: generate_context.cc:192-200 */
 	FSEQ_E_HIP          = 3,   /* HIP runtime error, see fseq_last_error */
-	FSEQ_E_OOM          = 4,
+	FSEQ_E_OOM          = 4,   /* a device (or pinned host) allocation failed; fseq_last_error has the sizes.  Typically the
+	                            * per-column lists of a very diverse input: n x (X + 3) x 8 bytes at list capacity X (DESIGN.md
+	                            * section 7).  Nothing was written; other contexts of the process are not affected */
 	FSEQ_E_UNSUPPORTED  = 5,   /* shape outside what this build's kernels cover (fails loudly, no CPU fallback) */
 	FSEQ_E_PEER         = 6    /* sharded run: another rank failed; every rank returns from the same exchange */
 };
